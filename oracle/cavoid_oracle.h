@@ -1,0 +1,67 @@
+/* CPU ORACLE (test infrastructure, NOT product code) -- see cavoid_oracle.c.
+ * PARITY UNPINNED for the env half: the env source is absent from /root/reference
+ * (.gitmodules:1-3, empty submodule); this restates the published algorithm.  */
+#ifndef CAVOID_ORACLE_H
+#define CAVOID_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_MAX_ACTIONS 32
+#define ORACLE_MAX_AGENTS 64
+
+typedef struct oracle_cfg {
+    double dt, near_goal_threshold, max_time_ratio, collision_dist, getting_close_range;
+    double reward_at_goal, reward_collision, reward_getting_close, reward_time_step;
+    double sensing_horizon, close_penalty_slope, max_turn_rate, reward_clip_lo, reward_clip_hi;
+    int32_t max_agents;        /* N */
+    int32_t max_other;         /* M */
+    int32_t sort_method;       /* 0 closest_last, 1 closest_first, 2 time_to_impact */
+    int32_t actions_fp32;
+    int32_t timeout_enabled;
+    int32_t dynamics;          /* 0 unicycle, 1 unicycle max-turn-rate, 2 holonomic */
+    int32_t num_actions;
+    int32_t _pad;
+    double actions[ORACLE_MAX_ACTIONS][2];
+} oracle_cfg;
+
+typedef struct oracle_gen {
+    int32_t min_agents, max_agents;
+    double nonlearning_fraction, static_fraction, goal_jitter, angle_jitter;
+} oracle_gen;
+
+/* SoA over A = W*N agents, agent a = w*N + i */
+typedef struct oracle_state {
+    double *px, *py, *heading, *t_remaining;
+    float *gx, *gy, *radius, *pref_speed, *speed;
+    uint32_t *flags;
+} oracle_state;
+
+void oracle_default_cfg(oracle_cfg *cfg, int32_t max_agents, int32_t max_other);
+
+/* actions: int32 [W,N] indices (cont == NULL) or float [W,N,2] continuous (cont != NULL).
+ * obs: double [W,N,2+4+7M]; rew: double [W,N]; done: u8 [W,N]; game_over: u8 [W]. */
+void oracle_step(const oracle_cfg *cfg, int64_t W, oracle_state *st, const int32_t *actions,
+                 const float *cont, double *obs, double *rew, uint8_t *done, uint8_t *game_over);
+
+void oracle_observe(const oracle_cfg *cfg, int64_t W, const oracle_state *st, double *obs);
+
+/* GEN v1: regenerate worlds whose mask byte is non-zero (mask == NULL: all).  World w uses the
+ * Philox counter (world_offset + w, episode[w], stream, agent). */
+void oracle_generate(const oracle_cfg *cfg, const oracle_gen *gen, uint64_t seed, int64_t world_offset,
+                     const uint32_t *episode, const uint8_t *mask, int64_t W, oracle_state *st);
+
+/* step, then for every game-over world: episode[w] += 1, regenerate, and overwrite its obs rows
+ * with the fresh episode's first observation (VecEnv auto-reset convention). */
+void oracle_step_autoreset(const oracle_cfg *cfg, const oracle_gen *gen, uint64_t seed, int64_t world_offset,
+                           uint32_t *episode, int64_t W, oracle_state *st, const int32_t *actions,
+                           double *obs, double *rew, uint8_t *done, uint8_t *game_over);
+
+void oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

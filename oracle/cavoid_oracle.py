@@ -1,0 +1,481 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- float64 restatement of the
+multi-agent collision-avoidance ``env.step`` hot path.
+
+    *** PARITY UNPINNED for the env half (E1..E9 of SURVEY.md section 8a). ***
+
+The reference tree ``/root/reference`` ships the GA3C half only; the env package
+``gym_collision_avoidance`` is an empty, un-vendored git submodule
+(``/root/reference/.gitmodules:1-3``; pinned SHA unrecoverable, era ~Mar-Apr 2020 per
+``ga3c/GA3C/Config.py:161-163``).  There is therefore no reference source, golden vector or
+fixture this file can be checked against.  It restates the *published* algorithm of
+``mit-acl/gym-collision-avoidance`` (Everett et al., arXiv:1805.01956 / 1910.11689) anchored on
+the in-tree evidence listed per function below:
+
+  * call sites ............ ga3c/GA3C/Environment.py:54-56,84-86,106,112 ; ProcessAgent.py:124-157
+  * obs layout ............ ga3c/GA3C/Config.py:40-41,66-76 ; NetworkVP_rnn.py:58-61
+  * scalar constants ...... ga3c/GA3C/checkpoints/regression/wandb/run-ws/config.yaml
+                            (DT :43-45, NEAR_GOAL_THRESHOLD :124-126, MAX_TIME_RATIO :115-117,
+                             COLLISION_DIST :31-33, GETTING_CLOSE_RANGE :64-66, REWARD_* :201-221,
+                             AGENT_SORTING_METHOD :9-11, SENSING_HORIZON :249-251)
+  * action table .......... ga3c/GA3C/Server.py:36,51-52 ; Regression.py:157-160 ; Config.py:79
+
+Every semantic that could differ from the true pinned upstream is a named switch in
+:class:`OracleConfig` (the "U" items of SURVEY.md Appendix A) so it can be flipped if the source
+ever becomes available.
+
+Style: deliberately the reference's style -- one ``World`` object, one Python ``Agent`` object
+per agent, Python loops over agents and pairs, NumPy float64 scalars -- so that timing it is a
+fair stand-in for "the reference Python/NumPy env" (baseline B1 of BASELINE.md).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product package must never import it.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# flag bits (shared vocabulary with include/cavoid.h; values restated there, not imported)
+# ----------------------------------------------------------------------------------------------
+F_AT_GOAL = 1 << 0          # Agent.is_at_goal
+F_RAN_OUT = 1 << 1          # Agent.ran_out_of_time
+F_IN_COLL = 1 << 2          # Agent.in_collision
+F_WAS_AT_GOAL = 1 << 3      # Agent.was_at_goal_already
+F_WAS_IN_COLL = 1 << 4      # Agent.was_in_collision_already
+F_PRESENT = 1 << 5          # row holds a real agent (worlds may have fewer than N agents)
+F_LEARNING = 1 << 6         # policy is the external (GA3C) learning policy -> obs col 0
+F_POLICY_SHIFT = 8          # bits 8..9: 0 external/learning, 1 static, 2 non-cooperative
+F_DONE_MASK = F_AT_GOAL | F_RAN_OUT | F_IN_COLL
+
+POLICY_EXTERNAL, POLICY_STATIC, POLICY_NONCOOP = 0, 1, 2
+SORT_CLOSEST_LAST, SORT_CLOSEST_FIRST, SORT_TIME_TO_IMPACT = 0, 1, 2
+DYN_UNICYCLE, DYN_UNICYCLE_MAX_TURN, DYN_HOLONOMIC = 0, 1, 2
+
+
+def build_action_table() -> np.ndarray:
+    """E4 -- the 11-row ``[speed_fraction, delta_heading]`` table of the GA3C-CADRL policy.
+
+    Evidence: ``Server.py:51-52`` (``Actions().num_actions``), ``Config.py:79`` (11),
+    ``Regression.py:157-160`` (column 0 = speed, column 1 = heading change).
+    Rows: 5 headings at full speed (step pi/12 from -pi/6), 3 at half speed and 3 at zero speed
+    (step pi/6).  Values are ``start + k*step`` in float64, i.e. what a NumPy grid produces.
+    """
+    rows = []
+    for frac, step, count in ((1.0, math.pi / 12, 5), (0.5, math.pi / 6, 3), (0.0, math.pi / 6, 3)):
+        for k in range(count):
+            rows.append((frac, -math.pi / 6 + k * step))
+    return np.array(rows, dtype=np.float64)
+
+
+@dataclass
+class OracleConfig:
+    # --- constants recorded in run-ws/config.yaml ---------------------------------------------
+    dt: float = 0.2
+    near_goal_threshold: float = 0.2
+    max_time_ratio: float = 2.0
+    collision_dist: float = 0.0
+    getting_close_range: float = 0.2
+    reward_at_goal: float = 1.0
+    reward_collision: float = -0.25
+    reward_getting_close: float = -0.1
+    reward_time_step: float = 0.0
+    sensing_horizon: float = math.inf
+    sort_method: int = SORT_CLOSEST_LAST
+    # --- sizes (Config.py:34-49) ---------------------------------------------------------------
+    max_agents: int = 4                  # MAX_NUM_AGENTS_IN_ENVIRONMENT (N)
+    max_other_agents_observed: int = 3   # MAX_NUM_OTHER_AGENTS_OBSERVED (M)
+    # --- U-switches ------------------------------------------------------
+    close_penalty_slope: float = -0.5    # U5: r = reward_getting_close + slope*gap  (-0.5 code / +0.5 paper)
+    actions_fp32: bool = True            # joint action array is float32 in the env's _take_action
+    timeout_enabled: bool = True         # U1
+    dynamics: int = DYN_UNICYCLE         # U3
+    max_turn_rate: float = 3.0           # rad/s, only DYN_UNICYCLE_MAX_TURN
+    # min/max of the env's list of possible reward values; rewards are clipped into it
+    reward_clip_lo: float = -0.25
+    reward_clip_hi: float = 1.0
+    actions: np.ndarray = field(default_factory=build_action_table)
+
+    @property
+    def obs_width(self) -> int:          # 1 + NN_INPUT_SIZE  (Config.py:66-71)
+        return 2 + 4 + 7 * self.max_other_agents_observed
+
+
+def wrap(angle: float) -> float:
+    """Wrap to [-pi, pi) by repeated +-2*pi (U2: half-open at +pi)."""
+    while angle >= math.pi:
+        angle -= 2.0 * math.pi
+    while angle < -math.pi:
+        angle += 2.0 * math.pi
+    return angle
+
+
+class Agent:
+    """One agent's global-frame state (E5).  ``policy`` picks who chooses its action."""
+
+    def __init__(self, px, py, gx, gy, radius, pref_speed, heading=None, policy=POLICY_EXTERNAL,
+                 cfg: Optional[OracleConfig] = None):
+        cfg = cfg or OracleConfig()
+        self.cfg = cfg
+        self.pos = np.array([px, py], dtype=np.float64)
+        self.goal = np.array([gx, gy], dtype=np.float64)
+        self.vel = np.zeros(2, dtype=np.float64)
+        self.speed = 0.0
+        self.radius = float(radius)
+        self.pref_speed = float(pref_speed)
+        if heading is None:
+            to_goal = self.goal - self.pos
+            heading = math.atan2(to_goal[1], to_goal[0])
+        self.heading = float(heading)
+        self.policy = policy
+        # time budget: MAX_TIME_RATIO x straight-line time, never below one step (run-ws/config.yaml:115-117)
+        dxg, dyg = float(px) - float(gx), float(py) - float(gy)
+        straight = (math.sqrt(dxg * dxg + dyg * dyg) - cfg.near_goal_threshold) / self.pref_speed
+        self.t_remaining = max(cfg.max_time_ratio * straight, cfg.dt)
+        self.is_at_goal = False
+        self.was_at_goal_already = False
+        self.in_collision = False
+        self.was_in_collision_already = False
+        self.ran_out_of_time = False
+        self.num_other_agents_observed = 0
+        self.update_ego_frame()
+
+    # -- bookkeeping ---------------------------------------------------------------------------
+    @property
+    def is_learning(self) -> bool:
+        return self.policy == POLICY_EXTERNAL
+
+    @property
+    def is_done(self) -> bool:
+        return self.is_at_goal or self.ran_out_of_time or self.in_collision
+
+    def flags(self) -> int:
+        f = F_PRESENT
+        f |= F_AT_GOAL if self.is_at_goal else 0
+        f |= F_RAN_OUT if self.ran_out_of_time else 0
+        f |= F_IN_COLL if self.in_collision else 0
+        f |= F_WAS_AT_GOAL if self.was_at_goal_already else 0
+        f |= F_WAS_IN_COLL if self.was_in_collision_already else 0
+        f |= F_LEARNING if self.is_learning else 0
+        f |= self.policy << F_POLICY_SHIFT
+        return f
+
+    def set_flags(self, f: int) -> None:
+        self.is_at_goal = bool(f & F_AT_GOAL)
+        self.ran_out_of_time = bool(f & F_RAN_OUT)
+        self.in_collision = bool(f & F_IN_COLL)
+        self.was_at_goal_already = bool(f & F_WAS_AT_GOAL)
+        self.was_in_collision_already = bool(f & F_WAS_IN_COLL)
+        self.policy = (f >> F_POLICY_SHIFT) & 3
+
+    # -- ego frame (E9 host part) --------------------------------------------------------------
+    def update_ego_frame(self) -> None:
+        """x-axis of the ego frame points at the goal (Config.py:72-73 'dist to goal, heading to goal')."""
+        to_goal = self.goal - self.pos
+        self.dist_to_goal = math.sqrt(to_goal[0] * to_goal[0] + to_goal[1] * to_goal[1])
+        if self.dist_to_goal > 1e-8:
+            self.ref_prll = to_goal / self.dist_to_goal
+        else:
+            self.ref_prll = to_goal.copy()
+        self.ref_orth = np.array([-self.ref_prll[1], self.ref_prll[0]])
+        self.heading_ego = wrap(self.heading - math.atan2(self.ref_prll[1], self.ref_prll[0]))
+
+    # -- E5: one dynamics step -----------------------------------------------------------------
+    def take_action(self, action: Sequence[float], dt: float) -> None:
+        """``action`` = [speed, delta_heading] (unicycle) or [vx, vy] (holonomic)."""
+        cfg = self.cfg
+        if self.is_done:
+            # frozen agents neither move nor spend time; latch the 'already' flags
+            if self.is_at_goal:
+                self.was_at_goal_already = True
+            if self.in_collision:
+                self.was_in_collision_already = True
+            self.vel[:] = 0.0
+            self.speed = 0.0
+            return
+        if cfg.dynamics == DYN_HOLONOMIC:
+            vx, vy = float(action[0]), float(action[1])
+            self.speed = math.sqrt(vx * vx + vy * vy)
+            if self.speed > 0.0:
+                self.heading = math.atan2(vy, vx)
+            self.pos += np.array([vx * dt, vy * dt])
+            self.vel[0], self.vel[1] = vx, vy
+        else:
+            speed = float(action[0])
+            dh = float(action[1])
+            if cfg.dynamics == DYN_UNICYCLE_MAX_TURN:
+                rate = min(max(dh / dt, -cfg.max_turn_rate), cfg.max_turn_rate)
+                dh = rate * dt
+            new_heading = wrap(dh + self.heading)
+            c, s = math.cos(new_heading), math.sin(new_heading)
+            self.pos += np.array([speed * c * dt, speed * s * dt])
+            self.vel[0], self.vel[1] = speed * c, speed * s
+            self.speed = speed
+            self.heading = new_heading
+        self.update_ego_frame()
+        d = self.pos - self.goal
+        self.is_at_goal = bool(d[0] * d[0] + d[1] * d[1] <= cfg.near_goal_threshold * cfg.near_goal_threshold)
+        self.t_remaining -= dt
+        if cfg.timeout_enabled and self.t_remaining <= 0.0:
+            self.ran_out_of_time = True
+
+
+def time_to_impact(host: Agent, other: Agent) -> float:
+    """U8 -- first time the relative motion brings the two discs into contact (inf if never,
+    0 if already overlapping).  Ray/disc first-hit of v_rel = v_host - v_other against the
+    combined radius; stated here in closed form."""
+    rx, ry = other.pos[0] - host.pos[0], other.pos[1] - host.pos[1]
+    vx, vy = host.vel[0] - other.vel[0], host.vel[1] - other.vel[1]
+    R = host.radius + other.radius
+    c = rx * rx + ry * ry - R * R
+    if c <= 0.0:
+        return 0.0
+    a = vx * vx + vy * vy
+    b = rx * vx + ry * vy            # closing speed x distance
+    if a < 1e-10 or b <= 0.0:
+        return math.inf
+    disc = b * b - a * c
+    if disc < 0.0:
+        return math.inf
+    return (b - math.sqrt(disc)) / a
+
+
+class World:
+    """One simulated world = what one reference ``CollisionAvoidanceEnv`` instance holds."""
+
+    def __init__(self, agents: List[Agent], cfg: Optional[OracleConfig] = None):
+        self.cfg = cfg or (agents[0].cfg if agents else OracleConfig())
+        self.agents = agents
+        assert len(agents) <= self.cfg.max_agents
+
+    # -- E4: decode ----------------------------------------------------------------------------
+    def _decode(self, agent: Agent, action_index: int) -> np.ndarray:
+        raw = self.cfg.actions[int(action_index)]
+        return np.array([agent.pref_speed * raw[0], raw[1]])
+
+    def _policy_action(self, agent: Agent) -> np.ndarray:
+        if agent.policy == POLICY_STATIC:
+            return np.array([0.0, 0.0])
+        # non-cooperative: full preferred speed straight at the goal
+        return np.array([agent.pref_speed, -agent.heading_ego])
+
+    # -- E3: the whole step ----------------------------------------------------------------------
+    def step(self, actions, continuous: bool = False):
+        """``actions``: dict/sequence ``agent index -> action index`` for the learning agents
+        (ProcessAgent.py:124,144,149), or with ``continuous=True`` ``agent index -> (a0, a1)``.
+
+        Returns ``(obs[N, 1+D] f64, rewards[n] f64, game_over bool, info)`` where ``info`` has
+        the two dicts ProcessAgent.py:155-157 reads."""
+        cfg = self.cfg
+        n = len(self.agents)
+        dtype = np.float32 if cfg.actions_fp32 else np.float64
+        joint = np.zeros((n, 2), dtype=dtype)
+        for i, ag in enumerate(self.agents):
+            if ag.is_done:
+                continue
+            if ag.policy == POLICY_EXTERNAL:
+                a = actions[i]
+                joint[i, :] = np.asarray(a, dtype=np.float64) if continuous else self._decode(ag, a)
+            else:
+                joint[i, :] = self._policy_action(ag)
+        for i, ag in enumerate(self.agents):
+            ag.take_action(joint[i, :], cfg.dt)
+        rewards = self._compute_rewards()
+        obs = self.observe()
+        done = {i: ag.is_done for i, ag in enumerate(self.agents)}
+        learning = {i: ag.is_learning for i, ag in enumerate(self.agents)}
+        learners = [ag.is_done for ag in self.agents if ag.is_learning]
+        game_over = bool(np.all(learners))       # TRAIN_MODE: every *learning* agent done
+        return obs, rewards, game_over, {"which_agents_done": done, "which_agents_learning": learning}
+
+    # -- E6: pairwise gaps / collisions ----------------------------------------------------------
+    def _check_for_collisions(self) -> Tuple[List[bool], List[float]]:
+        n = len(self.agents)
+        hit = [False] * n
+        min_gap = [math.inf] * n
+        for i in range(n):
+            for j in range(i + 1, n):
+                a, b = self.agents[i], self.agents[j]
+                dx, dy = a.pos[0] - b.pos[0], a.pos[1] - b.pos[1]
+                d = math.sqrt(dx * dx + dy * dy)
+                gap = d - (a.radius + b.radius)
+                min_gap[i] = min(min_gap[i], gap)
+                min_gap[j] = min(min_gap[j], gap)
+                if gap <= self.cfg.collision_dist:
+                    hit[i] = hit[j] = True
+        return hit, min_gap
+
+    # -- E7: rewards (+ in_collision latch) ------------------------------------------------------
+    def _compute_rewards(self) -> np.ndarray:
+        cfg = self.cfg
+        hit, min_gap = self._check_for_collisions()
+        rewards = cfg.reward_time_step * np.ones(len(self.agents))
+        for i, ag in enumerate(self.agents):
+            if ag.is_at_goal:
+                if not ag.was_at_goal_already:
+                    rewards[i] = cfg.reward_at_goal          # paid once
+            elif not ag.was_in_collision_already:
+                if hit[i]:
+                    rewards[i] = cfg.reward_collision
+                    ag.in_collision = True
+                elif min_gap[i] <= cfg.getting_close_range:
+                    rewards[i] = cfg.reward_getting_close + cfg.close_penalty_slope * min_gap[i]
+        return np.clip(rewards, cfg.reward_clip_lo, cfg.reward_clip_hi)
+
+    # -- E9: sensing + observation assembly ------------------------------------------------------
+    def _sense_others(self, hi: int) -> np.ndarray:
+        cfg = self.cfg
+        host = self.agents[hi]
+        M = cfg.max_other_agents_observed
+        crit = []
+        for j, other in enumerate(self.agents):
+            if j == hi:
+                continue
+            rel = other.pos - host.pos
+            d = math.sqrt(rel[0] * rel[0] + rel[1] * rel[1])
+            if d > cfg.sensing_horizon:
+                continue
+            gap = d - host.radius - other.radius
+            p_orth = rel[0] * host.ref_orth[0] + rel[1] * host.ref_orth[1]
+            tti = time_to_impact(host, other) if cfg.sort_method == SORT_TIME_TO_IMPACT else 0.0
+            # U7: gap rounded to centimetres, lateral offset breaks ties
+            crit.append((j, np.rint(gap * 100.0) / 100.0, p_orth, tti))
+        if cfg.sort_method == SORT_TIME_TO_IMPACT:
+            far_to_near = sorted(crit, key=lambda c: (-c[3], -c[1], c[2]))
+        else:
+            far_to_near = sorted(crit, key=lambda c: (-c[1], c[2]))
+        kept = far_to_near[-M:] if M > 0 else []
+        if cfg.sort_method == SORT_CLOSEST_FIRST:
+            kept = sorted(kept, key=lambda c: (c[1], c[2]))
+        out = np.zeros((M, 7), dtype=np.float64)
+        for slot, (j, _, _, _) in enumerate(kept):
+            other = self.agents[j]
+            rel = other.pos - host.pos
+            p_prll = rel[0] * host.ref_prll[0] + rel[1] * host.ref_prll[1]
+            p_orth = rel[0] * host.ref_orth[0] + rel[1] * host.ref_orth[1]
+            v_prll = other.vel[0] * host.ref_prll[0] + other.vel[1] * host.ref_prll[1]
+            v_orth = other.vel[0] * host.ref_orth[0] + other.vel[1] * host.ref_orth[1]
+            gap = math.sqrt(rel[0] * rel[0] + rel[1] * rel[1]) - host.radius - other.radius
+            out[slot] = (p_prll, p_orth, v_prll, v_orth, other.radius, host.radius + other.radius, gap)
+        host.num_other_agents_observed = len(kept)
+        return out
+
+    def observe(self) -> np.ndarray:
+        """``[N_max, 1+D]``; rows of absent agents are zero so ``is_learning == 0``
+        (Environment.py:84-86, ProcessAgent.py:130-133)."""
+        cfg = self.cfg
+        obs = np.zeros((cfg.max_agents, cfg.obs_width), dtype=np.float64)
+        for i, ag in enumerate(self.agents):
+            ag.update_ego_frame()
+            others = self._sense_others(i)
+            obs[i, 0] = 1.0 if ag.is_learning else 0.0
+            obs[i, 1] = ag.num_other_agents_observed
+            obs[i, 2] = ag.dist_to_goal
+            obs[i, 3] = ag.heading_ego
+            obs[i, 4] = ag.pref_speed
+            obs[i, 5] = ag.radius
+            obs[i, 6:] = others.reshape(-1)
+        return obs
+
+
+# ----------------------------------------------------------------------------------------------
+# Scenario generator "GEN v1" (E2).  The upstream random test-case generator and its np.random
+# stream are unknowable here, so the build defines its own counter-based
+# generator; this is its specification.  Philox4x32-10 (Salmon et al., SC'11), counter =
+# (global world id, episode index, stream, agent index), key = 64-bit seed.
+# ----------------------------------------------------------------------------------------------
+_PHILOX_M0, _PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+_MASK32 = 0xFFFFFFFF
+
+
+def philox4x32(c0: int, c1: int, c2: int, c3: int, k0: int, k1: int) -> Tuple[int, int, int, int]:
+    for _ in range(10):
+        p0 = _PHILOX_M0 * c0
+        p1 = _PHILOX_M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & _MASK32, p1 & _MASK32, ((p0 >> 32) ^ c3 ^ k1) & _MASK32, p0 & _MASK32
+        k0 = (k0 + _PHILOX_W0) & _MASK32
+        k1 = (k1 + _PHILOX_W1) & _MASK32
+    return c0, c1, c2, c3
+
+
+def _u01(r: int) -> float:
+    """24-bit uniform in [0,1): exact in float32 and float64."""
+    return (r >> 8) * (1.0 / 16777216.0)
+
+
+@dataclass
+class GenConfig:
+    min_agents: int = 4
+    max_agents: int = 4
+    nonlearning_fraction: float = 0.0     # P(agent i>0 runs a scripted policy)
+    static_fraction: float = 0.5          # of those, P(static) (else non-cooperative)
+    goal_jitter: float = 0.5              # half-width (m) of the uniform jitter on the antipodal goal
+    angle_jitter: float = 0.25            # fraction of the angular slot
+
+
+def generate_world(seed: int, world_id: int, episode: int, cfg: OracleConfig, gen: GenConfig) -> World:
+    """GEN v1: n agents on a circle, goals roughly antipodal (every pair must negotiate the
+    centre).  radius~U(0.2,0.8), pref_speed~U(0.5,2.0) stored as float32 values; start
+    positions stay float64; heading points at the goal; time budget as in ``Agent``."""
+    k0, k1 = seed & _MASK32, (seed >> 32) & _MASK32
+    w = philox4x32(world_id & _MASK32, episode & _MASK32, 0, 0, k0, k1)
+    span = gen.max_agents - gen.min_agents + 1
+    n = gen.min_agents + (w[0] % span)
+    base = max(4.0, 0.7 * n)
+    ring = base * (1.0 + _u01(w[1]))
+    phase = _u01(w[2])
+    agents = []
+    for i in range(n):
+        a = philox4x32(world_id & _MASK32, episode & _MASK32, 1, i, k0, k1)
+        b = philox4x32(world_id & _MASK32, episode & _MASK32, 2, i, k0, k1)
+        radius = float(np.float32(0.2 + 0.6 * _u01(a[0])))
+        pref_speed = float(np.float32(0.5 + 1.5 * _u01(a[1])))
+        turn = phase + (i + (_u01(a[2]) - 0.5) * 2.0 * gen.angle_jitter) / n
+        theta = 2.0 * math.pi * turn
+        px, py = ring * math.cos(theta), ring * math.sin(theta)
+        gx = float(np.float32(-px + (_u01(b[0]) - 0.5) * 2.0 * gen.goal_jitter))
+        gy = float(np.float32(-py + (_u01(b[1]) - 0.5) * 2.0 * gen.goal_jitter))
+        policy = POLICY_EXTERNAL
+        if i > 0 and _u01(b[2]) < gen.nonlearning_fraction:
+            policy = POLICY_STATIC if _u01(b[3]) < gen.static_fraction else POLICY_NONCOOP
+        agents.append(Agent(px, py, gx, gy, radius, pref_speed, None, policy, cfg))
+    return World(agents, cfg)
+
+
+# ----------------------------------------------------------------------------------------------
+# flat-array helpers: the same SoA record the C oracle and the HIP library exchange
+# ----------------------------------------------------------------------------------------------
+STATE_F64_FIELDS = ("px", "py", "heading", "t_remaining")
+STATE_F32_FIELDS = ("gx", "gy", "radius", "pref_speed", "speed")
+
+
+def world_to_arrays(world: World):
+    N = world.cfg.max_agents
+    f64 = np.zeros((4, N), dtype=np.float64)
+    f32 = np.zeros((5, N), dtype=np.float32)
+    flags = np.zeros(N, dtype=np.uint32)
+    for i, ag in enumerate(world.agents):
+        f64[:, i] = (ag.pos[0], ag.pos[1], ag.heading, ag.t_remaining)
+        f32[:, i] = (ag.goal[0], ag.goal[1], ag.radius, ag.pref_speed, ag.speed)
+        flags[i] = ag.flags()
+    return f64, f32, flags
+
+
+def world_from_arrays(f64, f32, flags, cfg: OracleConfig) -> World:
+    agents = []
+    for i in range(cfg.max_agents):
+        f = int(flags[i])
+        if not f & F_PRESENT:
+            break
+        ag = Agent(f64[0, i], f64[1, i], float(f32[0, i]), float(f32[1, i]), float(f32[2, i]),
+                   float(f32[3, i]), float(f64[2, i]), (f >> F_POLICY_SHIFT) & 3, cfg)
+        ag.t_remaining = float(f64[3, i])
+        ag.set_flags(f)
+        ag.speed = float(f32[4, i])
+        ag.vel[:] = (ag.speed * math.cos(ag.heading), ag.speed * math.sin(ag.heading))
+        agents.append(ag)
+    return World(agents, cfg)

@@ -1,0 +1,197 @@
+"""CPU tests of the oracle itself: the reference-style Python statement (oracle/cavoid_oracle.py)
+and the batched C statement (oracle/cavoid_oracle.c) must agree BIT-FOR-BIT (same libm, no FMA),
+plus analytic known-answer tests.  The env half is parity-unpinned:
+nothing here can be compared with the absent reference env source."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import cavoid_oracle as po
+
+
+def _cross(N, M, sort, nonl, W=12, steps=100, seed=7, dyn=0):
+    pcfg = po.OracleConfig(max_agents=N, max_other_agents_observed=M, sort_method=sort, dynamics=dyn)
+    pgen = po.GenConfig(min_agents=2, max_agents=N, nonlearning_fraction=nonl)
+    ccfg = co.default_cfg(N, M, sort_method=sort, dynamics=dyn)
+    cgen = co.default_gen(2, N, nonl)
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(ccfg, cgen, seed, st, ep)
+    worlds = [po.generate_world(seed, w, 0, pcfg, pgen) for w in range(W)]
+    for w, wd in enumerate(worlds):
+        f64, f32, fl = po.world_to_arrays(wd)
+        sl = slice(w * N, (w + 1) * N)
+        assert np.array_equal(f64, st.f64[:, sl]) and np.array_equal(f32, st.f32[:, sl]) and np.array_equal(fl, st.flags[sl])
+    o0 = co.observe(ccfg, st)
+    for w, wd in enumerate(worlds):
+        assert np.array_equal(wd.observe(), o0[w])
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = rng.integers(0, 11, size=(W, N))
+        obs, rew, done, go = co.step(ccfg, st, acts)
+        for w, wd in enumerate(worlds):
+            n = len(wd.agents)
+            pobs, prew, pgo, info = wd.step({i: acts[w, i] for i in range(n)})
+            assert np.array_equal(pobs, obs[w]), (t, w)
+            assert np.array_equal(prew, rew[w, :n])
+            assert pgo == bool(go[w])
+            assert [info["which_agents_done"][i] for i in range(n)] == list(done[w, :n].astype(bool))
+            assert np.all(done[w, n:] == 1) and np.all(rew[w, n:] == 0)
+            f64, f32, fl = po.world_to_arrays(wd)
+            sl = slice(w * N, (w + 1) * N)
+            assert np.array_equal(f64, st.f64[:, sl]) and np.array_equal(fl, st.flags[sl])
+            assert np.array_equal(f32, st.f32[:, sl])
+    return st
+
+
+@pytest.mark.parametrize("N,M,sort,nonl", [(4, 3, 0, 0.0), (4, 3, 1, 0.5), (10, 9, 0, 0.3), (10, 4, 1, 0.3),
+                                           (6, 7, 2, 0.2), (2, 1, 0, 0.0), (10, 9, 2, 0.0)])
+def test_python_and_c_statements_agree_bitwise(N, M, sort, nonl):
+    st = _cross(N, M, sort, nonl)
+    present = st.flags & po.F_PRESENT != 0
+    assert (st.flags[present] & po.F_DONE_MASK != 0).mean() > 0.3      # episodes actually terminate
+
+
+def test_python_and_c_agree_max_turn_rate():
+    _cross(4, 3, 0, 0.0, dyn=po.DYN_UNICYCLE_MAX_TURN, steps=40)
+
+
+def test_action_table():
+    t = po.build_action_table()
+    assert t.shape == (11, 2)
+    assert list(t[:, 0]) == [1.0] * 5 + [0.5] * 3 + [0.0] * 3
+    np.testing.assert_allclose(t[:5, 1], np.array([-2, -1, 0, 1, 2]) * math.pi / 12, atol=1e-15)
+    np.testing.assert_allclose(t[5:8, 1], np.array([-1, 0, 1]) * math.pi / 6, atol=1e-15)
+    c = co.default_cfg(4)
+    assert np.array_equal(np.array([[c.actions[r][0], c.actions[r][1]] for r in range(11)]), t)
+
+
+def test_philox_known_answers():
+    # Random123 known-answer vectors for philox4x32-10
+    assert po.philox4x32(0, 0, 0, 0, 0, 0) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    f = 0xFFFFFFFF
+    assert po.philox4x32(f, f, f, f, f, f) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert po.philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0) == (
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+
+
+def _two_agents(cfg, d=10.0, r=0.5, v=1.0):
+    a = po.Agent(-d / 2, 0.0, d / 2, 0.0, r, v, None, po.POLICY_EXTERNAL, cfg)
+    b = po.Agent(d / 2, 0.0, -d / 2, 0.0, r, v, None, po.POLICY_EXTERNAL, cfg)
+    return po.World([a, b], cfg)
+
+
+def test_head_on_collision_step_index_and_reward():
+    cfg = po.OracleConfig(max_agents=2, max_other_agents_observed=1)
+    w = _two_agents(cfg, d=10.0, r=0.5, v=1.0)
+    # closing speed 2 m/s, gap 9 m, 0.4 m per step -> overlap first at step ceil(9/0.4) = 23
+    for k in range(1, 40):
+        obs, rew, over, info = w.step({0: 2, 1: 2})
+        if k < 22:
+            assert not over and np.all(rew == 0.0)
+        if k == 22:      # gap = 9 - 8.8 = 0.2 -> getting-close term -0.1 - gap/2
+            gap = obs[0, 6 + 6]
+            assert abs(gap - 0.2) < 1e-9 and not over
+            if gap <= 0.2:
+                np.testing.assert_allclose(rew, -0.1 - gap / 2, atol=1e-12)
+        if over:
+            break
+    assert k == 23 and np.all(rew == -0.25)
+    assert info["which_agents_done"] == {0: True, 1: True}
+    # frozen afterwards: zero reward, zero velocity, no time spent
+    t_before = [a.t_remaining for a in w.agents]
+    obs, rew, over, info = w.step({0: 2, 1: 2})
+    assert np.all(rew == 0.0) and over
+    assert [a.t_remaining for a in w.agents] == t_before
+    assert np.all(obs[:, 6 + 2:6 + 4] == 0.0)
+
+
+def test_goal_reached_step_count_and_single_reward():
+    cfg = po.OracleConfig(max_agents=2, max_other_agents_observed=1)
+    # two agents far apart laterally so they never interact
+    a = po.Agent(0.0, 0.0, 5.05, 0.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+    b = po.Agent(0.0, 50.0, 5.05, 50.0, 0.3, 0.5, None, po.POLICY_EXTERNAL, cfg)
+    w = po.World([a, b], cfg)
+    hit = {}
+    for k in range(1, 200):
+        obs, rew, over, info = w.step({0: 2, 1: 2})
+        for i in (0, 1):
+            if rew[i] == 1.0:
+                assert i not in hit
+                hit[i] = k
+        if over:
+            break
+    # reach when 5.05 - v*dt*k <= 0.2  ->  k = ceil(4.85 / (v*0.2))  (kept off the exact threshold)
+    assert hit == {0: 25, 1: 49}
+    obs, rew, over, info = w.step({0: 2, 1: 2})
+    assert np.all(rew == 0.0)       # goal reward is paid once
+
+
+def test_timeout():
+    cfg = po.OracleConfig(max_agents=2, max_other_agents_observed=1)
+    a = po.Agent(0.0, 0.0, 5.05, 0.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+    b = po.Agent(0.0, 50.0, 5.05, 50.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+    w = po.World([a, b], cfg)
+    budget = 2.0 * (5.05 - 0.2) / 1.0        # 9.7 s = 48.5 steps (kept off the exact threshold)
+    assert a.t_remaining == pytest.approx(budget)
+    for k in range(1, 200):        # action 9 = zero speed: never arrives
+        obs, rew, over, info = w.step({0: 9, 1: 9})
+        if over:
+            break
+    assert k == 49 == math.ceil(budget / 0.2)
+    assert all(ag.ran_out_of_time and not ag.is_at_goal for ag in w.agents)
+
+
+def test_obs_layout_and_sorting():
+    cfg = po.OracleConfig(max_agents=4, max_other_agents_observed=3)
+    host = po.Agent(0.0, 0.0, 10.0, 0.0, 0.5, 1.0, None, po.POLICY_EXTERNAL, cfg)
+    near = po.Agent(2.0, 0.0, -10.0, 0.0, 0.5, 1.0, None, po.POLICY_EXTERNAL, cfg)
+    far = po.Agent(0.0, 6.0, 0.0, -10.0, 0.25, 1.0, None, po.POLICY_NONCOOP, cfg)
+    w = po.World([host, near, far], cfg)
+    obs = w.observe()
+    assert obs.shape == (4, 27)
+    assert obs[0, 0] == 1.0 and obs[2, 0] == 0.0 and np.all(obs[3] == 0.0)
+    assert obs[0, 1] == 2 and obs[0, 2] == 10.0 and obs[0, 3] == 0.0 and obs[0, 4] == 1.0 and obs[0, 5] == 0.5
+    # closest_last: far agent in slot 0, near agent in slot 1 (the last filled), slot 2 zero
+    np.testing.assert_allclose(obs[0, 6:13], [0.0, 6.0, 0.0, 0.0, 0.25, 0.75, 5.25])
+    np.testing.assert_allclose(obs[0, 13:20], [2.0, 0.0, 0.0, 0.0, 0.5, 1.0, 1.0])
+    assert np.all(obs[0, 20:] == 0.0)
+    cfg2 = po.OracleConfig(max_agents=4, max_other_agents_observed=3, sort_method=po.SORT_CLOSEST_FIRST)
+    for ag in w.agents:
+        ag.cfg = cfg2
+    obs2 = po.World(w.agents, cfg2).observe()
+    np.testing.assert_allclose(obs2[0, 6:13], obs[0, 13:20])
+    np.testing.assert_allclose(obs2[0, 13:20], obs[0, 6:13])
+    # clipping to M=1 keeps the closest
+    cfg3 = po.OracleConfig(max_agents=4, max_other_agents_observed=1)
+    for ag in w.agents:
+        ag.cfg = cfg3
+    obs3 = po.World(w.agents, cfg3).observe()
+    assert obs3.shape == (4, 13) and obs3[0, 1] == 1
+    np.testing.assert_allclose(obs3[0, 6:13], obs[0, 13:20])
+
+
+def test_worlds_are_independent_and_permutation_equivariant():
+    N = 4
+    cfg = co.default_cfg(N)
+    gen = co.default_gen(4, 4)
+    W = 16
+    st = co.State.empty(W, N)
+    co.generate(cfg, gen, 3, st, np.zeros(W, np.uint32))
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 11, size=(W, N))
+    full = st.copy()
+    obs, rew, done, go = co.step(cfg, full, acts)
+    for w in range(W):                              # batch of W == W single-world runs
+        one = co.State(st.f64[:, w * N:(w + 1) * N].copy(), st.f32[:, w * N:(w + 1) * N].copy(), st.flags[w * N:(w + 1) * N].copy())
+        o1, r1, d1, g1 = co.step(cfg, one, acts[w:w + 1])
+        assert np.array_equal(o1[0], obs[w]) and np.array_equal(r1[0], rew[w]) and g1[0] == go[w]
+    perm = np.array([2, 0, 3, 1])                   # permuting agents permutes rows
+    w = 5
+    sl = np.arange(w * N, (w + 1) * N)[perm]
+    one = co.State(st.f64[:, sl].copy(), st.f32[:, sl].copy(), st.flags[sl].copy())
+    o1, r1, d1, g1 = co.step(cfg, one, acts[w:w + 1, perm])
+    assert np.array_equal(r1[0], rew[w][perm]) and np.array_equal(d1[0], done[w][perm])
+    np.testing.assert_allclose(o1[0][:, :6], obs[w][perm][:, :6], rtol=0, atol=0)
