@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py -- agent-steps/s of the batched env.step hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path (cavoid_step_autoreset: decode, dynamics, pairwise sensing,
+rewards, done flags, sorted observation, in-kernel restart of finished worlds) over one batch of
+synthetic worlds: BASELINE configs[1], 4 agents x 8192 worlds per GPU, unicycle dynamics, random
+actions pre-generated on the device.  Weak scaling: every rank steps its own 8192 worlds (RNG
+keyed on global world ids); no data-path collective (the obs all-gather of configs[2] is
+measured separately with --gather).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def algorithmic_bytes_per_agent_step(M: int) -> int:
+    """fp32 words -- state read 11 + action 1 + state write 7 + obs (2+4+7M)
+    + reward 1 + done 1.  192 B at M=3, 360 B at M=9."""
+    return 4 * (11 + 1 + 7 + (6 + 7 * M) + 1 + 1)
+
+
+def cpu_baseline(N: int, W: int, budget_s: float):
+    """The C float64 oracle (a port/restatement -- the reference env source is absent) timed on this
+    box's host cores, 1 thread, on the same workload shape, for about `budget_s` seconds."""
+    import numpy as np
+    from oracle import c_oracle as co
+    cfg, gen = co.default_cfg(N), co.default_gen(N, N)
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(cfg, gen, 0, st, ep)
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 11, size=(16, W, N)).astype(np.int32)
+    co.step_autoreset(cfg, gen, 0, st, ep, acts[0])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        co.step_autoreset(cfg, gen, 0, st, ep, acts[n % 16])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {"value": W * N * n / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": "C float64 oracle (oracle/cavoid_oracle.c), %d agents x %d worlds, %d autoreset steps, %.1f s, 1 thread"
+                      % (N, W, n, dt)}
+
+
+def python_baseline(N: int, budget_s: float):
+    """Reference-style per-object Python/NumPy oracle, one world, one process (baseline B1)."""
+    import numpy as np
+    from oracle import cavoid_oracle as po
+    cfg = po.OracleConfig(max_agents=N, max_other_agents_observed=N - 1)
+    gen = po.GenConfig(min_agents=N, max_agents=N)
+    rng = np.random.default_rng(0)
+    steps, ep, t0 = 0, 0, time.perf_counter()
+    world = po.generate_world(0, 0, ep, cfg, gen)
+    while time.perf_counter() - t0 < budget_s:
+        _, _, over, _ = world.step({i: int(rng.integers(0, 11)) for i in range(N)})
+        steps += 1
+        if over:
+            ep += 1
+            world = po.generate_world(0, 0, ep, cfg, gen)
+    dt = time.perf_counter() - t0
+    return {"value": steps * N / dt, "unit": "agent-steps/s", "cores": 1,
+            "sample": "oracle/cavoid_oracle.py, 1 world x %d agents, %d steps" % (N, steps)}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--worlds", type=int, default=8192, help="worlds per GPU")
+    ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--slices", type=int, default=64, help="distinct pre-generated action slices")
+    ap.add_argument("--gather", action="store_true", help="also time the per-step RCCL all-gather of (obs,reward,done)")
+    ap.add_argument("--sweep", action="store_true", help="add a worlds-per-GPU saturation sweep to the JSON line")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+
+    rank = int(os.environ.get("RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world_size))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    N, W = args.agents, args.worlds
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    def make(Wl):
+        env = BatchedCollisionAvoidanceEnv(Wl, Cfg(), device=device, world_offset=rank * Wl, seed=1000 * 0 + 7)
+        g = torch.Generator(device=device)
+        g.manual_seed(1234 + rank)
+        acts = torch.randint(0, env.num_actions, (args.slices, Wl, N), generator=g, device=device, dtype=torch.int32)
+        env.reset()
+        return env, acts
+
+    def run_steps(env, acts, k):
+        T = acts.shape[0]
+        done = 0
+        while done < k:
+            n = min(T, k - done)
+            env.step_autoreset_n(acts, n)
+            done += n
+
+    env, acts = make(W)
+    run_steps(env, acts, args.warmup)
+
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks -------
+    sync_all()
+    t0 = time.perf_counter()
+    env.timer_begin()
+    run_steps(env, acts, args.steps)
+    stream_ms = env.timer_end()          # HIP events on the launch stream (includes launch gaps)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world_size * W * N * args.steps / elapsed
+
+    # ---- roofline of the dominant (only) kernel: per-launch HIP-event durations ---------------------
+    kern_ms = env.kernel_time_ms(acts, args.steps)
+    bytes_per_launch = algorithmic_bytes_per_agent_step(N - 1) * W * N
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "cavoid::env_kernel<%d, MODE_STEP_AUTORESET>" % N,
+                "kernel_us": kern_ms * 1e3, "stream_us_per_step": stream_ms * 1e3 / args.steps,
+                "algorithmic_bytes_per_launch": bytes_per_launch}
+
+    extra = {}
+    if args.gather and world_size > 1:
+        width = env.obs_width
+        packed = torch.empty((W, N, width + 2), dtype=torch.float32, device=device)
+        out = torch.empty((world_size * W, N, width + 2), dtype=torch.float32, device=device)
+        def gather_once():
+            packed[..., :width] = env.obs
+            packed[..., width] = env.rewards
+            packed[..., width + 1] = env.done
+            dist.all_gather_into_tensor(out, packed)
+        for _ in range(20):
+            gather_once()
+        sync_all()
+        tg = time.perf_counter()
+        for _ in range(200):
+            gather_once()
+        sync_all()
+        extra["allgather_ms_per_step"] = (time.perf_counter() - tg) * 1e3 / 200
+        extra["allgather_bytes_per_rank"] = packed.numel() * 4
+
+    if args.sweep and rank == 0:
+        sweep = []
+        for Ws in (1024, 8192, 65536, 262144, 1048576):
+            e2, a2 = make(Ws)
+            run_steps(e2, a2, 50)
+            k_ms = e2.kernel_time_ms(a2, 200)
+            torch.cuda.synchronize(device)
+            gbs = algorithmic_bytes_per_agent_step(N - 1) * Ws * N / (k_ms * 1e-3) / 1e9
+            sweep.append({"worlds": Ws, "kernel_us": k_ms * 1e3, "agent_steps_per_s": Ws * N / (k_ms * 1e-3),
+                          "GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+            e2.close()
+            del e2, a2
+        extra["saturation_sweep"] = sweep
+
+    line = {
+        "metric": "agent-steps/sec (env.step) at %d agents x %d worlds per GPU" % (N, W),
+        "value": value, "unit": "agent-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d agents x %d worlds per GPU, unicycle dynamics, "
+                               "GEN v1 synthetic scenarios, uniform random actions, in-kernel auto-reset" % (N, W),
+                   "worlds_per_gpu": W, "agents_per_world": N, "obs_width": env.obs_width,
+                   "parallelism": "worlds sharded over %d GPU(s), no data-path collective" % world_size},
+        "roofline": roofline,
+    }
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(N, W, args.cpu_seconds)
+        line["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        extra["python_reference_style_baseline"] = python_baseline(N, min(3.0, args.cpu_seconds))
+    if extra:
+        line["extra"] = extra
+    env.close()
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

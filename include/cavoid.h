@@ -1,0 +1,159 @@
+/* cavoid.h -- C ABI of the MI355X-native batched collision-avoidance env.step hot path.
+ *
+ * Drop-in boundary.  The reference has NO FFI for this path: the seam is a duck-typed Python
+ * object.  Each entry point below names the reference interface it
+ * stands in for (paths relative to /root/reference):
+ *
+ *   cavoid_create / cavoid_destroy ... `env, one_env = create_env()`            ga3c/GA3C/Environment.py:54-56
+ *   cavoid_reset ..................... `observations = self.game.reset()`        ga3c/GA3C/Environment.py:106
+ *   cavoid_step ...................... `self.game.step(action)` -> 4-tuple        ga3c/GA3C/Environment.py:112
+ *                                      (obs, rewards, game_over, which_agents_done) ga3c/GA3C/ProcessAgent.py:149-157
+ *   cavoid_step_autoreset ............ the per-episode `env.reset()` + step loop  ga3c/GA3C/ProcessAgent.py:105-116
+ *   cavoid_step_continuous ........... the env-level continuous action space      run-ws/config.yaml:3-5 (ACTION_SPACE_TYPE)
+ *   cavoid_observe ................... the obs half of reset()/step()             ga3c/GA3C/Environment.py:81-91
+ *   cavoid_set_state/get_state ....... (new) explicit initial states for parity runs; env checkpointing
+ *   cavoid_default_cfg ............... the env's Config scalars                   ga3c/GA3C/Config.py:29,34-52 +
+ *                                      checkpoints/regression/wandb/run-ws/config.yaml
+ *   cavoid_default_actions ........... `Actions().actions[11,2]`                  ga3c/GA3C/Server.py:36,51-52
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Every data pointer is a DEVICE pointer
+ * on the env's device and is owned by the caller; the library owns only its internal world
+ * buffer.  All work is enqueued asynchronously on the `hipStream_t` passed as `void *stream`
+ * (NULL = the default stream).  Return 0 on success, a negative CAVOID_E* code on failure; the
+ * library never throws, aborts or falls back to a CPU path.  A handle is not thread-safe; use
+ * one per device/stream.
+ *
+ * Layouts (W worlds, N = max_agents, M = max_other, flat agent index a = w*N + i):
+ *   obs        float  [W, N, 2+4+7M]  col0 is_learning, col1 num_other_agents, col2 dist_to_goal,
+ *                                     col3 heading_ego_frame, col4 pref_speed, col5 radius, then M x
+ *                                     [p_par, p_orth, v_par, v_orth, r_other, r_host+r_other, gap]
+ *                                     (ga3c/GA3C/Config.py:40,72-76; NetworkVP_rnn.py:58-61)
+ *   rewards    float  [W, N]
+ *   done       u8     [W, N]          which_agents_done; 1 for absent agents
+ *   game_over  u8     [W]             every *learning* agent of the world is done (TRAIN_MODE)
+ *   actions    int32  [W, N]          index into the action table; ignored for done / scripted agents
+ *   state_f64  double [4, W*N]        px, py, heading, t_remaining           (SoA, field-major)
+ *   state_f32  float  [5, W*N]        gx, gy, radius, pref_speed, speed
+ *   flags      u32    [W*N]           CAVOID_F_* bits
+ */
+#ifndef CAVOID_H
+#define CAVOID_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAVOID_ABI_VERSION 1
+#define CAVOID_MAX_ACTIONS 32
+#define CAVOID_MAX_AGENTS 16
+
+/* agent flag bits */
+#define CAVOID_F_AT_GOAL 0x01u
+#define CAVOID_F_RAN_OUT 0x02u
+#define CAVOID_F_IN_COLL 0x04u
+#define CAVOID_F_WAS_AT_GOAL 0x08u
+#define CAVOID_F_WAS_IN_COLL 0x10u
+#define CAVOID_F_PRESENT 0x20u
+#define CAVOID_F_LEARNING 0x40u
+#define CAVOID_F_POLICY_SHIFT 8 /* bits 8..9: 0 external (learning), 1 static, 2 non-cooperative */
+#define CAVOID_F_DONE_MASK 0x07u
+
+enum { CAVOID_SORT_CLOSEST_LAST = 0, CAVOID_SORT_CLOSEST_FIRST = 1, CAVOID_SORT_TIME_TO_IMPACT = 2 };
+enum { CAVOID_DYN_UNICYCLE = 0, CAVOID_DYN_UNICYCLE_MAX_TURN = 1, CAVOID_DYN_HOLONOMIC = 2 };
+
+enum {
+    CAVOID_OK = 0,
+    CAVOID_EINVAL = -1,    /* bad argument / config */
+    CAVOID_ENOMEM = -2,    /* device allocation failed */
+    CAVOID_EHIP = -3,      /* a HIP runtime call failed (see cavoid_last_hip_error) */
+    CAVOID_EUNSUPPORTED = -4, /* max_agents outside the compiled range */
+    CAVOID_ENODEVICE = -5  /* no usable gfx950 device */
+};
+
+typedef struct cavoid_cfg {
+    uint32_t struct_size;      /* = sizeof(cavoid_cfg); checked by cavoid_create */
+    uint32_t abi_version;      /* = CAVOID_ABI_VERSION */
+    int32_t max_agents;        /* N: MAX_NUM_AGENTS_IN_ENVIRONMENT   (Config.py:34-37) */
+    int32_t max_other;         /* M: MAX_NUM_OTHER_AGENTS_OBSERVED   (Config.py:46-49) */
+    int32_t sort_method;       /* AGENT_SORTING_METHOD               (run-ws/config.yaml:9-11) */
+    int32_t dynamics;          /* CAVOID_DYN_* */
+    int32_t actions_fp32;      /* joint action array is float32 (default 1) */
+    int32_t timeout_enabled;   /* default 1 */
+    int32_t num_actions;       /* NUM_ACTIONS (Config.py:79) */
+    int32_t _pad;
+    double dt;                 /* DT 0.2 */
+    double near_goal_threshold;/* 0.2 */
+    double max_time_ratio;     /* 2.0 */
+    double collision_dist;     /* 0.0 */
+    double getting_close_range;/* 0.2 */
+    double reward_at_goal;     /* 1.0 */
+    double reward_collision;   /* -0.25 */
+    double reward_getting_close;/* -0.1 */
+    double reward_time_step;   /* 0.0 */
+    double close_penalty_slope;/* -0.5: r = reward_getting_close + slope*gap */
+    double reward_clip_lo, reward_clip_hi; /* [-0.25, 1.0] */
+    double sensing_horizon;    /* +inf */
+    double max_turn_rate;      /* 3.0 rad/s (CAVOID_DYN_UNICYCLE_MAX_TURN only) */
+    double actions[CAVOID_MAX_ACTIONS][2]; /* [speed fraction, delta heading] */
+    /* scenario generator "GEN v1" used by cavoid_reset / autoreset */
+    int32_t gen_min_agents, gen_max_agents;
+    double gen_nonlearning_fraction, gen_static_fraction, gen_goal_jitter, gen_angle_jitter;
+} cavoid_cfg;
+
+typedef struct cavoid_env cavoid_env;
+
+int cavoid_abi_version(void);
+const char *cavoid_strerror(int code);
+int cavoid_last_hip_error(void);                /* raw hipError_t of the last CAVOID_EHIP */
+int cavoid_default_cfg(cavoid_cfg *cfg, int32_t max_agents, int32_t max_other);
+int cavoid_default_actions(double (*table)[2], int32_t *num_actions);
+
+/* world_offset: global id of this handle's first world (RNG streams are keyed on global world
+ * ids so that results do not depend on how worlds are sharded over GPUs). */
+int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t world_offset, int device, cavoid_env **out);
+void cavoid_destroy(cavoid_env *env);
+int64_t cavoid_num_worlds(const cavoid_env *env);
+int32_t cavoid_obs_width(const cavoid_env *env);
+
+/* seed the generator; episode (device u32 [W]) may be NULL = "before episode 0" for every world */
+int cavoid_seed(cavoid_env *env, uint64_t seed, const uint32_t *episode, void *stream);
+int cavoid_get_episode(cavoid_env *env, uint32_t *episode_out, void *stream);
+
+int cavoid_set_state(cavoid_env *env, const double *state_f64, const float *state_f32, const uint32_t *flags, void *stream);
+int cavoid_get_state(cavoid_env *env, double *state_f64, float *state_f32, uint32_t *flags, void *stream);
+
+/* start the next episode in every world whose mask byte is non-zero (mask NULL = all worlds) and
+ * write the observation of ALL worlds (obs may be NULL to skip) */
+int cavoid_reset(cavoid_env *env, const uint8_t *world_mask, float *obs, void *stream);
+int cavoid_observe(cavoid_env *env, float *obs, void *stream);
+
+int cavoid_step(cavoid_env *env, const int32_t *actions, float *obs, float *rewards, uint8_t *done,
+                uint8_t *game_over, void *stream);
+int cavoid_step_continuous(cavoid_env *env, const float *actions /* [W,N,2] */, float *obs, float *rewards,
+                           uint8_t *done, uint8_t *game_over, void *stream);
+/* step; worlds that end are restarted in the same launch and their obs rows hold the first
+ * observation of the new episode (rewards/done/game_over still describe the finished step) */
+int cavoid_step_autoreset(cavoid_env *env, const int32_t *actions, float *obs, float *rewards, uint8_t *done,
+                          uint8_t *game_over, void *stream);
+/* n_steps back-to-back autoreset steps from one call; step t reads actions + t*action_stride
+ * (int32 elements) and overwrites the same outputs.  Open-loop driver for benchmarks/scripted runs. */
+int cavoid_step_autoreset_n(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+                            float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream);
+
+/* as cavoid_step_autoreset_n, but every launch carries its own HIP start/stop event pair (recorded
+ * with the dispatch, so launch gaps are excluded); synchronises and returns the MEAN kernel
+ * duration in milliseconds.  Measurement aid for bench.py's roofline figure. */
+int cavoid_step_autoreset_n_timed(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+                                  float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream,
+                                  float *mean_kernel_ms);
+
+/* kernel timing helper: HIP events recorded on `stream` around the launches of the calls made
+ * between begin and end; end synchronises and returns elapsed milliseconds */
+int cavoid_timer_begin(cavoid_env *env, void *stream);
+int cavoid_timer_end(cavoid_env *env, void *stream, float *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAVOID_H */

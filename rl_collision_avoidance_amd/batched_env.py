@@ -1,0 +1,251 @@
+"""``BatchedCollisionAvoidanceEnv`` -- W independent collision-avoidance worlds stepped by one
+HIP kernel launch on an MI355X.
+
+Host-side mirror of the reference's env seam: one world of this class behaves like the object
+``create_env()`` hands to ``Environment`` (/root/reference/ga3c/GA3C/Environment.py:54-56):
+``reset() -> obs`` (:106) and ``step(actions) -> (obs, rewards, game_over, which_agents_done)``
+(:112; ProcessAgent.py:149-157), with the observation layout of Config.py:40,72-76.  Batched:
+every return value gains a leading world dimension and lives on the GPU as a torch tensor.
+
+PyTorch is plumbing only (device memory + the current HIP stream); the arithmetic is in
+``csrc/cavoid_kernels.hpp`` behind the C ABI of ``include/cavoid.h``.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EnvConfig
+
+_SORT = {"closest_last": 0, "closest_first": 1, "time_to_impact": 2}
+_DYN = {"unicycle": 0, "unicycle_max_turn_rate": 1, "holonomic": 2}
+
+
+def make_cfg(config: Optional[EnvConfig] = None, **overrides) -> _lib.CavoidCfg:
+    """Build the C-ABI config from an ``EnvConfig`` (attribute names of the reference's env Config);
+    ``overrides`` set raw ``cavoid_cfg`` fields (e.g. ``gen_min_agents=2``)."""
+    config = config or EnvConfig()
+    cfg = _lib.CavoidCfg()
+    N = int(config.MAX_NUM_AGENTS_IN_ENVIRONMENT)
+    M = int(config.MAX_NUM_OTHER_AGENTS_OBSERVED)
+    _lib.check(_lib.lib().cavoid_default_cfg(C.byref(cfg), N, M), "cavoid_default_cfg")
+    cfg.dt = config.DT
+    cfg.near_goal_threshold = config.NEAR_GOAL_THRESHOLD
+    cfg.max_time_ratio = config.MAX_TIME_RATIO
+    cfg.collision_dist = config.COLLISION_DIST
+    cfg.getting_close_range = config.GETTING_CLOSE_RANGE
+    cfg.sensing_horizon = float(config.SENSING_HORIZON)
+    cfg.sort_method = _SORT[config.AGENT_SORTING_METHOD]
+    cfg.reward_at_goal = config.REWARD_AT_GOAL
+    cfg.reward_collision = config.REWARD_COLLISION_WITH_AGENT
+    cfg.reward_getting_close = config.REWARD_GETTING_CLOSE
+    cfg.reward_time_step = config.REWARD_TIME_STEP
+    possible = [config.REWARD_AT_GOAL, config.REWARD_COLLISION_WITH_AGENT, config.REWARD_TIME_STEP,
+                config.REWARD_COLLISION_WITH_WALL, config.REWARD_WIGGLY_BEHAVIOR]
+    cfg.reward_clip_lo, cfg.reward_clip_hi = min(possible), max(possible)
+    for key, val in overrides.items():
+        if key == "actions":
+            table = np.asarray(val, dtype=np.float64)
+            if table.ndim != 2 or table.shape[1] != 2 or len(table) > _lib.MAX_ACTIONS:
+                raise ValueError("actions must be [<=%d, 2]" % _lib.MAX_ACTIONS)
+            cfg.num_actions = len(table)
+            for r, (a0, a1) in enumerate(table):
+                cfg.actions[r][0], cfg.actions[r][1] = a0, a1
+        elif key == "dynamics" and isinstance(val, str):
+            cfg.dynamics = _DYN[val]
+        elif key == "sort_method" and isinstance(val, str):
+            cfg.sort_method = _SORT[val]
+        elif hasattr(cfg, key):
+            setattr(cfg, key, val)
+        else:
+            raise AttributeError("cavoid_cfg has no field %r" % key)
+    return cfg
+
+
+class BatchedCollisionAvoidanceEnv(object):
+    """``num_worlds`` worlds of up to ``N`` agents on one GPU.
+
+    world_offset: global id of this shard's first world.  Scenario RNG streams are keyed on
+    (seed, global world id, episode), so a sharded run reproduces the unsharded one bit for bit.
+    """
+
+    def __init__(self, num_worlds: int, config: Optional[EnvConfig] = None, device="cuda:0",
+                 world_offset: int = 0, seed: int = 0, **cfg_overrides):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedCollisionAvoidanceEnv runs on an MI355X only (device=%r); "
+                               "there is no CPU fallback" % (device,))
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the env.step hot path has no CPU fallback")
+        self.config = config or EnvConfig()
+        self.cfg = make_cfg(self.config, **cfg_overrides)
+        self.num_worlds = int(num_worlds)
+        self.max_agents = int(self.cfg.max_agents)
+        self.max_other = int(self.cfg.max_other)
+        self.obs_width = 6 + 7 * self.max_other
+        self.num_actions = int(self.cfg.num_actions)
+        self.world_offset = int(world_offset)
+        self._lib = _lib.lib()
+        handle = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        _lib.check(self._lib.cavoid_create(C.byref(self.cfg), self.num_worlds, self.world_offset, dev_index,
+                                           C.byref(handle)), "cavoid_create")
+        self._h = handle
+        W, N = self.num_worlds, self.max_agents
+        self.obs = torch.zeros((W, N, self.obs_width), dtype=torch.float32, device=self.device)
+        self.rewards = torch.zeros((W, N), dtype=torch.float32, device=self.device)
+        self.done = torch.zeros((W, N), dtype=torch.uint8, device=self.device)
+        self.game_over = torch.zeros((W,), dtype=torch.uint8, device=self.device)
+        self.seed(seed)
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            torch.cuda.synchronize(self.device)
+            self._lib.cavoid_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ptr(t: Optional[torch.Tensor]):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _want(self, t: torch.Tensor, shape, dtype, name: str) -> torch.Tensor:
+        if t.device != self.device:
+            raise ValueError("%s must live on %s (got %s)" % (name, self.device, t.device))
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s (got %s)" % (name, tuple(shape), tuple(t.shape)))
+        return t.contiguous()
+
+    # -- RNG / episodes ----------------------------------------------------------------------------
+    def seed(self, seed: int, episode: Optional[torch.Tensor] = None) -> None:
+        """Seed the scenario generator; ``episode`` (uint32-valued int32/int64 tensor [W]) sets the
+        per-world index of the *current* episode (default: before the first)."""
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        ep = None
+        if episode is not None:
+            ep = self._want(episode, (self.num_worlds,), torch.int32, "episode")
+        _lib.check(self._lib.cavoid_seed(self._h, self._seed, self._ptr(ep), self._stream()), "cavoid_seed")
+
+    @property
+    def episode(self) -> torch.Tensor:
+        out = torch.empty((self.num_worlds,), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.cavoid_get_episode(self._h, self._ptr(out), self._stream()), "cavoid_get_episode")
+        return out
+
+    # -- state -------------------------------------------------------------------------------------
+    def set_state(self, state_f64: torch.Tensor, state_f32: torch.Tensor, flags: torch.Tensor) -> None:
+        """Inject explicit world states (SoA): f64 [4,W*N] px,py,heading,t_remaining; f32 [5,W*N]
+        gx,gy,radius,pref_speed,speed; flags int32 [W*N] (CAVOID_F_* bits)."""
+        A = self.num_worlds * self.max_agents
+        f64 = self._want(state_f64, (4, A), torch.float64, "state_f64")
+        f32 = self._want(state_f32, (5, A), torch.float32, "state_f32")
+        fl = self._want(flags, (A,), torch.int32, "flags")
+        _lib.check(self._lib.cavoid_set_state(self._h, self._ptr(f64), self._ptr(f32), self._ptr(fl), self._stream()),
+                   "cavoid_set_state")
+
+    def get_state(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        A = self.num_worlds * self.max_agents
+        f64 = torch.empty((4, A), dtype=torch.float64, device=self.device)
+        f32 = torch.empty((5, A), dtype=torch.float32, device=self.device)
+        fl = torch.empty((A,), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.cavoid_get_state(self._h, self._ptr(f64), self._ptr(f32), self._ptr(fl), self._stream()),
+                   "cavoid_get_state")
+        return f64, f32, fl
+
+    # -- the gym-style surface ---------------------------------------------------------------------
+    def reset(self, world_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Start the next episode in the masked worlds (all if None); returns obs [W,N,1+D]."""
+        mask = None
+        if world_mask is not None:
+            mask = self._want(world_mask, (self.num_worlds,), torch.uint8, "world_mask")
+        _lib.check(self._lib.cavoid_reset(self._h, self._ptr(mask), self._ptr(self.obs), self._stream()), "cavoid_reset")
+        return self.obs
+
+    def observe(self) -> torch.Tensor:
+        _lib.check(self._lib.cavoid_observe(self._h, self._ptr(self.obs), self._stream()), "cavoid_observe")
+        return self.obs
+
+    def _actions(self, actions: torch.Tensor) -> torch.Tensor:
+        return self._want(actions, (self.num_worlds, self.max_agents), torch.int32, "actions")
+
+    def step(self, actions: torch.Tensor):
+        """actions int [W,N] (indices into the action table; ignored for done / scripted agents)
+        -> (obs f32 [W,N,1+D], rewards f32 [W,N], done u8 [W,N], game_over u8 [W]).
+        The returned tensors are the env's own output buffers, overwritten by the next call."""
+        a = self._actions(actions)
+        _lib.check(self._lib.cavoid_step(self._h, self._ptr(a), self._ptr(self.obs), self._ptr(self.rewards),
+                                         self._ptr(self.done), self._ptr(self.game_over), self._stream()), "cavoid_step")
+        return self.obs, self.rewards, self.done, self.game_over
+
+    def step_continuous(self, actions: torch.Tensor):
+        """actions f32 [W,N,2]: (speed, delta_heading) for unicycle dynamics, (vx, vy) for holonomic."""
+        a = self._want(actions, (self.num_worlds, self.max_agents, 2), torch.float32, "actions")
+        _lib.check(self._lib.cavoid_step_continuous(self._h, self._ptr(a), self._ptr(self.obs), self._ptr(self.rewards),
+                                                    self._ptr(self.done), self._ptr(self.game_over), self._stream()),
+                   "cavoid_step_continuous")
+        return self.obs, self.rewards, self.done, self.game_over
+
+    def step_autoreset(self, actions: torch.Tensor):
+        """``step`` + in-kernel restart of finished worlds: their obs rows hold the first observation
+        of the next episode; rewards / done / game_over still describe the finished step."""
+        a = self._actions(actions)
+        _lib.check(self._lib.cavoid_step_autoreset(self._h, self._ptr(a), self._ptr(self.obs), self._ptr(self.rewards),
+                                                   self._ptr(self.done), self._ptr(self.game_over), self._stream()),
+                   "cavoid_step_autoreset")
+        return self.obs, self.rewards, self.done, self.game_over
+
+    def step_autoreset_n(self, actions: torch.Tensor, n_steps: Optional[int] = None):
+        """Open-loop run: actions int32 [T,W,N]; launches ``n_steps`` (default T) steps back to back
+        from C, step t reading ``actions[t % T]`` only when n_steps <= T."""
+        T = actions.shape[0]
+        n = T if n_steps is None else int(n_steps)
+        if n > T:
+            raise ValueError("n_steps > number of action slices")
+        a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
+        stride = self.num_worlds * self.max_agents
+        _lib.check(self._lib.cavoid_step_autoreset_n(self._h, self._ptr(a), stride, n, self._ptr(self.obs),
+                                                     self._ptr(self.rewards), self._ptr(self.done),
+                                                     self._ptr(self.game_over), self._stream()), "cavoid_step_autoreset_n")
+        return self.obs, self.rewards, self.done, self.game_over
+
+    # -- measurement -------------------------------------------------------------------------------
+    def kernel_time_ms(self, actions: torch.Tensor, n_steps: int) -> float:
+        """Run ``n_steps`` autoreset steps (cycling through actions [T,W,N]) with a HIP event pair per
+        launch; returns the mean kernel duration in ms (launch gaps excluded)."""
+        T = actions.shape[0]
+        a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
+        stride = self.num_worlds * self.max_agents
+        total, left = 0.0, int(n_steps)
+        while left > 0:
+            n = min(T, left)
+            ms = C.c_float(0.0)
+            _lib.check(self._lib.cavoid_step_autoreset_n_timed(
+                self._h, self._ptr(a), stride, n, self._ptr(self.obs), self._ptr(self.rewards), self._ptr(self.done),
+                self._ptr(self.game_over), self._stream(), C.byref(ms)), "cavoid_step_autoreset_n_timed")
+            total += ms.value * n
+            left -= n
+        return total / n_steps
+
+    def timer_begin(self) -> None:
+        _lib.check(self._lib.cavoid_timer_begin(self._h, self._stream()), "cavoid_timer_begin")
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0.0)
+        _lib.check(self._lib.cavoid_timer_end(self._h, self._stream(), C.byref(ms)), "cavoid_timer_end")
+        return float(ms.value)

@@ -1,0 +1,368 @@
+// cavoid_capi.hip -- the C ABI of include/cavoid.h over the gfx950 kernels of cavoid_kernels.hpp.
+// Host side only: argument checking, the library-owned world buffer, launch geometry.
+// There is deliberately no CPU path here: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "cavoid.h"
+#include "cavoid_kernels.hpp"
+
+using namespace cavoid;
+
+static thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) {                        \
+            g_last_hip_error = (int)_e;                \
+            return CAVOID_EHIP;                        \
+        }                                              \
+    } while (0)
+
+struct cavoid_env {
+    int device = 0;
+    int64_t W = 0, A = 0, world_offset = 0;
+    cavoid_cfg cfg{};
+    KCfg k{};
+    KState st{};
+    void *slab = nullptr;
+    double *d_actions = nullptr;
+    int waves_per_block = 4;
+    size_t lds_bytes = 0;
+    int grid = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" int cavoid_abi_version(void) { return CAVOID_ABI_VERSION; }
+
+extern "C" int cavoid_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" const char *cavoid_strerror(int code) {
+    switch (code) {
+        case CAVOID_OK: return "ok";
+        case CAVOID_EINVAL: return "invalid argument or configuration";
+        case CAVOID_ENOMEM: return "device memory allocation failed";
+        case CAVOID_EHIP: return "HIP runtime call failed (see cavoid_last_hip_error)";
+        case CAVOID_EUNSUPPORTED: return "max_agents outside the compiled range [1,16]";
+        case CAVOID_ENODEVICE: return "no usable HIP device";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int cavoid_default_actions(double (*table)[2], int32_t *num_actions) {
+    if (!table || !num_actions) return CAVOID_EINVAL;
+    // E4: 5 headings at full speed (pi/12 apart), 3 at half speed, 3 at zero speed (pi/6 apart);
+    // evidence Server.py:51-52, Config.py:79, Regression.py:157-160
+    const double frac[3] = {1.0, 0.5, 0.0}, step[3] = {kPi / 12, kPi / 6, kPi / 6};
+    const int count[3] = {5, 3, 3};
+    int r = 0;
+    for (int g = 0; g < 3; ++g)
+        for (int k = 0; k < count[g]; ++k, ++r) {
+            table[r][0] = frac[g];
+            table[r][1] = -kPi / 6 + k * step[g];
+        }
+    *num_actions = r;
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_default_cfg(cavoid_cfg *c, int32_t max_agents, int32_t max_other) {
+    if (!c || max_agents < 1 || max_other < 0) return CAVOID_EINVAL;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (uint32_t)sizeof(cavoid_cfg);
+    c->abi_version = CAVOID_ABI_VERSION;
+    c->max_agents = max_agents;
+    c->max_other = max_other;
+    c->sort_method = CAVOID_SORT_CLOSEST_LAST;
+    c->dynamics = CAVOID_DYN_UNICYCLE;
+    c->actions_fp32 = 1;
+    c->timeout_enabled = 1;
+    c->dt = 0.2;
+    c->near_goal_threshold = 0.2;
+    c->max_time_ratio = 2.0;
+    c->collision_dist = 0.0;
+    c->getting_close_range = 0.2;
+    c->reward_at_goal = 1.0;
+    c->reward_collision = -0.25;
+    c->reward_getting_close = -0.1;
+    c->reward_time_step = 0.0;
+    c->close_penalty_slope = -0.5;
+    c->reward_clip_lo = -0.25;
+    c->reward_clip_hi = 1.0;
+    c->sensing_horizon = INFINITY;
+    c->max_turn_rate = 3.0;
+    cavoid_default_actions(c->actions, &c->num_actions);
+    c->gen_min_agents = max_agents;
+    c->gen_max_agents = max_agents;
+    c->gen_nonlearning_fraction = 0.0;
+    c->gen_static_fraction = 0.5;
+    c->gen_goal_jitter = 0.5;
+    c->gen_angle_jitter = 0.25;
+    return CAVOID_OK;
+}
+
+static int validate(const cavoid_cfg *c) {
+    if (!c || c->struct_size != sizeof(cavoid_cfg) || c->abi_version != CAVOID_ABI_VERSION) return CAVOID_EINVAL;
+    if (c->max_agents < 1 || c->max_agents > CAVOID_MAX_AGENTS) return CAVOID_EUNSUPPORTED;
+    if (c->max_other < 0 || c->max_other > 64) return CAVOID_EINVAL;
+    if (c->num_actions < 1 || c->num_actions > CAVOID_MAX_ACTIONS) return CAVOID_EINVAL;
+    if (c->sort_method < 0 || c->sort_method > 2 || c->dynamics < 0 || c->dynamics > 2) return CAVOID_EINVAL;
+    if (!(c->dt > 0.0)) return CAVOID_EINVAL;
+    if (c->gen_min_agents < 1 || c->gen_max_agents > c->max_agents || c->gen_min_agents > c->gen_max_agents) return CAVOID_EINVAL;
+    return CAVOID_OK;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t world_offset, int device, cavoid_env **out) {
+    if (!out) return CAVOID_EINVAL;
+    *out = nullptr;
+    int rc = validate(cfg);
+    if (rc != CAVOID_OK) return rc;
+    if (num_worlds < 1 || world_offset < 0 || num_worlds > (int64_t)1 << 31) return CAVOID_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CAVOID_ENODEVICE;
+    HIP_TRY(hipSetDevice(device));
+
+    cavoid_env *e = new (std::nothrow) cavoid_env();
+    if (!e) return CAVOID_ENOMEM;
+    e->device = device;
+    e->W = num_worlds;
+    e->A = num_worlds * cfg->max_agents;
+    e->world_offset = world_offset;
+    e->cfg = *cfg;
+
+    const size_t A = (size_t)e->A, W = (size_t)e->W;
+    size_t off = 0, o_f64 = off;
+    off = align_up(off + 4 * A * sizeof(double), 256);
+    size_t o_f32 = off;
+    off = align_up(off + 5 * A * sizeof(float), 256);
+    size_t o_flags = off;
+    off = align_up(off + A * sizeof(uint32_t), 256);
+    size_t o_ep = off;
+    off = align_up(off + W * sizeof(uint32_t), 256);
+    size_t o_act = off;
+    off = align_up(off + CAVOID_MAX_ACTIONS * 2 * sizeof(double), 256);
+    if (hipMalloc(&e->slab, off) != hipSuccess) { delete e; return CAVOID_ENOMEM; }
+    unsigned char *b = static_cast<unsigned char *>(e->slab);
+    double *f64 = reinterpret_cast<double *>(b + o_f64);
+    float *f32 = reinterpret_cast<float *>(b + o_f32);
+    e->st.px = f64; e->st.py = f64 + A; e->st.heading = f64 + 2 * A; e->st.t_rem = f64 + 3 * A;
+    e->st.gx = f32; e->st.gy = f32 + A; e->st.radius = f32 + 2 * A; e->st.pref = f32 + 3 * A; e->st.speed = f32 + 4 * A;
+    e->st.flags = reinterpret_cast<uint32_t *>(b + o_flags);
+    e->st.episode = reinterpret_cast<uint32_t *>(b + o_ep);
+    e->d_actions = reinterpret_cast<double *>(b + o_act);
+    if (hipMemset(e->slab, 0, off) != hipSuccess || hipMemset(e->st.episode, 0xFF, W * sizeof(uint32_t)) != hipSuccess ||
+        hipMemcpy(e->d_actions, cfg->actions, sizeof(cfg->actions), hipMemcpyHostToDevice) != hipSuccess ||
+        hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
+        g_last_hip_error = (int)hipGetLastError();
+        cavoid_destroy(e);
+        return CAVOID_EHIP;
+    }
+
+    KCfg &k = e->k;
+    k.dt = cfg->dt;
+    k.near_goal = cfg->near_goal_threshold;
+    k.near_goal_sq = cfg->near_goal_threshold * cfg->near_goal_threshold;
+    k.max_time_ratio = cfg->max_time_ratio;
+    k.collision_dist = cfg->collision_dist;
+    k.close_range = cfg->getting_close_range;
+    k.r_goal = cfg->reward_at_goal; k.r_coll = cfg->reward_collision; k.r_close = cfg->reward_getting_close;
+    k.r_step = cfg->reward_time_step; k.close_slope = cfg->close_penalty_slope;
+    k.clip_lo = cfg->reward_clip_lo; k.clip_hi = cfg->reward_clip_hi;
+    k.horizon = cfg->sensing_horizon; k.max_turn_rate = cfg->max_turn_rate;
+    k.gen_nonlearning = cfg->gen_nonlearning_fraction; k.gen_static = cfg->gen_static_fraction;
+    k.gen_goal_jitter = cfg->gen_goal_jitter; k.gen_angle_jitter = cfg->gen_angle_jitter;
+    k.max_other = cfg->max_other; k.width = 6 + 7 * cfg->max_other;
+    k.sort_method = cfg->sort_method; k.dynamics = cfg->dynamics; k.actions_fp32 = cfg->actions_fp32;
+    k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
+    k.gen_min_agents = cfg->gen_min_agents; k.gen_max_agents = cfg->gen_max_agents;
+    k.seed_lo = 0; k.seed_hi = 0;
+    k.num_worlds = num_worlds; k.world_offset = world_offset;
+    k.action_table = e->d_actions;
+
+    // launch geometry: a wavefront owns floor(64/N) worlds; up to 4 wavefronts per workgroup,
+    // fewer when the per-wave LDS obs tile is large (keep a workgroup <= 64 KiB of LDS)
+    const int N = cfg->max_agents, wpw = 64 / N, lanes = wpw * N;
+    const size_t per_wave = (size_t)(lds_floats_fixed() + ((lanes * k.width + 3) & ~3)) * sizeof(float);
+    int wpb = (int)((size_t)65536 / per_wave);
+    if (wpb < 1) { cavoid_destroy(e); return CAVOID_EUNSUPPORTED; }
+    if (wpb > 4) wpb = 4;
+    e->waves_per_block = wpb;
+    e->lds_bytes = per_wave * wpb;
+    const int64_t waves = (num_worlds + wpw - 1) / wpw;
+    e->grid = (int)((waves + wpb - 1) / wpb);
+    *out = e;
+    return CAVOID_OK;
+}
+
+extern "C" void cavoid_destroy(cavoid_env *e) {
+    if (!e) return;
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->slab) (void)hipFree(e->slab);
+    delete e;
+}
+
+extern "C" int64_t cavoid_num_worlds(const cavoid_env *e) { return e ? e->W : 0; }
+extern "C" int32_t cavoid_obs_width(const cavoid_env *e) { return e ? e->k.width : 0; }
+
+template <int MODE>
+static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    const dim3 grid(e->grid), block(64 * e->waves_per_block);
+    const size_t lds = e->lds_bytes;
+#define CAVOID_CASE(NN) \
+    case NN: hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, e->k, e->st, io); break;
+    switch (e->cfg.max_agents) {
+        CAVOID_CASE(1) CAVOID_CASE(2) CAVOID_CASE(3) CAVOID_CASE(4) CAVOID_CASE(5) CAVOID_CASE(6)
+        CAVOID_CASE(7) CAVOID_CASE(8) CAVOID_CASE(9) CAVOID_CASE(10) CAVOID_CASE(11) CAVOID_CASE(12)
+        CAVOID_CASE(13) CAVOID_CASE(14) CAVOID_CASE(15) CAVOID_CASE(16)
+        default: return CAVOID_EUNSUPPORTED;
+    }
+#undef CAVOID_CASE
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_seed(cavoid_env *e, uint64_t seed, const uint32_t *episode, void *stream) {
+    if (!e) return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    e->k.seed_lo = (uint32_t)seed;
+    e->k.seed_hi = (uint32_t)(seed >> 32);
+    if (episode) HIP_TRY(hipMemcpyAsync(e->st.episode, episode, (size_t)e->W * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemsetAsync(e->st.episode, 0xFF, (size_t)e->W * sizeof(uint32_t), s));
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_get_episode(cavoid_env *e, uint32_t *out, void *stream) {
+    if (!e || !out) return CAVOID_EINVAL;
+    HIP_TRY(hipMemcpyAsync(out, e->st.episode, (size_t)e->W * sizeof(uint32_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_set_state(cavoid_env *e, const double *f64, const float *f32, const uint32_t *flags, void *stream) {
+    if (!e || !f64 || !f32 || !flags) return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t A = (size_t)e->A;
+    HIP_TRY(hipMemcpyAsync(e->st.px, f64, 4 * A * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->st.gx, f32, 5 * A * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->st.flags, flags, A * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_get_state(cavoid_env *e, double *f64, float *f32, uint32_t *flags, void *stream) {
+    if (!e || !f64 || !f32 || !flags) return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t A = (size_t)e->A;
+    HIP_TRY(hipMemcpyAsync(f64, e->st.px, 4 * A * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(f32, e->st.gx, 5 * A * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(flags, e->st.flags, A * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_reset(cavoid_env *e, const uint8_t *world_mask, float *obs, void *stream) {
+    if (!e) return CAVOID_EINVAL;
+    KIO io{};
+    io.mask = world_mask;
+    io.obs = obs;
+    return launch<MODE_RESET>(e, io, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_observe(cavoid_env *e, float *obs, void *stream) {
+    if (!e || !obs) return CAVOID_EINVAL;
+    KIO io{};
+    io.obs = obs;
+    return launch<MODE_OBSERVE>(e, io, static_cast<hipStream_t>(stream));
+}
+
+static int step_args(cavoid_env *e, const void *actions, float *rew, uint8_t *done, uint8_t *go) {
+    return (e && actions && rew && done && go) ? CAVOID_OK : CAVOID_EINVAL;
+}
+
+extern "C" int cavoid_step(cavoid_env *e, const int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;   // holonomic needs velocity actions
+    KIO io{};
+    io.actions = actions; io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    return launch<MODE_STEP>(e, io, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_step_continuous(cavoid_env *e, const float *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
+    KIO io{};
+    io.cont = actions; io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    return launch<MODE_STEP>(e, io, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_step_autoreset(cavoid_env *e, const int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
+    KIO io{};
+    io.actions = actions; io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    return launch<MODE_STEP_AUTORESET>(e, io, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_step_autoreset_n(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+                                       float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 0 || action_stride < 0) return CAVOID_EINVAL;
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
+    KIO io{};
+    io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    for (int32_t t = 0; t < n_steps; ++t) {
+        io.actions = actions + (int64_t)t * action_stride;
+        int rc = launch<MODE_STEP_AUTORESET>(e, io, static_cast<hipStream_t>(stream));
+        if (rc != CAVOID_OK) return rc;
+    }
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+                                             float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream,
+                                             float *mean_kernel_ms) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 1 || action_stride < 0 || !mean_kernel_ms) return CAVOID_EINVAL;
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int kPool = 128;
+    hipEvent_t ev[2 * kPool];
+    for (int i = 0; i < 2 * kPool; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+    KIO io{};
+    io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    double total_ms = 0.0;
+    int rc = CAVOID_OK;
+    for (int32_t t0 = 0; t0 < n_steps && rc == CAVOID_OK; t0 += kPool) {
+        const int32_t n = (n_steps - t0) < kPool ? (n_steps - t0) : kPool;
+        for (int32_t t = 0; t < n && rc == CAVOID_OK; ++t) {
+            io.actions = actions + (int64_t)(t0 + t) * action_stride;
+            rc = launch<MODE_STEP_AUTORESET>(e, io, s, ev[2 * t], ev[2 * t + 1]);
+        }
+        if (rc != CAVOID_OK) break;
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = CAVOID_EHIP; break; }
+        for (int32_t t = 0; t < n; ++t) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * t], ev[2 * t + 1]) != hipSuccess) { rc = CAVOID_EHIP; break; }
+            total_ms += ms;
+        }
+    }
+    for (int i = 0; i < 2 * kPool; ++i) (void)hipEventDestroy(ev[i]);
+    if (rc == CAVOID_OK) *mean_kernel_ms = (float)(total_ms / n_steps);
+    return rc;
+}
+
+extern "C" int cavoid_timer_begin(cavoid_env *e, void *stream) {
+    if (!e) return CAVOID_EINVAL;
+    HIP_TRY(hipEventRecord(e->ev0, static_cast<hipStream_t>(stream)));
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_timer_end(cavoid_env *e, void *stream, float *elapsed_ms) {
+    if (!e || !elapsed_ms) return CAVOID_EINVAL;
+    HIP_TRY(hipEventRecord(e->ev1, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
+    return CAVOID_OK;
+}

@@ -1,0 +1,269 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via BatchedCollisionAvoidanceEnv)
+against the float64 CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): collision/goal/done/game_over flags BIT-EXACT, float observations
+and rewards within 1e-5.  The env half of the oracle is parity-unpinned (reference env source
+absent) -- these tests prove HIP == oracle, not oracle == upstream."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL = 1e-5      # tolerance stated by north_star for float observations / rewards
+STATE_TOL = 1e-9    # float64 world state (positions, heading, time) after free-running both sides
+
+
+def _env(W, N, M=None, seed=0, **over):
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            self.MAX_NUM_OTHER_AGENTS_OBSERVED = N - 1 if M is None else M
+            EnvConfig.__init__(self)
+    return BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=seed, **over)
+
+
+def _oracle(N, M=None, gen_min=None, nonl=0.0, **over):
+    cfg = co.default_cfg(N, N - 1 if M is None else M, **over)
+    gen = co.default_gen(N if gen_min is None else gen_min, N, nonl)
+    return cfg, gen
+
+
+def _push(env, st):
+    env.set_state(torch.from_numpy(st.f64).cuda(), torch.from_numpy(st.f32).cuda(),
+                  torch.from_numpy(st.flags.view(np.int32)).cuda())
+
+
+def _pull(env):
+    f64, f32, fl = env.get_state()
+    return f64.cpu().numpy(), f32.cpu().numpy(), fl.cpu().numpy().view(np.uint32)
+
+
+def _compare_step(tag, env_out, ora_out, env, st):
+    obs, rew, done, go = [t.cpu().numpy() for t in env_out]
+    oobs, orew, odone, ogo = ora_out
+    assert np.array_equal(done, odone), tag
+    assert np.array_equal(go, ogo), tag
+    f64, f32, fl = _pull(env)
+    assert np.array_equal(fl, st.flags), tag                       # every flag bit, incl. collision / goal
+    assert np.array_equal(f32, st.f32), tag
+    np.testing.assert_allclose(f64, st.f64, rtol=0, atol=STATE_TOL, err_msg=str(tag))
+    np.testing.assert_allclose(rew, orew, rtol=0, atol=OBS_TOL, err_msg=str(tag))
+    np.testing.assert_allclose(obs, oobs, rtol=0, atol=OBS_TOL, err_msg=str(tag))
+    assert np.array_equal(obs[..., :2], oobs[..., :2].astype(np.float32)), tag   # is_learning, num_other exact
+
+
+@pytest.mark.parametrize("N,M,sort,nonl,gen_min", [
+    (4, None, 0, 0.0, 4),      # BASELINE configs[1] shape
+    (4, None, 1, 0.4, 2),      # closest_first, scripted agents, 2..4 agents
+    (2, None, 0, 0.0, 2),      # configs[0] shape
+    (3, None, 2, 0.3, 2),      # time-to-impact ordering
+    (10, None, 0, 0.3, 2),     # configs[3]: TrainPhase2-style, variable neighbour count
+    (10, 4, 1, 0.0, 5),        # clipping to the 4 closest
+    (5, 7, 0, 0.2, 1),         # M > N-1: padded slots (weight-sharing arch layout)
+    (7, None, 0, 0.0, 7),      # 64 % N != 0: idle tail lanes
+    (16, None, 0, 0.1, 9),
+])
+def test_trajectory_parity(N, M, sort, nonl, gen_min):
+    W, steps, seed = 777, 140, 11
+    ocfg, ogen = _oracle(N, M, gen_min, nonl, sort_method=sort)
+    env = _env(W, N, M, seed=seed, sort_method=sort, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
+    st = co.State.empty(W, N)
+    co.generate(ocfg, ogen, seed, st, np.zeros(W, np.uint32))
+    _push(env, st)
+    np.testing.assert_allclose(env.observe().cpu().numpy(), co.observe(ocfg, st), rtol=0, atol=OBS_TOL)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = rng.integers(0, 11, size=(W, N)).astype(np.int32)
+        out = env.step(torch.from_numpy(acts).cuda())
+        _compare_step((N, M, sort, t), out, co.step(ocfg, st, acts), env, st)
+    present = st.flags & 0x20 != 0
+    assert (st.flags[present] & 7 != 0).mean() > 0.5       # most agents reached a terminal flag
+    assert (st.flags & 4 != 0).any() and (st.flags & 1 != 0).any() and (st.flags & 2 != 0).any()
+    env.close()
+
+
+def test_reset_generator_parity():
+    W, N, seed = 1000, 6, 99
+    ocfg, ogen = _oracle(N, None, 2, 0.3)
+    env = _env(W, N, seed=seed, gen_min_agents=2, gen_nonlearning_fraction=0.3)
+    obs = env.reset().cpu().numpy()
+    st = co.State.empty(W, N)
+    co.generate(ocfg, ogen, seed, st, np.zeros(W, np.uint32))
+    f64, f32, fl = _pull(env)
+    assert np.array_equal(fl, st.flags)
+    assert np.array_equal(f32, st.f32)
+    np.testing.assert_allclose(f64, st.f64, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(obs, co.observe(ocfg, st), rtol=0, atol=OBS_TOL)
+    assert np.array_equal(env.episode.cpu().numpy(), np.zeros(W, np.int32))
+    # masked reset advances only the masked worlds
+    mask = (np.arange(W) % 3 == 0).astype(np.uint8)
+    obs2 = env.reset(torch.from_numpy(mask).cuda()).cpu().numpy()
+    ep = mask.astype(np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep, mask)
+    f64, f32, fl = _pull(env)
+    assert np.array_equal(fl, st.flags) and np.array_equal(f32, st.f32)
+    np.testing.assert_allclose(obs2, co.observe(ocfg, st), rtol=0, atol=OBS_TOL)
+    assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep)
+    env.close()
+
+
+@pytest.mark.parametrize("N,gen_min,nonl", [(4, 4, 0.0), (10, 2, 0.2)])
+def test_autoreset_parity(N, gen_min, nonl):
+    W, steps, seed = 512, 300, 5
+    ocfg, ogen = _oracle(N, None, gen_min, nonl)
+    env = _env(W, N, seed=seed, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
+    env.reset()
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = rng.integers(0, 11, size=(W, N)).astype(np.int32)
+        out = env.step_autoreset(torch.from_numpy(acts).cuda())
+        ora = co.step_autoreset(ocfg, ogen, seed, st, ep, acts)
+        _compare_step(("autoreset", N, t), out, ora, env, st)
+        assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep)
+    assert ep.min() >= 1       # every world finished at least one episode
+    env.close()
+
+
+def test_step_autoreset_n_matches_single_steps():
+    W, N, T, seed = 300, 4, 64, 3
+    rng = np.random.default_rng(seed)
+    acts = torch.from_numpy(rng.integers(0, 11, size=(T, W, N)).astype(np.int32)).cuda()
+    a = _env(W, N, seed=seed)
+    b = _env(W, N, seed=seed)
+    a.reset(); b.reset()
+    for t in range(T):
+        a.step_autoreset(acts[t])
+    b.step_autoreset_n(acts)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.rewards, b.rewards) and torch.equal(a.episode, b.episode)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("dyn", ["unicycle", "unicycle_max_turn_rate", "holonomic"])
+def test_continuous_actions_parity(dyn):
+    W, N, steps, seed = 400, 4, 80, 21
+    code = {"unicycle": 0, "unicycle_max_turn_rate": 1, "holonomic": 2}[dyn]
+    ocfg, ogen = _oracle(N, dynamics=code)
+    env = _env(W, N, seed=seed, dynamics=dyn)
+    st = co.State.empty(W, N)
+    co.generate(ocfg, ogen, seed, st, np.zeros(W, np.uint32))
+    _push(env, st)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        if dyn == "holonomic":      # velocity toward the goal with noise
+            g = np.stack([st.f32[0] - st.f64[0], st.f32[1] - st.f64[1]], -1)
+            v = g / np.maximum(np.linalg.norm(g, axis=-1, keepdims=True), 1e-6) * st.f32[3][:, None]
+            acts = (v + rng.normal(0, 0.3, size=v.shape)).astype(np.float32).reshape(W, N, 2)
+        else:
+            acts = np.stack([rng.uniform(0, 1.5, (W, N)), rng.uniform(-1.5, 1.5, (W, N))], -1).astype(np.float32)
+        out = env.step_continuous(torch.from_numpy(acts).cuda())
+        _compare_step((dyn, t), out, co.step(ocfg, st, None, acts), env, st)
+    env.close()
+
+
+def test_u_switches_follow_the_oracle():
+    """close-penalty sign (U5), float64 action array, timeout off (U1): flipped on both sides."""
+    W, N, steps, seed = 300, 4, 120, 8
+    over = dict(close_penalty_slope=0.5, actions_fp32=0, timeout_enabled=0)
+    ocfg, ogen = _oracle(N, **over)
+    env = _env(W, N, seed=seed, **over)
+    st = co.State.empty(W, N)
+    co.generate(ocfg, ogen, seed, st, np.zeros(W, np.uint32))
+    _push(env, st)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = rng.integers(0, 11, size=(W, N)).astype(np.int32)
+        _compare_step(("U", t), env.step(torch.from_numpy(acts).cuda()), co.step(ocfg, st, acts), env, st)
+    assert not (st.flags & 2).any()
+    env.close()
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] size (4 agents x 8192 worlds): size-independent properties.
+    (a) worlds are independent: a 8192-world batch == the same worlds run as two 4096 shards with
+        world_offset (bitwise) -- also the multi-GPU sharding invariant;
+    (b) determinism: same seed, same result;  (c) permuting agents permutes rewards/done."""
+    W, N, seed, steps = 8192, 4, 1234, 60
+    rng = np.random.default_rng(seed)
+    acts = torch.from_numpy(rng.integers(0, 11, size=(steps, W, N)).astype(np.int32)).cuda()
+    full = _env(W, N, seed=seed)
+    lo = _env(W // 2, N, seed=seed)
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    hi = BatchedCollisionAvoidanceEnv(W // 2, lo.config, device="cuda:0", world_offset=W // 2, seed=seed)
+    full.reset(); lo.reset(); hi.reset()
+    tot_rew = torch.zeros((), dtype=torch.float64, device="cuda")
+    for t in range(steps):
+        o, r, d, g = full.step_autoreset(acts[t])
+        o1, r1, d1, g1 = lo.step_autoreset(acts[t, :W // 2])
+        o2, r2, d2, g2 = hi.step_autoreset(acts[t, W // 2:])
+        assert torch.equal(o, torch.cat([o1, o2])) and torch.equal(r, torch.cat([r1, r2]))
+        assert torch.equal(d, torch.cat([d1, d2])) and torch.equal(g, torch.cat([g1, g2]))
+        tot_rew += r.double().sum()
+    assert torch.equal(full.episode, torch.cat([lo.episode, hi.episode]))
+    assert full.episode.min().item() >= 0 and full.episode.max().item() >= 1
+    assert torch.isfinite(full.obs).all()
+    again = _env(W, N, seed=seed)
+    again.reset()
+    again.step_autoreset_n(acts)
+    assert torch.equal(again.obs, full.obs) and torch.equal(again.episode, full.episode)
+    # (c) permutation equivariance on a fresh state
+    f64, f32, fl = full.get_state()
+    perm = torch.tensor([2, 0, 3, 1], device="cuda")
+    idx = (torch.arange(W, device="cuda")[:, None] * N + perm[None, :]).reshape(-1)
+    p = _env(W, N, seed=seed)
+    p.set_state(f64[:, idx], f32[:, idx], fl[idx])
+    q = _env(W, N, seed=seed)
+    q.set_state(f64, f32, fl)
+    a = acts[0]
+    _, rq, dq, gq = q.step(a)
+    _, rp, dp, gp = p.step(a[:, perm])
+    assert torch.equal(rp, rq[:, perm]) and torch.equal(dp, dq[:, perm]) and torch.equal(gp, gq)
+    for e in (full, lo, hi, again, p, q):
+        e.close()
+
+
+def test_state_roundtrip_and_observe_idempotent():
+    W, N, seed = 500, 4, 2
+    env = _env(W, N, seed=seed)
+    env.reset()
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        env.step(torch.from_numpy(rng.integers(0, 11, size=(W, N)).astype(np.int32)).cuda())
+    obs = env.obs.clone()
+    s1 = [x.clone() for x in env.get_state()]
+    assert torch.equal(env.observe(), obs)             # observe() reproduces the step's observation
+    env2 = _env(W, N, seed=seed)
+    env2.set_state(*s1)
+    assert torch.equal(env2.observe(), obs)
+    for x, y in zip(env2.get_state(), s1):
+        assert torch.equal(x, y)
+    env.close(); env2.close()
+
+
+def test_errors_are_codes_not_crashes():
+    from rl_collision_avoidance_amd import _lib
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    env = _env(8, 4)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((7, 4), dtype=torch.int32, device="cuda"))
+    with pytest.raises(_lib.CavoidError):
+        BatchedCollisionAvoidanceEnv(8, env.config, gen_min_agents=9)
+    h = _env(8, 4, dynamics="holonomic")
+    with pytest.raises(_lib.CavoidError):
+        h.step(torch.zeros((8, 4), dtype=torch.int32, device="cuda"))
+    # out-of-range action indices are clamped, never read out of bounds
+    env.reset()
+    env.step(torch.full((8, 4), 999, dtype=torch.int32, device="cuda"))
+    assert torch.isfinite(env.obs).all()
+    env.close(); h.close()
