@@ -83,6 +83,11 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -m rl_collision_avoidance_amd.build` (needs hipcc). "
                 "There is no CPU fallback for the env.step hot path." % LIB_PATH)
+        # PyTorch first: its wheel bundles the HIP runtime (libamdhip64) that owns the tensors we are
+        # handed; loading it before our library makes the dynamic linker bind us to that SAME
+        # runtime instead of pulling a second copy from /opt/rocm (two runtimes in one process:
+        # hipGetDeviceCount fails / foreign pointers).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(handle, name)      # AttributeError if the library lacks a declared symbol
