@@ -32,12 +32,12 @@ def algorithmic_bytes_per_agent_step(M: int) -> int:
     return 4 * (11 + 1 + 7 + (6 + 7 * M) + 1 + 1)
 
 
-def cpu_baseline(N: int, W: int, budget_s: float):
+def cpu_baseline(N: int, W: int, budget_s: float, pool_size: int):
     """The C float64 oracle (a port/restatement -- the reference env source is absent) timed on this
     box's host cores, 1 thread, on the same workload shape, for about `budget_s` seconds."""
     import numpy as np
     from oracle import c_oracle as co
-    cfg, gen = co.default_cfg(N), co.default_gen(N, N)
+    cfg, gen = co.default_cfg(N), co.default_gen(N, N, pool_size=pool_size)
     st = co.State.empty(W, N)
     ep = np.zeros(W, np.uint32)
     co.generate(cfg, gen, 0, st, ep)
@@ -211,7 +211,7 @@ def main() -> None:
         "roofline": roofline,
     }
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(N, W, args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(N, W, args.cpu_seconds, int(env.cfg.gen_pool_size))
         line["cpu_baseline"]["host_cpus"] = os.cpu_count()
         extra["python_reference_style_baseline"] = python_baseline(N, min(3.0, args.cpu_seconds))
     if extra:

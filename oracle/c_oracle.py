@@ -30,7 +30,8 @@ class OracleCfg(C.Structure):
 
 class OracleGen(C.Structure):
     _fields_ = [("min_agents", C.c_int32), ("max_agents", C.c_int32), ("nonlearning_fraction", C.c_double),
-                ("static_fraction", C.c_double), ("goal_jitter", C.c_double), ("angle_jitter", C.c_double)]
+                ("static_fraction", C.c_double), ("goal_jitter", C.c_double), ("angle_jitter", C.c_double),
+                ("pool_size", C.c_int32), ("_pad", C.c_int32)]
 
 
 class _State(C.Structure):
@@ -90,8 +91,10 @@ def set_actions(cfg: OracleCfg, table) -> None:
 
 
 def default_gen(min_agents: int = 4, max_agents: int = 4, nonlearning_fraction: float = 0.0,
-                static_fraction: float = 0.5, goal_jitter: float = 0.5, angle_jitter: float = 0.25) -> OracleGen:
-    return OracleGen(min_agents, max_agents, nonlearning_fraction, static_fraction, goal_jitter, angle_jitter)
+                static_fraction: float = 0.5, goal_jitter: float = 0.5, angle_jitter: float = 0.25,
+                pool_size: int = 0) -> OracleGen:
+    return OracleGen(min_agents, max_agents, nonlearning_fraction, static_fraction, goal_jitter, angle_jitter,
+                     pool_size, 0)
 
 
 @dataclass

@@ -290,6 +290,13 @@ static void generate_world(const oracle_cfg *c, const oracle_gen *g, uint64_t se
                            oracle_state *s, int64_t w) {
     const int N = c->max_agents;
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, ctr[4] = {gw, ep, 0, 0}, r[4], a[4], b[4];
+    if (g->pool_size > 0) {            /* scenario pool: pick the pool entry, which is generator world k, episode 0 */
+        ctr[2] = 3;
+        oracle_philox4x32(ctr, key, r);
+        ctr[0] = gw = r[0] % (uint32_t)g->pool_size;
+        ctr[1] = ep = 0;
+        ctr[2] = 0;
+    }
     oracle_philox4x32(ctr, key, r);
     int span = g->max_agents - g->min_agents + 1;
     int n = g->min_agents + (int)(r[0] % (uint32_t)span);

@@ -415,6 +415,7 @@ class GenConfig:
     static_fraction: float = 0.5          # of those, P(static) (else non-cooperative)
     goal_jitter: float = 0.5              # half-width (m) of the uniform jitter on the antipodal goal
     angle_jitter: float = 0.25            # fraction of the angular slot
+    pool_size: int = 0                    # > 0: scenario pool (episode ep of world gw = pool entry philox(gw,ep,3,0)[0] % P)
 
 
 def generate_world(seed: int, world_id: int, episode: int, cfg: OracleConfig, gen: GenConfig) -> World:
@@ -422,6 +423,9 @@ def generate_world(seed: int, world_id: int, episode: int, cfg: OracleConfig, ge
     centre).  radius~U(0.2,0.8), pref_speed~U(0.5,2.0) stored as float32 values; start
     positions stay float64; heading points at the goal; time budget as in ``Agent``."""
     k0, k1 = seed & _MASK32, (seed >> 32) & _MASK32
+    if gen.pool_size > 0:      # pool entry k is generator world k, episode 0
+        world_id = philox4x32(world_id & _MASK32, episode & _MASK32, 3, 0, k0, k1)[0] % gen.pool_size
+        episode = 0
     w = philox4x32(world_id & _MASK32, episode & _MASK32, 0, 0, k0, k1)
     span = gen.max_agents - gen.min_agents + 1
     n = gen.min_agents + (w[0] % span)

@@ -33,6 +33,7 @@ class CavoidCfg(C.Structure):
         ("gen_min_agents", C.c_int32), ("gen_max_agents", C.c_int32),
         ("gen_nonlearning_fraction", C.c_double), ("gen_static_fraction", C.c_double),
         ("gen_goal_jitter", C.c_double), ("gen_angle_jitter", C.c_double),
+        ("gen_pool_size", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 

@@ -31,7 +31,10 @@ struct cavoid_env {
     cavoid_cfg cfg{};
     KCfg k{};
     KState st{};
+    KState pool{};               // pre-generated scenarios (GEN v1 worlds 0..P-1, episode 0)
+    int64_t pool_size = 0;
     void *slab = nullptr;
+    void *pool_slab = nullptr;
     double *d_actions = nullptr;
     int waves_per_block = 4;
     size_t lds_bytes = 0;
@@ -103,6 +106,7 @@ extern "C" int cavoid_default_cfg(cavoid_cfg *c, int32_t max_agents, int32_t max
     c->gen_static_fraction = 0.5;
     c->gen_goal_jitter = 0.5;
     c->gen_angle_jitter = 0.25;
+    c->gen_pool_size = 65536;
     return CAVOID_OK;
 }
 
@@ -114,10 +118,42 @@ static int validate(const cavoid_cfg *c) {
     if (c->sort_method < 0 || c->sort_method > 2 || c->dynamics < 0 || c->dynamics > 2) return CAVOID_EINVAL;
     if (!(c->dt > 0.0)) return CAVOID_EINVAL;
     if (c->gen_min_agents < 1 || c->gen_max_agents > c->max_agents || c->gen_min_agents > c->gen_max_agents) return CAVOID_EINVAL;
+    if (c->gen_pool_size < 0 || c->gen_pool_size > (1 << 24)) return CAVOID_EINVAL;
     return CAVOID_OK;
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// one device allocation holding the SoA world buffer of `worlds` worlds (+ `extra` trailing bytes)
+static int alloc_state(size_t worlds, size_t agents, size_t extra, void **slab, KState *st, size_t *extra_off) {
+    const size_t A = worlds * agents;
+    size_t off = 0, o_f64 = off;
+    off = align_up(off + 4 * A * sizeof(double), 256);
+    const size_t o_f32 = off;
+    off = align_up(off + 5 * A * sizeof(float), 256);
+    const size_t o_flags = off;
+    off = align_up(off + A * sizeof(uint32_t), 256);
+    const size_t o_ep = off;
+    off = align_up(off + worlds * sizeof(uint32_t), 256);
+    *extra_off = off;
+    off = align_up(off + extra, 256);
+    if (hipMalloc(slab, off) != hipSuccess) return CAVOID_ENOMEM;
+    if (hipMemset(*slab, 0, off) != hipSuccess) return CAVOID_EHIP;
+    unsigned char *b = static_cast<unsigned char *>(*slab);
+    double *f64 = reinterpret_cast<double *>(b + o_f64);
+    float *f32 = reinterpret_cast<float *>(b + o_f32);
+    st->px = f64; st->py = f64 + A; st->heading = f64 + 2 * A; st->t_rem = f64 + 3 * A;
+    st->gx = f32; st->gy = f32 + A; st->radius = f32 + 2 * A; st->pref = f32 + 3 * A; st->speed = f32 + 4 * A;
+    st->flags = reinterpret_cast<uint32_t *>(b + o_flags);
+    st->episode = reinterpret_cast<uint32_t *>(b + o_ep);
+    return CAVOID_OK;
+}
+
+static int grid_for(const cavoid_env *e, int64_t worlds) {
+    const int wpw = 64 / e->cfg.max_agents;
+    const int64_t waves = (worlds + wpw - 1) / wpw;
+    return (int)((waves + e->waves_per_block - 1) / e->waves_per_block);
+}
 
 extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t world_offset, int device, cavoid_env **out) {
     if (!out) return CAVOID_EINVAL;
@@ -137,27 +173,16 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     e->world_offset = world_offset;
     e->cfg = *cfg;
 
-    const size_t A = (size_t)e->A, W = (size_t)e->W;
-    size_t off = 0, o_f64 = off;
-    off = align_up(off + 4 * A * sizeof(double), 256);
-    size_t o_f32 = off;
-    off = align_up(off + 5 * A * sizeof(float), 256);
-    size_t o_flags = off;
-    off = align_up(off + A * sizeof(uint32_t), 256);
-    size_t o_ep = off;
-    off = align_up(off + W * sizeof(uint32_t), 256);
-    size_t o_act = off;
-    off = align_up(off + CAVOID_MAX_ACTIONS * 2 * sizeof(double), 256);
-    if (hipMalloc(&e->slab, off) != hipSuccess) { delete e; return CAVOID_ENOMEM; }
-    unsigned char *b = static_cast<unsigned char *>(e->slab);
-    double *f64 = reinterpret_cast<double *>(b + o_f64);
-    float *f32 = reinterpret_cast<float *>(b + o_f32);
-    e->st.px = f64; e->st.py = f64 + A; e->st.heading = f64 + 2 * A; e->st.t_rem = f64 + 3 * A;
-    e->st.gx = f32; e->st.gy = f32 + A; e->st.radius = f32 + 2 * A; e->st.pref = f32 + 3 * A; e->st.speed = f32 + 4 * A;
-    e->st.flags = reinterpret_cast<uint32_t *>(b + o_flags);
-    e->st.episode = reinterpret_cast<uint32_t *>(b + o_ep);
-    e->d_actions = reinterpret_cast<double *>(b + o_act);
-    if (hipMemset(e->slab, 0, off) != hipSuccess || hipMemset(e->st.episode, 0xFF, W * sizeof(uint32_t)) != hipSuccess ||
+    const size_t W = (size_t)e->W;
+    size_t o_act = 0, o_unused = 0;
+    rc = alloc_state(W, (size_t)cfg->max_agents, CAVOID_MAX_ACTIONS * 2 * sizeof(double), &e->slab, &e->st, &o_act);
+    if (rc == CAVOID_OK && cfg->gen_pool_size > 0) {
+        e->pool_size = cfg->gen_pool_size;
+        rc = alloc_state((size_t)e->pool_size, (size_t)cfg->max_agents, 0, &e->pool_slab, &e->pool, &o_unused);
+    }
+    if (rc != CAVOID_OK) { g_last_hip_error = (int)hipGetLastError(); cavoid_destroy(e); return rc; }
+    e->d_actions = reinterpret_cast<double *>(static_cast<unsigned char *>(e->slab) + o_act);
+    if (hipMemset(e->st.episode, 0xFF, W * sizeof(uint32_t)) != hipSuccess ||
         hipMemcpy(e->d_actions, cfg->actions, sizeof(cfg->actions), hipMemcpyHostToDevice) != hipSuccess ||
         hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError();
@@ -182,6 +207,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.sort_method = cfg->sort_method; k.dynamics = cfg->dynamics; k.actions_fp32 = cfg->actions_fp32;
     k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
     k.gen_min_agents = cfg->gen_min_agents; k.gen_max_agents = cfg->gen_max_agents;
+    k.pool_size = cfg->gen_pool_size;
     k.seed_lo = 0; k.seed_hi = 0;
     k.num_worlds = num_worlds; k.world_offset = world_offset;
     k.action_table = e->d_actions;
@@ -195,8 +221,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     if (wpb > 4) wpb = 4;
     e->waves_per_block = wpb;
     e->lds_bytes = per_wave * wpb;
-    const int64_t waves = (num_worlds + wpw - 1) / wpw;
-    e->grid = (int)((waves + wpb - 1) / wpb);
+    e->grid = grid_for(e, num_worlds);
     *out = e;
     return CAVOID_OK;
 }
@@ -206,6 +231,7 @@ extern "C" void cavoid_destroy(cavoid_env *e) {
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->slab) (void)hipFree(e->slab);
+    if (e->pool_slab) (void)hipFree(e->pool_slab);
     delete e;
 }
 
@@ -213,11 +239,12 @@ extern "C" int64_t cavoid_num_worlds(const cavoid_env *e) { return e ? e->W : 0;
 extern "C" int32_t cavoid_obs_width(const cavoid_env *e) { return e ? e->k.width : 0; }
 
 template <int MODE>
-static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    const dim3 grid(e->grid), block(64 * e->waves_per_block);
+static int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int grid_x, const KIO &io, hipStream_t s,
+                     hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const dim3 grid(grid_x), block(64 * e->waves_per_block);
     const size_t lds = e->lds_bytes;
 #define CAVOID_CASE(NN) \
-    case NN: hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, e->k, e->st, io); break;
+    case NN: hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, k, st, e->pool, io); break;
     switch (e->cfg.max_agents) {
         CAVOID_CASE(1) CAVOID_CASE(2) CAVOID_CASE(3) CAVOID_CASE(4) CAVOID_CASE(5) CAVOID_CASE(6)
         CAVOID_CASE(7) CAVOID_CASE(8) CAVOID_CASE(9) CAVOID_CASE(10) CAVOID_CASE(11) CAVOID_CASE(12)
@@ -229,6 +256,24 @@ static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_sta
     return CAVOID_OK;
 }
 
+template <int MODE>
+static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    return launch_on<MODE>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
+}
+
+// (re)fill the scenario pool for the current seed: the RESET kernel run over the pool buffer as
+// worlds 0..P-1, episode 0, generator in-kernel
+static int fill_pool(cavoid_env *e, hipStream_t s) {
+    if (e->pool_size <= 0) return CAVOID_OK;
+    HIP_TRY(hipMemsetAsync(e->pool.episode, 0xFF, (size_t)e->pool_size * sizeof(uint32_t), s));
+    KCfg k = e->k;
+    k.num_worlds = e->pool_size;
+    k.world_offset = 0;
+    k.pool_size = 0;
+    KIO io{};
+    return launch_on<MODE_RESET>(e, k, e->pool, grid_for(e, e->pool_size), io, s, nullptr, nullptr);
+}
+
 extern "C" int cavoid_seed(cavoid_env *e, uint64_t seed, const uint32_t *episode, void *stream) {
     if (!e) return CAVOID_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -236,7 +281,7 @@ extern "C" int cavoid_seed(cavoid_env *e, uint64_t seed, const uint32_t *episode
     e->k.seed_hi = (uint32_t)(seed >> 32);
     if (episode) HIP_TRY(hipMemcpyAsync(e->st.episode, episode, (size_t)e->W * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     else HIP_TRY(hipMemsetAsync(e->st.episode, 0xFF, (size_t)e->W * sizeof(uint32_t), s));
-    return CAVOID_OK;
+    return fill_pool(e, s);
 }
 
 extern "C" int cavoid_get_episode(cavoid_env *e, uint32_t *out, void *stream) {

@@ -16,8 +16,12 @@
 //   * the [agents, 1+D] observation tile is assembled in LDS and leaves as 16-byte coalesced
 //     stores (a lane-owns-a-row store would touch 64 cache lines per instruction);
 //   * float64 arithmetic throughout (the reference env is NumPy float64; flags are threshold
-//     tests that flip on fp32 rounding), compiled with -ffp-contract=off so that the only
-//     numerical difference from the float64 CPU oracle is sin/cos/atan2 (ocml vs libm, <=1 ulp).
+//     tests that flip on fp32 rounding), compiled with -ffp-contract=off so that everything that
+//     decides a flag, a reward branch or a sort order is the oracle's operation sequence; what
+//     differs is sin/cos/atan2 (<=1 ulp) and, on observation-only values, x*(1/d) for x/d;
+//   * a restart (auto-reset) is decided BEFORE the observation pass, so a step assembles
+//     observations exactly once; restarted worlds take their scenario from a pre-generated
+//     pool (a gather) instead of running the generator on the step's critical path.
 //   No MFMA: there is no dense contraction anywhere on this path.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -36,6 +40,7 @@ struct KCfg {
     double gen_nonlearning, gen_static, gen_goal_jitter, gen_angle_jitter;
     int32_t max_other, width, sort_method, dynamics, actions_fp32, timeout_enabled, num_actions;
     int32_t gen_min_agents, gen_max_agents;
+    int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
     const double *action_table;  // [num_actions][2]
@@ -101,8 +106,37 @@ struct Geometry {
     static constexpr int kLanes = kWorldsPerWave * N;  // active lanes per wavefront
 };
 
-// LDS carve per wavefront: 4 double[64] + 1 float[64] + obs tile float[kLanes*width]
-__host__ __device__ constexpr int lds_floats_fixed() { return 64 * 2 * 4 + 64; }
+// LDS carve per wavefront: 4 double[64] (pos, vel) + float[64] (radius) + double[64] (action
+// table, 32 x 2) + obs tile float[kLanes*width]
+__host__ __device__ constexpr int lds_floats_fixed() { return 64 * 2 * 4 + 64 + 64 * 2; }
+
+// sin/cos for |x| up to a few thousand: 2-term Cody-Waite reduction by pi/2 and the degree-13/14
+// kernels of the classic fdlibm sin/cos (max error ~1 ulp).  Headings live in [-pi, pi), so the
+// huge-argument path of a general sincos is dead weight on the step's critical path.
+__device__ __forceinline__ void sincos_bounded(double x, double *sn, double *cs) {
+    const double k = rint(x * 0.63661977236758134308);            // 2/pi
+    double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);   // pi/2, leading 33 bits
+    r = __builtin_fma(-k, 6.07710050650619224932e-11, r);          // pi/2 tail
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double s = __builtin_fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double s_out = (q & 1) ? c : s, c_out = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s_out : s_out;
+    *cs = ((q + 1) & 2) ? -c_out : c_out;
+}
 
 // GEN v1 scenario generator (E2; own specification, see oracle/cavoid_oracle.py generate_world)
 template <int N>
@@ -124,7 +158,7 @@ __device__ __forceinline__ void generate_agent(const KCfg &c, uint32_t gw, uint3
     const double turn = phase + (i + (u01(p.z) - 0.5) * 2.0 * c.gen_angle_jitter) / n;
     const double theta = 2.0 * kPi * turn;
     double sn, cs;
-    sincos(theta, &sn, &cs);
+    sincos_bounded(theta, &sn, &cs);
     a.px = ring * cs;
     a.py = ring * sn;
     a.gx = (float)(-a.px + (u01(q.x) - 0.5) * 2.0 * c.gen_goal_jitter);
@@ -141,17 +175,21 @@ __device__ __forceinline__ void generate_agent(const KCfg &c, uint32_t gw, uint3
     a.flags = CAVOID_F_PRESENT | (pol == 0u ? CAVOID_F_LEARNING : 0u) | (pol << CAVOID_F_POLICY_SHIFT);
 }
 
-// Ego frame of one host (x axis -> goal).
-struct Ego { double dist, prll_x, prll_y, orth_x, orth_y, heading_ego; };
+// Ego frame of one host (x axis -> goal).  (tx, ty) is the un-normalised goal direction: the
+// lateral-offset sort key uses it directly (same ordering as the normalised p_orth).
+struct Ego { double dist, tx, ty, prll_x, prll_y, heading_ego; };
 __device__ __forceinline__ Ego ego_frame(const Agent &a) {
     Ego e;
-    const double tx = (double)a.gx - a.px, ty = (double)a.gy - a.py;
-    e.dist = sqrt(tx * tx + ty * ty);
-    if (e.dist > 1e-8) { e.prll_x = tx / e.dist; e.prll_y = ty / e.dist; }
-    else { e.prll_x = tx; e.prll_y = ty; }
-    e.orth_x = -e.prll_y;
-    e.orth_y = e.prll_x;
-    e.heading_ego = wrap_angle(a.heading - atan2(e.prll_y, e.prll_x));
+    e.tx = (double)a.gx - a.px;
+    e.ty = (double)a.gy - a.py;
+    e.dist = sqrt(e.tx * e.tx + e.ty * e.ty);
+    const double inv = e.dist > 1e-8 ? 1.0 / e.dist : 1.0;
+    e.prll_x = e.tx * inv;
+    e.prll_y = e.ty * inv;
+    double h = a.heading - atan2(e.prll_y, e.prll_x);
+    h = h >= kPi ? h - 2.0 * kPi : h;            // |heading| <= pi and |atan2| <= pi: one fold each way
+    h = h < -kPi ? h + 2.0 * kPi : h;
+    e.heading_ego = h;
     return e;
 }
 
@@ -165,120 +203,130 @@ __device__ __forceinline__ double time_to_impact(double rx, double ry, double vx
     return (bb - sqrt(disc)) / aa;
 }
 
-// E6 + E9 for the lane's host agent.  All 64 lanes of the wavefront must call this together.
-//   lds_*: wave-private staging arrays; tile: wave-private obs tile [kLanes][width]
-//   emit: this lane rewrites its obs row (false: keep what the tile holds)
-// Outputs hit / min_gap feed the reward (E7).
+// E6: centre distances to every agent of the lane's world (from the LDS-staged positions), the
+// collision test and the nearest gap.  All 64 lanes call this together.
 template <int N>
-__device__ __forceinline__ void sense_world(const KCfg &c, const Agent &a, const Ego &e, int lane, int i, int base,
-                                            bool active, bool emit, double *lds_px, double *lds_py,
-                                            double *lds_vx, double *lds_vy, float *lds_r, float *tile,
-                                            bool &hit, double &min_gap) {
-    const bool present = active && (a.flags & CAVOID_F_PRESENT);
-    lds_px[lane] = a.px;
-    lds_py[lane] = a.py;
-    lds_vx[lane] = a.vx;
-    lds_vy[lane] = a.vy;
-    lds_r[lane] = present ? a.radius : -1.0f;     // radius < 0 marks an absent row
-    wave_lds_sync();
-
-    const int M = c.max_other, width = c.width;
+__device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, bool present, int i, int base,
+                                          const double *lds_px, const double *lds_py, const float *lds_r,
+                                          double (&dist)[N], uint32_t &others, bool &hit, double &min_gap) {
     const double ri = (double)a.radius;
-    double key0[N], key1[N], key2[N];
-    uint32_t valid = 0u;
+    others = 0u;
     hit = false;
     min_gap = INFINITY;
-    const bool tti_sort = c.sort_method == CAVOID_SORT_TIME_TO_IMPACT;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const float rjf = lds_r[base + j];
-        const double rj = (double)rjf;
         const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
         const double d = sqrt(rx * rx + ry * ry);
+        dist[j] = d;
         const bool other = present && (j != i) && (rjf >= 0.0f);
-        // E6: unordered-pair gap d - (r_lo + r_hi); the sum is commutative so either end agrees
-        const double gap_c = d - (ri + rj);
-        if (other) {
-            min_gap = fmin(min_gap, gap_c);
-            hit = hit || (gap_c <= c.collision_dist);
-        }
-        // E9 sort criteria: gap rounded to centimetres, then lateral offset
-        const double gap_s = d - ri - rj;
-        const double p_orth = rx * e.orth_x + ry * e.orth_y;
-        const double gr = rint(gap_s * 100.0);      // order-isomorphic to rint(.)/100
-        const bool seen = other && !(d > c.horizon);
-        if (tti_sort) {
-            const double tti = time_to_impact(rx, ry, a.vx - lds_vx[base + j], a.vy - lds_vy[base + j], ri + rj);
-            key0[j] = -tti; key1[j] = -gr; key2[j] = p_orth;
-        } else {
-            key0[j] = -gr; key1[j] = p_orth; key2[j] = 0.0;
-        }
-        valid |= seen ? (1u << j) : 0u;
+        // unordered-pair gap d - (r_lo + r_hi): the sum is commutative, both ends agree bitwise
+        const double gap_c = d - (ri + (double)rjf);
+        min_gap = other ? fmin(min_gap, gap_c) : min_gap;
+        hit = hit || (other && gap_c <= c.collision_dist);
+        others |= other ? (1u << j) : 0u;
     }
+}
 
-    // stable ranks by counting: pos = number of seen agents strictly before j in far->near order
+// E9: neighbour ordering by counting ranks + the lane's observation row into the LDS tile.
+template <int N>
+__device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int base,
+                                             const double *lds_px, const double *lds_py, const double *lds_vx,
+                                             const double *lds_vy, const float *lds_r, const double (&dist)[N],
+                                             uint32_t others, float *tile) {
+    const int M = c.max_other, width = c.width;
+    const bool present = active && (a.flags & CAVOID_F_PRESENT);
+    const double ri = (double)a.radius;
+    // sort criteria: gap rounded to centimetres (rint(gap*100) is order-isomorphic to round(gap,2)),
+    // then the lateral offset; its sign-preserving un-normalised form ry*tx - rx*ty orders the same
+    double gr[N], lat[N];
+    uint32_t valid = 0u;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double rj = (double)lds_r[base + j];
+        const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
+        gr[j] = rint((dist[j] - ri - rj) * 100.0);
+        lat[j] = ry * e.tx - rx * e.ty;
+        valid |= (((others >> j) & 1u) && !(dist[j] > c.horizon)) ? (1u << j) : 0u;
+    }
     const int m = __popc(valid);
     const int first = m > M ? m - M : 0;
     const int kept = m - first;
     int slot[N];
     uint32_t keep = 0u;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        int pos = 0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (k == j) continue;
-            const bool lt = (key0[k] < key0[j]) ||
-                            (key0[k] == key0[j] && (key1[k] < key1[j] || (key1[k] == key1[j] && (key2[k] < key2[j] || (key2[k] == key2[j] && k < j)))));
-            pos += (lt && ((valid >> k) & 1u)) ? 1 : 0;
-        }
-        slot[j] = pos - first;
-        keep |= (((valid >> j) & 1u) && pos >= first) ? (1u << j) : 0u;
-    }
-    if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {
-        // re-rank the kept set near->far on (+gap, p_orth); full ties keep index order
+    if (c.sort_method == CAVOID_SORT_TIME_TO_IMPACT) {
+        double tti[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
+            const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
+            tti[j] = time_to_impact(rx, ry, a.vx - lds_vx[base + j], a.vy - lds_vy[base + j], ri + (double)lds_r[base + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {       // far -> near: larger time first, then larger gap, then smaller lateral
             int pos = 0;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 if (k == j) continue;
-                const bool lt = (key0[k] > key0[j]) ||
-                                (key0[k] == key0[j] && (key1[k] < key1[j] || (key1[k] == key1[j] && k < j)));
-                pos += (lt && ((keep >> k) & 1u)) ? 1 : 0;
+                const bool before = (tti[k] > tti[j]) ||
+                                    (tti[k] == tti[j] && (gr[k] > gr[j] || (gr[k] == gr[j] && (lat[k] < lat[j] || (lat[k] == lat[j] && k < j)))));
+                pos += (before && ((valid >> k) & 1u)) ? 1 : 0;
             }
-            slot[j] = pos;
+            slot[j] = pos - first;
+            keep |= (((valid >> j) & 1u) && pos >= first) ? (1u << j) : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {       // far -> near: larger gap first, then smaller lateral, then index
+            int pos = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (k == j) continue;
+                const bool before = (gr[k] > gr[j]) || (gr[k] == gr[j] && (lat[k] < lat[j] || (lat[k] == lat[j] && k < j)));
+                pos += (before && ((valid >> k) & 1u)) ? 1 : 0;
+            }
+            slot[j] = pos - first;
+            keep |= (((valid >> j) & 1u) && pos >= first) ? (1u << j) : 0u;
+        }
+        if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {   // kept set re-ranked near -> far; full ties keep index order
+                int pos = 0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if (k == j) continue;
+                    const bool before = (gr[k] < gr[j]) || (gr[k] == gr[j] && (lat[k] < lat[j] || (lat[k] == lat[j] && k < j)));
+                    pos += (before && ((keep >> k) & 1u)) ? 1 : 0;
+                }
+                slot[j] = pos;
+            }
         }
     }
 
-    if (emit && active) {
+    if (active) {
         float *row = tile + lane * width;
-        for (int k = 0; k < width; ++k) row[k] = 0.0f;
-        if (present) {
-            row[0] = (a.flags & CAVOID_F_LEARNING) ? 1.0f : 0.0f;
-            row[1] = (float)kept;
-            row[2] = (float)e.dist;
-            row[3] = (float)e.heading_ego;
-            row[4] = a.pref;
-            row[5] = a.radius;
+        row[0] = (present && (a.flags & CAVOID_F_LEARNING)) ? 1.0f : 0.0f;
+        row[1] = (float)kept;                                   // 0 for an absent agent (others == 0)
+        row[2] = present ? (float)e.dist : 0.0f;
+        row[3] = present ? (float)e.heading_ego : 0.0f;
+        row[4] = present ? a.pref : 0.0f;
+        row[5] = present ? a.radius : 0.0f;
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                if (!((keep >> j) & 1u)) continue;
-                const double rj = (double)lds_r[base + j];
-                const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
-                const double ovx = lds_vx[base + j], ovy = lds_vy[base + j];
-                float *f = row + 6 + 7 * slot[j];
-                f[0] = (float)(rx * e.prll_x + ry * e.prll_y);
-                f[1] = (float)(rx * e.orth_x + ry * e.orth_y);
-                f[2] = (float)(ovx * e.prll_x + ovy * e.prll_y);
-                f[3] = (float)(ovx * e.orth_x + ovy * e.orth_y);
-                f[4] = (float)rj;
-                f[5] = (float)(ri + rj);
-                f[6] = (float)(sqrt(rx * rx + ry * ry) - ri - rj);
-            }
+        for (int j = 0; j < N; ++j) {
+            if (!((keep >> j) & 1u)) continue;
+            const double rj = (double)lds_r[base + j];
+            const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
+            const double ovx = lds_vx[base + j], ovy = lds_vy[base + j];
+            float *f = row + 6 + 7 * slot[j];
+            f[0] = (float)(rx * e.prll_x + ry * e.prll_y);
+            f[1] = (float)(ry * e.prll_x - rx * e.prll_y);
+            f[2] = (float)(ovx * e.prll_x + ovy * e.prll_y);
+            f[3] = (float)(ovy * e.prll_x - ovx * e.prll_y);
+            f[4] = (float)rj;
+            f[5] = (float)(ri + rj);
+            f[6] = (float)(dist[j] - ri - rj);
         }
+        for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;   // unfilled slots
     }
-    wave_lds_sync();
 }
 
 // Coalesced write-out of the wave's obs tile: n_floats contiguous floats starting at dst.
@@ -292,10 +340,37 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
     }
 }
 
+__device__ __forceinline__ void load_agent(const KState &s, int64_t k, Agent &a) {
+    a.px = s.px[k]; a.py = s.py[k]; a.heading = s.heading[k]; a.t_rem = s.t_rem[k];
+    a.gx = s.gx[k]; a.gy = s.gy[k]; a.radius = s.radius[k]; a.pref = s.pref[k];
+    a.flags = s.flags[k];
+}
+
+__device__ __forceinline__ void store_agent(const KState &s, int64_t k, const Agent &a) {
+    s.px[k] = a.px; s.py[k] = a.py; s.heading[k] = a.heading; s.t_rem[k] = a.t_rem;
+    s.gx[k] = a.gx; s.gy[k] = a.gy; s.radius[k] = a.radius; s.pref[k] = a.pref;
+    s.speed[k] = a.speed; s.flags[k] = a.flags;
+}
+
+// Scenario of (global world gw, episode ep): a gather from the pre-generated pool (pool entry k is
+// GEN v1's world k, episode 0) or, with no pool, the generator itself.
+template <int N>
+__device__ __forceinline__ void new_episode(const KCfg &c, const KState &pool, uint32_t gw, uint32_t ep, int i, Agent &a) {
+    if (c.pool_size > 0) {
+        const U4 r = philox4x32(gw, ep, 3u, 0u, c.seed_lo, c.seed_hi);
+        const int64_t k = (int64_t)(r.x % (uint32_t)c.pool_size) * N + i;
+        load_agent(pool, k, a);
+        a.vx = a.vy = 0.0;
+        a.speed = 0.0f;
+    } else {
+        generate_agent<N>(c, gw, ep, i, a);
+    }
+}
+
 enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESET = 3 };
 
 template <int N, int MODE>
-__global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, const KIO io) {
+__global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, const KState pool, const KIO io) {
     using G = Geometry<N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -304,8 +379,8 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     const int per_wave_floats = lds_floats_fixed() + tile_floats;
     float *wbase = reinterpret_cast<float *>(smem) + (size_t)wave_in_block * per_wave_floats;
     double *lds_px = reinterpret_cast<double *>(wbase);
-    double *lds_py = lds_px + 64, *lds_vx = lds_py + 64, *lds_vy = lds_vx + 64;
-    float *lds_r = reinterpret_cast<float *>(lds_vy + 64);
+    double *lds_py = lds_px + 64, *lds_vx = lds_py + 64, *lds_vy = lds_vx + 64, *lds_tab = lds_vy + 64;
+    float *lds_r = reinterpret_cast<float *>(lds_tab + 64);
     float *tile = lds_r + 64;
 
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
@@ -313,94 +388,98 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = w0 + lw;
     const bool active = lane < G::kLanes && w < c.num_worlds;
-    const int base = lane < G::kLanes ? lw * N : 0;     // first lane of this lane's world
+    const int base = lane < G::kLanes ? lw * N : 0;        // first lane of this lane's world
     const int64_t a_idx = w * N + i;                       // == w0*N + lane: contiguous per wave
+    const bool stepping = MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET;
+
+    // action table -> LDS (overlaps the state loads; the decode then needs no second trip to memory)
+    if (stepping && io.actions && lane < 2 * c.num_actions) lds_tab[lane] = c.action_table[lane];
 
     Agent a;
     a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
     a.gx = a.gy = a.radius = a.pref = a.speed = 0.0f;
     a.flags = 0u;
     uint32_t episode = 0u;
-    bool regenerate = false;
+    bool fresh = false;                                    // this lane's world starts a new episode
+    int act = 0;
+    float c0 = 0.f, c1 = 0.f;
     if (active) {
         if (MODE == MODE_RESET) {
-            regenerate = io.mask == nullptr || io.mask[w] != 0;
-            episode = s.episode[w] + (regenerate ? 1u : 0u);
+            fresh = io.mask == nullptr || io.mask[w] != 0;
+            episode = s.episode[w] + (fresh ? 1u : 0u);
         } else if (MODE == MODE_STEP_AUTORESET) {
             episode = s.episode[w];
         }
-        if (!(MODE == MODE_RESET && regenerate)) {
-            a.px = s.px[a_idx]; a.py = s.py[a_idx]; a.heading = s.heading[a_idx]; a.t_rem = s.t_rem[a_idx];
-            a.gx = s.gx[a_idx]; a.gy = s.gy[a_idx]; a.radius = s.radius[a_idx]; a.pref = s.pref[a_idx];
-            a.flags = s.flags[a_idx];
-            if (MODE == MODE_OBSERVE || MODE == MODE_RESET) a.speed = s.speed[a_idx];
+        if (!fresh) {
+            load_agent(s, a_idx, a);
+            if (!stepping) a.speed = s.speed[a_idx];
+        }
+        if (stepping) {
+            if (io.cont) { c0 = io.cont[2 * a_idx]; c1 = io.cont[2 * a_idx + 1]; }
+            else act = io.actions[a_idx];
         }
     }
-
     const uint32_t flags_in = a.flags;
-    const bool present = active && (flags_in & CAVOID_F_PRESENT);
+    const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
 
     if (MODE == MODE_RESET) {
-        if (active && regenerate) generate_agent<N>(c, (uint32_t)(c.world_offset + w), episode, i, a);
+        if (fresh) new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
     }
     if (MODE == MODE_OBSERVE || MODE == MODE_RESET) {
-        if (present || (MODE == MODE_RESET && regenerate)) {
-            double sn, cs;
-            sincos(a.heading, &sn, &cs);
-            a.vx = (double)a.speed * cs;
-            a.vy = (double)a.speed * sn;
-        }
+        double sn, cs;
+        sincos_bounded(a.heading, &sn, &cs);
+        a.vx = (double)a.speed * cs;
+        a.vy = (double)a.speed * sn;
     }
 
-    if (MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET) {
-        // ---- E4 decode + E5 dynamics --------------------------------------------------------
-        if (present && done_in) {
-            if (flags_in & CAVOID_F_AT_GOAL) a.flags |= CAVOID_F_WAS_AT_GOAL;
-            if (flags_in & CAVOID_F_IN_COLL) a.flags |= CAVOID_F_WAS_IN_COLL;
-            a.vx = a.vy = 0.0;
-            a.speed = 0.0f;
-        } else if (present) {
-            const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
-            double a0 = 0.0, a1 = 0.0;
-            if (pol == 0u) {
-                if (io.cont) { a0 = (double)io.cont[2 * a_idx]; a1 = (double)io.cont[2 * a_idx + 1]; }
-                else {
-                    int act = io.actions[a_idx];
-                    act = act < 0 ? 0 : (act >= c.num_actions ? c.num_actions - 1 : act);
-                    a0 = (double)a.pref * c.action_table[2 * act];
-                    a1 = c.action_table[2 * act + 1];
-                }
-            } else if (pol == 2u) {
-                const Ego e0 = ego_frame(a);            // non-cooperative: pref speed straight at the goal
+    if (stepping) {
+        // ---- E4 decode ------------------------------------------------------------------------------
+        wave_lds_sync();
+        const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
+        double a0 = 0.0, a1 = 0.0;
+        if (io.cont) { a0 = (double)c0; a1 = (double)c1; }
+        else {
+            act = act < 0 ? 0 : (act >= c.num_actions ? c.num_actions - 1 : act);
+            a0 = (double)a.pref * lds_tab[2 * act];
+            a1 = lds_tab[2 * act + 1];
+        }
+        if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {   // scripted agents in this tile
+            if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
+            if (pol == 2u) {                                            // straight at the goal, full speed
+                const Ego e0 = ego_frame(a);
                 a0 = (double)a.pref;
                 a1 = -e0.heading_ego;
             }
-            if (c.actions_fp32) { a0 = (double)(float)a0; a1 = (double)(float)a1; }
-            if (c.dynamics == CAVOID_DYN_HOLONOMIC) {
-                const double sp = sqrt(a0 * a0 + a1 * a1);
-                if (sp > 0.0) a.heading = atan2(a1, a0);
-                a.px += a0 * c.dt; a.py += a1 * c.dt;
-                a.vx = a0; a.vy = a1; a.speed = (float)sp;
-            } else {
-                double dh = a1;
-                if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
-                    const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
-                    dh = rate * c.dt;
-                }
-                const double h = wrap_angle(dh + a.heading);
-                double sn, cs;
-                sincos(h, &sn, &cs);
-                a.px += a0 * cs * c.dt; a.py += a0 * sn * c.dt;
-                a.vx = a0 * cs; a.vy = a0 * sn; a.speed = (float)a0; a.heading = h;
-            }
         }
-    }
-
-    Ego e = ego_frame(a);
-
-    if (MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET) {
-        if (present && !done_in) {
+        if (c.actions_fp32) { a0 = (double)(float)a0; a1 = (double)(float)a1; }
+        // ---- E5 dynamics (computed by every lane, committed only by agents still running) ------------
+        const bool moving = present_in && !done_in;
+        double npx, npy, nh, nvx, nvy, nsp;
+        if (c.dynamics == CAVOID_DYN_HOLONOMIC) {
+            nsp = sqrt(a0 * a0 + a1 * a1);
+            nh = nsp > 0.0 ? atan2(a1, a0) : a.heading;
+            npx = a.px + a0 * c.dt; npy = a.py + a1 * c.dt;
+            nvx = a0; nvy = a1;
+        } else {
+            double dh = a1;
+            if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
+                const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
+                dh = rate * c.dt;
+            }
+            nh = wrap_angle(dh + a.heading);
+            double sn, cs;
+            sincos_bounded(nh, &sn, &cs);
+            npx = a.px + a0 * cs * c.dt; npy = a.py + a0 * sn * c.dt;
+            nvx = a0 * cs; nvy = a0 * sn; nsp = a0;
+        }
+        a.px = moving ? npx : a.px; a.py = moving ? npy : a.py; a.heading = moving ? nh : a.heading;
+        a.vx = moving ? nvx : 0.0; a.vy = moving ? nvy : 0.0; a.speed = moving ? (float)nsp : 0.0f;
+        if (present_in && done_in) {                                    // frozen: latch the 'already' flags
+            if (flags_in & CAVOID_F_AT_GOAL) a.flags |= CAVOID_F_WAS_AT_GOAL;
+            if (flags_in & CAVOID_F_IN_COLL) a.flags |= CAVOID_F_WAS_IN_COLL;
+        }
+        if (moving) {
             const double dx = a.px - (double)a.gx, dy = a.py - (double)a.gy;
             if (dx * dx + dy * dy <= c.near_goal_sq) a.flags |= CAVOID_F_AT_GOAL;
             a.t_rem -= c.dt;
@@ -408,13 +487,21 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
         }
     }
 
-    // ---- E6 + E9 ----------------------------------------------------------------------------
+    // ---- stage post-move state in LDS; E6 pair pass (ego frame in the same block: independent chains) ---
+    bool present = active && (a.flags & CAVOID_F_PRESENT);
+    lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = a.vx; lds_vy[lane] = a.vy;
+    lds_r[lane] = present ? a.radius : -1.0f;              // radius < 0 marks an absent row
+    wave_lds_sync();
+    Ego e = ego_frame(a);
+    double dist[N];
+    uint32_t others;
     bool hit;
     double min_gap;
-    sense_world<N>(c, a, e, lane, i, base, active, true, lds_px, lds_py, lds_vx, lds_vy, lds_r, tile, hit, min_gap);
+    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, dist, others, hit, min_gap);
 
-    if (MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET) {
-        // ---- E7 rewards, E8 done -------------------------------------------------------------
+    bool restart = false;
+    if (stepping) {
+        // ---- E7 rewards, E8 done ---------------------------------------------------------------------
         double r = 0.0;
         bool done = true;
         if (present) {
@@ -429,56 +516,62 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
         }
         // game over <=> no learning agent of the world is still running
         const unsigned long long running = __ballot(present && (a.flags & CAVOID_F_LEARNING) && !done);
-        const unsigned long long wmask = ((N == 64) ? ~0ull : ((1ull << N) - 1ull)) << base;
+        const unsigned long long wmask = ((1ull << N) - 1ull) << base;
         const bool game_over = (running & wmask) == 0ull;
         if (active) {
             io.rew[a_idx] = (float)r;
             io.done[a_idx] = done ? 1 : 0;
             if (i == 0) io.game_over[w] = game_over ? 1 : 0;
         }
-
-        bool restart = false;
         if (MODE == MODE_STEP_AUTORESET) {
             restart = active && game_over;
-            if (__ballot(restart) != 0ull) {              // wave-uniform: some world of this tile restarts
+            if (__ballot(restart) != 0ull) {               // wave-uniform: some world of this tile restarts
+                wave_lds_sync();                           // every lane is done reading the old positions
                 if (restart) {
                     episode += 1u;
-                    generate_agent<N>(c, (uint32_t)(c.world_offset + w), episode, i, a);
-                    e = ego_frame(a);
+                    new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
+                    present = (a.flags & CAVOID_F_PRESENT) != 0u;
+                    lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = 0.0; lds_vy[lane] = 0.0;
+                    lds_r[lane] = present ? a.radius : -1.0f;
                 }
-                bool hit2;
-                double gap2;
-                sense_world<N>(c, a, e, lane, i, base, active, restart, lds_px, lds_py, lds_vx, lds_vy, lds_r, tile, hit2, gap2);
+                wave_lds_sync();
+                if (restart) {
+                    e = ego_frame(a);
+                    bool hit2;
+                    double gap2;
+                    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, dist, others, hit2, gap2);
+                }
             }
         }
-        if (restart) {                                   // fresh episode: every field of every row
-            s.px[a_idx] = a.px; s.py[a_idx] = a.py; s.heading[a_idx] = a.heading; s.t_rem[a_idx] = a.t_rem;
-            s.gx[a_idx] = a.gx; s.gy[a_idx] = a.gy; s.radius[a_idx] = a.radius; s.pref[a_idx] = a.pref;
-            s.speed[a_idx] = a.speed; s.flags[a_idx] = a.flags;
+    }
+
+    // ---- E9 observation: once per step, after the restart decision -----------------------------------
+    if (io.obs) {
+        assemble_obs<N>(c, a, e, active, lane, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, dist, others, tile);
+        wave_lds_sync();
+        int64_t worlds_here = c.num_worlds - w0;
+        if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
+        if (worlds_here > 0) flush_tile(tile, io.obs + w0 * N * width, (int)worlds_here * N * width, lane);
+    }
+
+    // ---- state write-back ---------------------------------------------------------------------------
+    if (stepping) {
+        if (restart) {                                     // fresh episode: every field of every row
+            store_agent(s, a_idx, a);
             if (i == 0) s.episode[w] = episode;
-        } else if (present) {
-            if (!done_in) {                              // frozen agents keep pos / heading / time
+        } else if (present_in) {
+            if (!done_in) {                                // frozen agents keep pos / heading / time
                 s.px[a_idx] = a.px; s.py[a_idx] = a.py; s.heading[a_idx] = a.heading; s.t_rem[a_idx] = a.t_rem;
             }
             s.speed[a_idx] = a.speed;
             s.flags[a_idx] = a.flags;
         }
     }
-
     if (MODE == MODE_RESET) {
-        if (active && regenerate) {
-            s.px[a_idx] = a.px; s.py[a_idx] = a.py; s.heading[a_idx] = a.heading; s.t_rem[a_idx] = a.t_rem;
-            s.gx[a_idx] = a.gx; s.gy[a_idx] = a.gy; s.radius[a_idx] = a.radius; s.pref[a_idx] = a.pref;
-            s.speed[a_idx] = a.speed; s.flags[a_idx] = a.flags;
+        if (fresh) {
+            store_agent(s, a_idx, a);
             if (i == 0) s.episode[w] = episode;
         }
-    }
-
-    if (io.obs) {
-        int64_t worlds_here = c.num_worlds - w0;
-        if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
-        if (worlds_here > 0)
-            flush_tile(tile, io.obs + w0 * N * width, (int)worlds_here * N * width, lane);
     }
 }
 

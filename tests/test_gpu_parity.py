@@ -29,9 +29,12 @@ def _env(W, N, M=None, seed=0, **over):
     return BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=seed, **over)
 
 
-def _oracle(N, M=None, gen_min=None, nonl=0.0, **over):
+DEFAULT_POOL = 65536     # cavoid_default_cfg's gen_pool_size
+
+
+def _oracle(N, M=None, gen_min=None, nonl=0.0, pool=DEFAULT_POOL, **over):
     cfg = co.default_cfg(N, N - 1 if M is None else M, **over)
-    gen = co.default_gen(N if gen_min is None else gen_min, N, nonl)
+    gen = co.default_gen(N if gen_min is None else gen_min, N, nonl, pool_size=pool)
     return cfg, gen
 
 
@@ -105,10 +108,11 @@ def test_trajectory_parity(N, M, sort, nonl, gen_min):
     env.close()
 
 
-def test_reset_generator_parity():
+@pytest.mark.parametrize("pool", [0, 500, DEFAULT_POOL])
+def test_reset_generator_parity(pool):
     W, N, seed = 1000, 6, 99
-    ocfg, ogen = _oracle(N, None, 2, 0.3)
-    env = _env(W, N, seed=seed, gen_min_agents=2, gen_nonlearning_fraction=0.3)
+    ocfg, ogen = _oracle(N, None, 2, 0.3, pool=pool)
+    env = _env(W, N, seed=seed, gen_min_agents=2, gen_nonlearning_fraction=0.3, gen_pool_size=pool)
     obs = env.reset().cpu().numpy()
     st = co.State.empty(W, N)
     co.generate(ocfg, ogen, seed, st, np.zeros(W, np.uint32))
@@ -130,11 +134,12 @@ def test_reset_generator_parity():
     env.close()
 
 
-@pytest.mark.parametrize("N,gen_min,nonl", [(4, 4, 0.0), (10, 2, 0.2)])
-def test_autoreset_parity(N, gen_min, nonl):
+@pytest.mark.parametrize("N,gen_min,nonl,pool", [(4, 4, 0.0, DEFAULT_POOL), (4, 4, 0.0, 0), (10, 2, 0.2, 300), (10, 2, 0.2, 0),
+                                                 (3, 1, 0.5, 7)])
+def test_autoreset_parity(N, gen_min, nonl, pool):
     W, steps, seed = 512, 300, 5
-    ocfg, ogen = _oracle(N, None, gen_min, nonl)
-    env = _env(W, N, seed=seed, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
+    ocfg, ogen = _oracle(N, None, gen_min, nonl, pool=pool)
+    env = _env(W, N, seed=seed, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl, gen_pool_size=pool)
     env.reset()
     st = co.State.empty(W, N)
     ep = np.zeros(W, np.uint32)
@@ -146,7 +151,7 @@ def test_autoreset_parity(N, gen_min, nonl):
         ora = co.step_autoreset(ocfg, ogen, seed, st, ep, acts)
         _compare_step(("autoreset", N, t), out, ora, env, st)
         assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep)
-    assert (ep >= 1).mean() > 0.9       # nearly every world finished at least one episode
+    assert (ep >= 1).mean() > 0.8       # most worlds finished at least one episode
     env.close()
 
 
