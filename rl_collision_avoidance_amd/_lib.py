@@ -7,7 +7,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _DEFAULT_LIB_PATH
+
+# CAVOID_LIB selects another build of the SAME HIP library (e.g. the phase-tracing development
+# variant); it is not a fallback mechanism.
+LIB_PATH = os.environ.get("CAVOID_LIB", _DEFAULT_LIB_PATH)
 
 MAX_ACTIONS = 32
 MAX_AGENTS = 16

@@ -41,5 +41,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_trace(verbose: bool = False) -> str:
+    """Development variant with in-kernel phase time stamps (tools/trace_step.py); never loaded by
+    the product (select it with CAVOID_LIB=<path>)."""
+    out = os.path.join(PKG_DIR, "libcavoid_hip_trace.so")
+    cmd = [hipcc()] + FLAGS + ["-DCAVOID_TRACE"] + SOURCES + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build_trace(verbose=True) if "--trace" in sys.argv else build(force=True, verbose=True))

@@ -398,6 +398,14 @@ extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actio
     return rc;
 }
 
+#ifdef CAVOID_TRACE
+// development build only: point the kernels' phase-stamp buffer (u64 [waves][16]) somewhere
+extern "C" int cavoid_debug_trace(unsigned long long *dev_ptr) {
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dev_ptr, sizeof(dev_ptr)));
+    return CAVOID_OK;
+}
+#endif
+
 extern "C" int cavoid_timer_begin(cavoid_env *e, void *stream) {
     if (!e) return CAVOID_EINVAL;
     HIP_TRY(hipEventRecord(e->ev0, static_cast<hipStream_t>(stream)));

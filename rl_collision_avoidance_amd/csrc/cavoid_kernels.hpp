@@ -31,6 +31,18 @@
 
 namespace cavoid {
 
+// Development aid (never in the product build): -DCAVOID_TRACE makes lane 0 of every wavefront
+// stamp the shader clock at the phase boundaries into g_trace[wave*16 + k] (tools/trace_step.py).
+#ifdef CAVOID_TRACE
+__device__ unsigned long long *g_trace = nullptr;
+#define CAVOID_STAMP(k)                                                                \
+    do {                                                                               \
+        if (lane == 0 && g_trace) g_trace[wave * 16 + (k)] = (unsigned long long)clock64(); \
+    } while (0)
+#else
+#define CAVOID_STAMP(k) do { } while (0)
+#endif
+
 constexpr double kPi = 3.14159265358979323846;
 
 // kernel-argument POD (by value).  The action table lives in device memory (per-lane index).
@@ -178,7 +190,10 @@ __device__ __forceinline__ void generate_agent(const KCfg &c, uint32_t gw, uint3
 // Ego frame of one host (x axis -> goal).  (tx, ty) is the un-normalised goal direction: the
 // lateral-offset sort key uses it directly (same ordering as the normalised p_orth).
 struct Ego { double dist, tx, ty, prll_x, prll_y, heading_ego; };
-__device__ __forceinline__ Ego ego_frame(const Agent &a) {
+
+// exact form: correctly-rounded sqrt, float64 atan2.  Used where the result feeds the STATE (the
+// non-cooperative policy steers by -heading_ego).
+__device__ __forceinline__ Ego ego_frame_exact(const Agent &a) {
     Ego e;
     e.tx = (double)a.gx - a.px;
     e.ty = (double)a.gy - a.py;
@@ -188,6 +203,30 @@ __device__ __forceinline__ Ego ego_frame(const Agent &a) {
     e.prll_y = e.ty * inv;
     double h = a.heading - atan2(e.prll_y, e.prll_x);
     h = h >= kPi ? h - 2.0 * kPi : h;            // |heading| <= pi and |atan2| <= pi: one fold each way
+    h = h < -kPi ? h + 2.0 * kPi : h;
+    e.heading_ego = h;
+    return e;
+}
+
+// observation form: everything here ends in a float32 observation (tolerance 1e-5) and never in a
+// flag, a reward branch, a sort key or the state, so the long float64 sqrt/div/atan2 chains are
+// replaced by a Newton-refined v_rsq_f32 seed (relative error ~1e-14) and a float32 atan2
+// (absolute error < 1e-6 rad) -- a third of the dependent latency of the exact form.
+__device__ __forceinline__ Ego ego_frame_obs(const Agent &a) {
+    Ego e;
+    e.tx = (double)a.gx - a.px;
+    e.ty = (double)a.gy - a.py;
+    const double ss = e.tx * e.tx + e.ty * e.ty;
+    const bool tiny = !(ss > 1e-16);                                  // dist <= 1e-8: axes stay un-normalised
+    double y = (double)__builtin_amdgcn_rsqf((float)ss);              // ~1e-7 relative
+    y = y * __builtin_fma(-0.5 * ss, y * y, 1.5);                     // -> ~1e-14
+    y = y * __builtin_fma(-0.5 * ss, y * y, 1.5);
+    e.dist = tiny ? sqrt(ss) : ss * y;
+    const double inv = tiny ? 1.0 : y;
+    e.prll_x = e.tx * inv;
+    e.prll_y = e.ty * inv;
+    double h = a.heading - (double)atan2f((float)e.ty, (float)e.tx);
+    h = h >= kPi ? h - 2.0 * kPi : h;
     h = h < -kPi ? h + 2.0 * kPi : h;
     e.heading_ego = h;
     return e;
@@ -334,7 +373,20 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
     if ((n_floats & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
         const float4 *src4 = reinterpret_cast<const float4 *>(tile);
         float4 *dst4 = reinterpret_cast<float4 *>(dst);
-        for (int k = lane; k < (n_floats >> 2); k += 64) dst4[k] = src4[k];
+        const int n4 = n_floats >> 2;
+        for (int k0 = lane; k0 < n4; k0 += 64 * 8) {       // 8 LDS reads in flight, then 8 stores
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u;
+                v[u] = k < n4 ? src4[k] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u;
+                if (k < n4) dst4[k] = v[u];
+            }
+        }
     } else {
         for (int k = lane; k < n_floats; k += 64) dst[k] = tile[k];
     }
@@ -391,9 +443,13 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     const int base = lane < G::kLanes ? lw * N : 0;        // first lane of this lane's world
     const int64_t a_idx = w * N + i;                       // == w0*N + lane: contiguous per wave
     const bool stepping = MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET;
+    CAVOID_STAMP(0);
 
-    // action table -> LDS (overlaps the state loads; the decode then needs no second trip to memory)
-    if (stepping && io.actions && lane < 2 * c.num_actions) lds_tab[lane] = c.action_table[lane];
+    // action table -> LDS: the load is issued first and lands together with the state loads; the
+    // decode then needs no second trip to memory
+    double tab_v = 0.0;
+    const bool use_table = stepping && io.actions != nullptr;
+    if (use_table && lane < 2 * c.num_actions) tab_v = c.action_table[lane];
 
     Agent a;
     a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
@@ -419,6 +475,8 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
             else act = io.actions[a_idx];
         }
     }
+    if (use_table) lds_tab[lane] = tab_v;
+    CAVOID_STAMP(1);                                        // loads landed
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
@@ -447,7 +505,7 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
         if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {   // scripted agents in this tile
             if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
             if (pol == 2u) {                                            // straight at the goal, full speed
-                const Ego e0 = ego_frame(a);
+                const Ego e0 = ego_frame_exact(a);
                 a0 = (double)a.pref;
                 a1 = -e0.heading_ego;
             }
@@ -487,18 +545,20 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
         }
     }
 
+    CAVOID_STAMP(3);                                        // dynamics done
     // ---- stage post-move state in LDS; E6 pair pass (ego frame in the same block: independent chains) ---
     bool present = active && (a.flags & CAVOID_F_PRESENT);
     lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = a.vx; lds_vy[lane] = a.vy;
     lds_r[lane] = present ? a.radius : -1.0f;              // radius < 0 marks an absent row
     wave_lds_sync();
-    Ego e = ego_frame(a);
+    Ego e = ego_frame_obs(a);
     double dist[N];
     uint32_t others;
     bool hit;
     double min_gap;
     pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, dist, others, hit, min_gap);
 
+    CAVOID_STAMP(4);                                        // ego frame + pair pass done
     bool restart = false;
     if (stepping) {
         // ---- E7 rewards, E8 done ---------------------------------------------------------------------
@@ -536,7 +596,7 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
                 }
                 wave_lds_sync();
                 if (restart) {
-                    e = ego_frame(a);
+                    e = ego_frame_obs(a);
                     bool hit2;
                     double gap2;
                     pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, dist, others, hit2, gap2);
@@ -545,15 +605,18 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
         }
     }
 
+    CAVOID_STAMP(5);                                        // rewards / restart done
     // ---- E9 observation: once per step, after the restart decision -----------------------------------
     if (io.obs) {
         assemble_obs<N>(c, a, e, active, lane, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, dist, others, tile);
         wave_lds_sync();
+        CAVOID_STAMP(6);                                    // obs rows assembled in LDS
         int64_t worlds_here = c.num_worlds - w0;
         if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
         if (worlds_here > 0) flush_tile(tile, io.obs + w0 * N * width, (int)worlds_here * N * width, lane);
     }
 
+    CAVOID_STAMP(7);                                        // tile flushed
     // ---- state write-back ---------------------------------------------------------------------------
     if (stepping) {
         if (restart) {                                     // fresh episode: every field of every row
@@ -573,6 +636,7 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
             if (i == 0) s.episode[w] = episode;
         }
     }
+    CAVOID_STAMP(8);
 }
 
 }  // namespace cavoid

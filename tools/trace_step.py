@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Where does one env-step wavefront spend its time?  Runs the -DCAVOID_TRACE build
+(CAVOID_LIB=rl_collision_avoidance_amd/libcavoid_hip_trace.so) and prints, per phase, the
+shader-clock deltas (median / p90 / max over wavefronts) plus the launch span."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("CAVOID_LIB", os.path.join(ROOT, "rl_collision_avoidance_amd", "libcavoid_hip_trace.so"))
+
+import numpy as np
+import torch
+
+from rl_collision_avoidance_amd import _lib
+from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+from rl_collision_avoidance_amd.config import EnvConfig
+
+NAMES = ["start", "loads issued", "-", "dynamics", "ego+pairs", "reward/restart", "obs in LDS", "tile flushed", "stores issued"]
+
+
+def main():
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+    env = BatchedCollisionAvoidanceEnv(W, Cfg(), seed=7)
+    lib = _lib.lib()
+    lib.cavoid_debug_trace.argtypes = [C.c_void_p]
+    waves = (W + (64 // N) - 1) // (64 // N) + 8
+    trace = torch.zeros((waves, 16), dtype=torch.int64, device="cuda")
+    acts = torch.randint(0, 11, (32, W, N), device="cuda", dtype=torch.int32)
+    env.reset()
+    for _ in range(3):
+        env.step_autoreset_n(acts)
+    torch.cuda.synchronize()
+    assert lib.cavoid_debug_trace(C.c_void_p(trace.data_ptr())) == 0
+    for rep in range(3):
+        trace.zero_()
+        env.step_autoreset(acts[rep])
+        torch.cuda.synchronize()
+        t = trace.cpu().numpy()[: waves - 8].astype(np.int64)
+        used = [k for k in range(9) if k != 2]
+        t0 = t[:, 0].min()
+        print("rep %d: launch span (first wave start -> last wave end) = %d clk; per-wave total median %d max %d"
+              % (rep, t[:, 8].max() - t0, np.median(t[:, 8] - t[:, 0]), (t[:, 8] - t[:, 0]).max()))
+        print("   wave start spread: %d clk" % (t[:, 0].max() - t0))
+        for a, b in zip(used[:-1], used[1:]):
+            d = t[:, b] - t[:, a]
+            print("   %-16s -> %-16s median %6d  p90 %6d  max %6d" % (NAMES[a], NAMES[b], np.median(d), np.percentile(d, 90), d.max()))
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
