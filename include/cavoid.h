@@ -155,6 +155,29 @@ int cavoid_step_autoreset_n_timed(cavoid_env *env, const int32_t *actions, int64
                                   float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream,
                                   float *mean_kernel_ms);
 
+/* ---- batched GA3C actor bookkeeping (rollout) -------------------------------------------------------
+ * Stands in for one ProcessAgent per world: ProcessAgent.run_episode / _accumulate_rewards /
+ * convert_to_nparray (ga3c/GA3C/ProcessAgent.py:54-87,105-211) and the training_q / episode_log_q
+ * puts (:238,243).  cavoid_rollout_push records one env step for every learning (world, agent) slot
+ * and appends the flushed training rows (x, y_r, action) to a caller-owned device batch.
+ *   prev_obs  float [W,N,1+D]  the observation the policy acted on (Environment.previous_state plus col 0)
+ *   actions   int32 [W,N], values float [W,N] (V(s_t) of the predictor), rewards/done/game_over from the step
+ *   out_x float [capacity,D], out_r float [capacity], out_a int32 [capacity] (action index; the trainer's
+ *   one-hot is eye(num_actions)[out_a]), out_src int32 [capacity,4] (world, agent, recorded-at, emitted-at)
+ *   out_count int32 [2] (rows appended -- the caller zeroes it when it drains the batch --, rows dropped)
+ *   ep_out float [ep_capacity,3] (world, total_reward, total_length), ep_count int32 [2]
+ * reflush_done = 1 reproduces the reference: a done agent that is still reported learning re-flushes a
+ * 2-row chunk on every later step of the episode; 0 records nothing more. */
+typedef struct cavoid_rollout cavoid_rollout;
+int cavoid_rollout_create(int64_t num_worlds, int32_t max_agents, int32_t obs_width, int32_t time_max, double discount,
+                          int32_t reflush_done, int device, cavoid_rollout **out);
+void cavoid_rollout_destroy(cavoid_rollout *r);
+int cavoid_rollout_reset(cavoid_rollout *r, void *stream);
+int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t *actions, const float *values,
+                        const float *rewards, const uint8_t *done, const uint8_t *game_over, int32_t step,
+                        float *out_x, float *out_r, int32_t *out_a, int32_t *out_src, int32_t *out_count, int64_t capacity,
+                        float *ep_out, int32_t *ep_count, int64_t ep_capacity, void *stream);
+
 /* kernel timing helper: HIP events recorded on `stream` around the launches of the calls made
  * between begin and end; end synchronises and returns elapsed milliseconds */
 int cavoid_timer_begin(cavoid_env *env, void *stream);

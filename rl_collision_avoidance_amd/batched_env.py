@@ -201,14 +201,19 @@ class BatchedCollisionAvoidanceEnv(object):
                    "cavoid_step_continuous")
         return self.obs, self.rewards, self.done, self.game_over
 
-    def step_autoreset(self, actions: torch.Tensor):
+    def step_autoreset(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
         """``step`` + in-kernel restart of finished worlds: their obs rows hold the first observation
-        of the next episode; rewards / done / game_over still describe the finished step."""
+        of the next episode; rewards / done / game_over still describe the finished step.
+        ``obs_out``: write the observation there instead of into ``self.obs`` (lets a rollout keep
+        the previous observation alive without a copy)."""
         a = self._actions(actions)
-        _lib.check(self._lib.cavoid_step_autoreset(self._h, self._ptr(a), self._ptr(self.obs), self._ptr(self.rewards),
+        obs = self.obs if obs_out is None else self._want(obs_out, self.obs.shape, torch.float32, "obs_out")
+        if obs_out is not None and obs.data_ptr() != obs_out.data_ptr():
+            raise ValueError("obs_out must be a contiguous float32 tensor on the env's device")
+        _lib.check(self._lib.cavoid_step_autoreset(self._h, self._ptr(a), self._ptr(obs), self._ptr(self.rewards),
                                                    self._ptr(self.done), self._ptr(self.game_over), self._stream()),
                    "cavoid_step_autoreset")
-        return self.obs, self.rewards, self.done, self.game_over
+        return obs, self.rewards, self.done, self.game_over
 
     def step_autoreset_n(self, actions: torch.Tensor, n_steps: Optional[int] = None):
         """Open-loop run: actions int32 [T,W,N]; launches ``n_steps`` (default T) steps back to back

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
 SOURCES = [os.path.join(CSRC, "cavoid_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "cavoid_kernels.hpp"), os.path.join(ROOT, "include", "cavoid.h")]
+DEPS = SOURCES + [os.path.join(CSRC, "cavoid_kernels.hpp"), os.path.join(CSRC, "cavoid_rollout.hpp"),
+               os.path.join(ROOT, "include", "cavoid.h")]
 # -ffp-contract=off: the reference env is unfused NumPy float64; keep mul/add separate so that the
 # only numerical difference from the CPU oracle is the transcendental library.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

@@ -1,0 +1,147 @@
+"""``BatchedRollout`` -- every world's GA3C actor loop, on the device.
+
+Replaces W x ``ProcessAgent`` (/root/reference/ga3c/GA3C/ProcessAgent.py): the per-step
+predict -> sample -> env.step -> Experience bookkeeping of ``run_episode`` (:105-211), the n-step
+return of ``_accumulate_rewards`` (:54-79), ``convert_to_nparray`` (:82-87) and the two queue
+puts of ``run`` (:233-243).  Nothing crosses a process boundary: the policy is called once per
+step on the whole ``[W*N, D]`` observation matrix (what 128-row ``ThreadPredictor`` batches
+approximate, ThreadPredictor.py:40-75), the env steps in one kernel launch, and a second kernel
+(csrc/cavoid_rollout.hpp) keeps the experience rings and appends flushed training rows to a device
+batch that ``drain()`` hands to the trainer in the shapes ``Server.train_model(x_, r_, a_)``
+takes (Server.py:114-124; x [n, D], r [n], a one-hot float32 [n, num_actions])."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from .. import _lib
+from ..batched_env import BatchedCollisionAvoidanceEnv
+
+Policy = Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]   # x[B, D] -> (p[B, A], v[B])
+
+
+class TrainingBatch(object):
+    """Rows flushed since the last drain: ``x`` f32 [n, D], ``r`` f32 [n] (n-step returns),
+    ``a_index`` int32 [n], ``src`` int32 [n, 4] (world, agent, recorded-at step, emitted-at step)."""
+
+    def __init__(self, x, r, a_index, src, num_actions: int, dropped: int):
+        self.x, self.r, self.a_index, self.src = x, r, a_index, src
+        self.num_actions, self.dropped = num_actions, dropped
+
+    def __len__(self) -> int:
+        return int(self.r.shape[0])
+
+    @property
+    def a(self) -> torch.Tensor:
+        """one-hot float32 [n, num_actions] -- ``np.eye(num_actions)[idx].astype(np.float32)`` (ProcessAgent.py:84)."""
+        return torch.nn.functional.one_hot(self.a_index.long(), self.num_actions).to(torch.float32)
+
+
+class BatchedRollout(object):
+    def __init__(self, env: BatchedCollisionAvoidanceEnv, policy: Policy, time_max: Optional[int] = None,
+                 discount: float = 0.97, capacity: Optional[int] = None, episode_capacity: Optional[int] = None,
+                 reflush_done: bool = True, greedy: bool = False, generator: Optional[torch.Generator] = None):
+        self.env, self.policy = env, policy
+        cfg = env.config
+        self.time_max = int(time_max if time_max is not None else getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
+        self.discount = float(getattr(cfg, "DISCOUNT", discount))
+        self.greedy = greedy                     # PLAY_MODE / EVALUATE_MODE: argmax instead of sampling (:98-103)
+        self.generator = generator
+        W, N, D = env.num_worlds, env.max_agents, env.obs_width - 1
+        self.capacity = int(capacity if capacity is not None else 4 * W * N + 4096)
+        self.episode_capacity = int(episode_capacity if episode_capacity is not None else 4 * W + 1024)
+        dev = env.device
+        self.out_x = torch.empty((self.capacity, D), dtype=torch.float32, device=dev)
+        self.out_r = torch.empty((self.capacity,), dtype=torch.float32, device=dev)
+        self.out_a = torch.empty((self.capacity,), dtype=torch.int32, device=dev)
+        self.out_src = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
+        self.out_count = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self.ep_out = torch.empty((self.episode_capacity, 3), dtype=torch.float32, device=dev)
+        self.ep_count = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self._obs_buffers = [env.obs, torch.zeros_like(env.obs)]
+        self._cur = 0
+        self.step_index = 0
+        self.frames = 0                           # learning-agent steps emitted (the reference's PPS numerator)
+        self._lib = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._lib.cavoid_rollout_create(W, N, env.obs_width, self.time_max, self.discount,
+                                                   1 if reflush_done else 0, dev.index, C.byref(h)), "cavoid_rollout_create")
+        self._h = h
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            torch.cuda.synchronize(self.env.device)
+            self._lib.cavoid_rollout_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def obs(self) -> torch.Tensor:
+        """Observation the next ``step()`` will act on, [W, N, 1+D]."""
+        return self._obs_buffers[self._cur]
+
+    def reset(self) -> torch.Tensor:
+        """Start every world's first episode (``env.reset()`` at ProcessAgent.py:107)."""
+        self._cur = 0
+        self.env.reset()
+        _lib.check(self._lib.cavoid_rollout_reset(self._h, self.env._stream()), "cavoid_rollout_reset")
+        self.out_count.zero_()
+        self.ep_count.zero_()
+        self.step_index = 0
+        return self.obs
+
+    def act(self, obs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """predict + select_action for every agent row (ProcessAgent.py:89-103,128-144)."""
+        W, N = self.env.num_worlds, self.env.max_agents
+        p, v = self.policy(obs[..., 1:].reshape(W * N, -1))
+        if self.greedy:
+            actions = p.argmax(dim=-1)
+        else:
+            actions = torch.multinomial(p, 1, generator=self.generator).squeeze(-1)
+        return actions.to(torch.int32).reshape(W, N), v.reshape(W, N).to(torch.float32)
+
+    def step(self, actions: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None):
+        """One env step of every world + experience bookkeeping.  ``actions``/``values`` override the
+        policy (scripted runs).  Returns ``(rewards, done, game_over)`` of the step."""
+        env = self.env
+        obs = self.obs
+        if actions is None:
+            actions, values = self.act(obs)
+        actions = env._want(actions, (env.num_worlds, env.max_agents), torch.int32, "actions")
+        values = env._want(values, (env.num_worlds, env.max_agents), torch.float32, "values")
+        nxt = self._obs_buffers[1 - self._cur]
+        _, rew, done, game_over = env.step_autoreset(actions, obs_out=nxt)
+        p = BatchedCollisionAvoidanceEnv._ptr
+        _lib.check(self._lib.cavoid_rollout_push(
+            self._h, p(obs), p(actions), p(values), p(rew), p(done), p(game_over), self.step_index,
+            p(self.out_x), p(self.out_r), p(self.out_a), p(self.out_src), p(self.out_count), self.capacity,
+            p(self.ep_out), p(self.ep_count), self.episode_capacity, env._stream()), "cavoid_rollout_push")
+        self._cur = 1 - self._cur
+        self.step_index += 1
+        return rew, done, game_over
+
+    def drain(self) -> TrainingBatch:
+        """Hand the flushed rows to the trainer (``training_q.put((x_, r_, a_))``, :238) and empty the
+        device batch.  Synchronises (the row count comes back to the host)."""
+        n, dropped = [int(v) for v in self.out_count.tolist()]
+        n = min(n, self.capacity)
+        batch = TrainingBatch(self.out_x[:n].clone(), self.out_r[:n].clone(), self.out_a[:n].clone(),
+                              self.out_src[:n].clone(), self.env.num_actions, dropped)
+        self.out_count.zero_()
+        self.frames += n
+        return batch
+
+    def drain_episodes(self) -> torch.Tensor:
+        """Finished-episode records [k, 3] = (world, total_reward, total_length): the payload of
+        ``episode_log_q.put((now, total_reward, total_length))`` (:243)."""
+        n = min(int(self.ep_count[0].item()), self.episode_capacity)
+        out = self.ep_out[:n].clone()
+        self.ep_count.zero_()
+        return out

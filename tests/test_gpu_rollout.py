@@ -1,0 +1,129 @@
+"""GPU parity of the batched rollout (HIP, through the C ABI) against the rollout oracle, which is
+itself pinned bit-for-bit to the reference's ProcessAgent (tests/test_rollout_oracle.py).  The real
+GPU env drives it; the per-step inputs are recorded and replayed, world by world and episode by
+episode, through oracle/rollout_oracle.run_episode."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import rollout_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+R_TOL = 1e-6      # n-step returns: float64 on both sides, emitted as float32
+
+
+def _make(W, N, seed, **over):
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+    return BatchedCollisionAvoidanceEnv(W, Cfg(), seed=seed, **over)
+
+
+@pytest.mark.parametrize("N,gen_min,nonl,reflush", [(4, 2, 0.3, True), (4, 4, 0.0, False), (10, 2, 0.2, True)])
+def test_rollout_matches_oracle(N, gen_min, nonl, reflush):
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    W, steps, seed, T_MAX, GAMMA = 96, 260, 3, 20, 0.97
+    env = _make(W, N, seed, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
+    roll = BatchedRollout(env, policy=None, time_max=T_MAX, discount=GAMMA, reflush_done=reflush, capacity=1000000)
+    roll.reset()
+    rng = np.random.default_rng(seed)
+    rec = []
+    for t in range(steps):
+        obs = roll.obs.cpu().numpy().copy()
+        acts = rng.integers(0, 11, size=(W, N)).astype(np.int32)
+        acts[rng.random((W, N)) < 0.7] = 2
+        vals = np.round(rng.normal(0, 0.5, size=(W, N)), 3).astype(np.float32)
+        rew, done, over = roll.step(torch.from_numpy(acts).cuda(), torch.from_numpy(vals).cuda())
+        rec.append((obs, acts, vals, rew.cpu().numpy().copy(), done.cpu().numpy().astype(bool), over.cpu().numpy().astype(bool)))
+    batch = roll.drain()
+    episodes = roll.drain_episodes().cpu().numpy()
+    assert batch.dropped == 0 and len(batch) > W * 20
+    x, r, a, src = [v.cpu().numpy() for v in (batch.x, batch.r, batch.a_index, batch.src)]
+    got = {}
+    for k in range(len(r)):
+        got.setdefault(tuple(src[k]), []).append(k)          # (world, agent, recorded-at, emitted-at)
+
+    # replay per world, episode by episode
+    expect_rows, expect_eps = 0, []
+    for w in range(W):
+        start = 0
+        for t in range(steps):
+            if not rec[t][5][w]:
+                continue
+            ts = list(range(start, t + 1))
+            obs_seq = np.stack([rec[k][0][w] for k in ts] + [rec[t][0][w]])   # last entry unused by the oracle
+            learning = obs_seq[0][:, 0] > 0.5
+            n_present = int(np.flatnonzero(obs_seq[0][:, 4] > 0).max()) + 1
+            rewards = np.stack([rec[k][3][w] for k in ts]).astype(np.float64)
+            done = np.stack([rec[k][4][w] for k in ts])
+            actions = np.stack([rec[k][1][w] for k in ts])
+            values = np.stack([rec[k][2][w] for k in ts]).astype(np.float64)
+            chunks = ro.run_episode(obs_seq.astype(np.float64), rewards, done, learning, n_present, actions, values, GAMMA, T_MAX)
+            if not reflush:          # cleaned mode: drop what a done-and-trained agent would re-flush
+                trained_at, kept = {}, []
+                for c in chunks:
+                    if c.agent in trained_at and c.emitted_t > trained_at[c.agent]:
+                        continue                      # a re-flush of an already trained agent
+                    kept.append(c)
+                    if done[c.emitted_t, c.agent]:
+                        trained_at.setdefault(c.agent, c.emitted_t)
+                chunks = kept
+            total_reward, total_length = 0.0, 0
+            for c in chunks:
+                emitted = start + c.emitted_t
+                for row, tl in enumerate(c.t):
+                    key = (w, c.agent, start + tl, emitted)
+                    assert key in got and got[key], (key, "missing row")
+                    k = got[key].pop(0)
+                    assert np.array_equal(x[k], c.x[row].astype(np.float32)), key
+                    assert abs(r[k] - c.r[row]) <= R_TOL, (key, r[k], c.r[row])
+                    assert a[k] == int(np.argmax(c.a[row])), key
+                    expect_rows += 1
+                total_reward += c.score
+                total_length += len(c.r) + 1
+            if reflush:
+                expect_eps.append((w, total_reward, total_length))
+            start = t + 1
+    # everything the device emitted for finished episodes was expected (rows of unfinished episodes remain)
+    leftover = sum(len(v) for v in got.values())
+    assert expect_rows + leftover == len(r)
+    finished_until = {w: max([t for t in range(steps) if rec[t][5][w]], default=-1) for w in range(W)}
+    for key, ks in got.items():
+        if ks:
+            assert key[3] > finished_until[key[0]], ("unexpected row", key)
+    if reflush:
+        assert len(episodes) == len(expect_eps)
+        dev = sorted((int(e[0]), round(float(e[2]))) for e in episodes)
+        assert dev == sorted((w, tl) for w, _, tl in expect_eps)
+        np.testing.assert_allclose(sorted(float(e[1]) for e in episodes), sorted(tr for _, tr, _ in expect_eps), atol=1e-4)
+    roll.close()
+    env.close()
+
+
+def test_rollout_with_policy_and_one_hot():
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    W, N = 256, 4
+    env = _make(W, N, 1)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0)
+
+    def policy(x):                       # uniform policy, zero value
+        B = x.shape[0]
+        return torch.full((B, 11), 1.0 / 11, device=x.device), torch.zeros(B, device=x.device)
+    roll = BatchedRollout(env, policy, generator=gen)
+    roll.reset()
+    for _ in range(120):
+        roll.step()
+    b = roll.drain()
+    assert len(b) > 0 and b.x.shape == (len(b), 26) and b.a.shape == (len(b), 11) and b.a.dtype == torch.float32
+    assert torch.all(b.a.sum(dim=1) == 1) and torch.isfinite(b.r).all() and torch.isfinite(b.x).all()
+    eps = roll.drain_episodes()
+    assert eps.shape[1] == 3 and len(eps) > 0
+    assert len(roll.drain()) == 0
+    roll.close(); env.close()
