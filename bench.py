@@ -76,6 +76,44 @@ def python_baseline(N: int, budget_s: float):
             "sample": "oracle/cavoid_oracle.py, 1 world x %d agents, %d steps" % (N, steps)}
 
 
+def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int = 300, train_every: int = 5, max_rows: int = 4096):
+    """BASELINE configs[4]: everything on the device -- policy inference (PyTorch-ROCm NetworkVP_rnn), action
+    sampling, env.step, experience rings / n-step returns (HIP), and an Adam step on the drained rows every
+    `train_every` env steps (policy replica per GPU, no collective).  Reports the reference's PPS definition:
+    learning-agent steps per second (ProcessStats.py:54-56)."""
+    import torch
+    from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
+    net = NetworkVP_rnn(cfg).to(device)
+    trainer = A3CTrainer(net)
+    roll = BatchedRollout(env, net.predict_p_and_v, capacity=8 * W * N + 4096, reflush_done=False)
+    roll.reset()
+
+    def run(n):
+        learner_steps = 0
+        for k in range(n):
+            learner_steps += int(W * N)                      # all agents learn in this workload
+            roll.step()
+            if (k + 1) % train_every == 0:
+                b = roll.drain()
+                if len(b) > 0:
+                    trainer.train(b.x[:max_rows], b.r[:max_rows], b.a[:max_rows])
+        return learner_steps
+    run(30)
+    sync_all()
+    t0 = time.perf_counter()
+    frames = run(steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    out = {"learning_agent_steps_per_s_per_gpu": frames / dt, "env_steps": steps, "ms_per_env_step": dt * 1e3 / steps,
+           "training_steps": trainer.training_step, "train_rows_cap": max_rows,
+           "note": "policy+sampling+env+rollout+Adam on one GPU; reference PPS datum: 563 (32 procs, laptop CPU)"}
+    roll.close()
+    env.close()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +124,8 @@ def main() -> None:
     ap.add_argument("--slices", type=int, default=64, help="distinct pre-generated action slices")
     ap.add_argument("--gather", action="store_true", help="also time the per-step RCCL all-gather of (obs,reward,done)")
     ap.add_argument("--sweep", action="store_true", help="add a worlds-per-GPU saturation sweep to the JSON line")
+    ap.add_argument("--full-loop", action="store_true",
+                    help="also time BASELINE configs[4]: batched env + NetworkVP_rnn policy + rollout bookkeeping + Adam steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -184,6 +224,9 @@ def main() -> None:
         sync_all()
         extra["allgather_ms_per_step"] = (time.perf_counter() - tg) * 1e3 / 200
         extra["allgather_bytes_per_rank"] = packed.numel() * 4
+
+    if args.full_loop:
+        extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, Cfg(), device, W, N, rank, world_size, sync_all)
 
     if args.sweep and rank == 0:
         sweep = []

@@ -1,0 +1,150 @@
+"""``NetworkVP_rnn`` re-expressed in PyTorch-ROCm, so that the policy can sit
+on the same device as the batched env (BASELINE configs[4]).
+
+Graph (all citations /root/reference/ga3c/GA3C):
+  x [B, NN_INPUT_SIZE] -> (x - avg) / std                                   NetworkVP_rnn.py:50-53
+  num_other_agents = x[:, 0] (raw)                                          :58
+  host = x_norm[:, 1:5]; others = x_norm[:, 5:].reshape(B, M, 7)            :59-61
+  LSTMCell(64) over the M others with sequence_length = num_other_agents,
+      final hidden state h (state frozen past each row's length)            :64-66
+  concat[host(4), h(64)] -> dense256-relu 'layer1' -> dense256-relu 'layer2' :67,103-105
+  -> dense256-relu 'fullyconnected1' -> logits_v (1), logits_p (A)          NetworkVPCore.py:66-75
+  softmax_p = (softmax(logits_p) + MIN_POLICY) / (1 + MIN_POLICY * A)        :75
+Loss (A3C with GA3C's epsilon; NetworkVPCore.py:71-100), optimiser Adam(lr = LEARNING_RATE_RL_START).
+
+Parameters are stored in TensorFlow's layout (dense kernels [in, out]; the LSTM kernel [7+64, 4*64] with
+gate order i, j, f, o and forget_bias = 1 added at run time, as tf.contrib.rnn.LSTMCell does) and
+``TF_VARIABLE_NAMES`` maps them to the reference checkpoint's variable names (the Saver is keyed by
+``var.name``, NetworkVPCore.py:56-57), so a TF1 checkpoint converts by plain assignment.
+The dense layers are library GEMMs (rocBLAS/hipBLASLt through torch): tiny and dense, not a kernel target.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+TF_VARIABLE_NAMES = {
+    "lstm_kernel": "rnn/lstm_cell/kernel:0", "lstm_bias": "rnn/lstm_cell/bias:0",
+    "layer1_kernel": "layer1/kernel:0", "layer1_bias": "layer1/bias:0",
+    "layer2_kernel": "layer2/kernel:0", "layer2_bias": "layer2/bias:0",
+    "fc1_kernel": "fullyconnected1/kernel:0", "fc1_bias": "fullyconnected1/bias:0",
+    "v_kernel": "logits_v/kernel:0", "v_bias": "logits_v/bias:0",
+    "p_kernel": "logits_p/kernel:0", "p_bias": "logits_p/bias:0",
+}
+
+
+def _glorot(shape, gen) -> torch.Tensor:
+    limit = float(np.sqrt(6.0 / (shape[0] + shape[1])))
+    return (torch.rand(shape, generator=gen) * 2.0 - 1.0) * limit
+
+
+class NetworkVP_rnn(nn.Module):
+    HOST, OTHER, HIDDEN, WIDTH = 4, 7, 64, 256
+
+    def __init__(self, config, num_actions: Optional[int] = None, seed: int = 0):
+        super().__init__()
+        self.num_actions = int(num_actions if num_actions is not None else getattr(config, "NUM_ACTIONS", 11))
+        self.max_others = int(config.MAX_NUM_OTHER_AGENTS_OBSERVED)
+        self.input_size = 1 + self.HOST + self.OTHER * self.max_others
+        self.min_policy = float(getattr(config, "MIN_POLICY", 0.0))
+        self.log_epsilon = float(getattr(config, "LOG_EPSILON", 1e-6))
+        self.beta = float(getattr(config, "BETA_START", 1e-4))
+        self.normalize = bool(getattr(config, "NORMALIZE_INPUT", True))
+        avg = getattr(config, "NN_INPUT_AVG_VECTOR", None)
+        std = getattr(config, "NN_INPUT_STD_VECTOR", None)
+        if avg is None or len(avg) != self.input_size:      # plain EnvConfig: derive them like Config.py:64-71
+            avg, std = input_normalisation(config)
+        self.register_buffer("avg", torch.as_tensor(np.asarray(avg), dtype=torch.float32))
+        self.register_buffer("std", torch.as_tensor(np.asarray(std), dtype=torch.float32))
+        g = torch.Generator().manual_seed(seed)
+        H, Wd = self.HIDDEN, self.WIDTH
+        self.lstm_kernel = nn.Parameter(_glorot((self.OTHER + H, 4 * H), g))
+        self.lstm_bias = nn.Parameter(torch.zeros(4 * H))
+        self.layer1_kernel = nn.Parameter(_glorot((self.HOST + H, Wd), g)); self.layer1_bias = nn.Parameter(torch.zeros(Wd))
+        self.layer2_kernel = nn.Parameter(_glorot((Wd, Wd), g)); self.layer2_bias = nn.Parameter(torch.zeros(Wd))
+        self.fc1_kernel = nn.Parameter(_glorot((Wd, Wd), g)); self.fc1_bias = nn.Parameter(torch.zeros(Wd))
+        self.v_kernel = nn.Parameter(_glorot((Wd, 1), g)); self.v_bias = nn.Parameter(torch.zeros(1))
+        self.p_kernel = nn.Parameter(_glorot((Wd, self.num_actions), g)); self.p_bias = nn.Parameter(torch.zeros(self.num_actions))
+
+    # ---------------------------------------------------------------------------------------------
+    def _lstm_final_h(self, seq: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """tf.nn.dynamic_rnn(LSTMCell(64), seq, sequence_length=lengths)[1].h : rows stop updating once
+        their own length is reached (zero state for length 0)."""
+        B = seq.shape[0]
+        h = seq.new_zeros((B, self.HIDDEN))
+        c = seq.new_zeros((B, self.HIDDEN))
+        for t in range(self.max_others):
+            gates = torch.addmm(self.lstm_bias, torch.cat([seq[:, t, :], h], dim=1), self.lstm_kernel)
+            i, j, f, o = gates.chunk(4, dim=1)
+            c_new = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+            h_new = torch.sigmoid(o) * torch.tanh(c_new)
+            live = (lengths > t).unsqueeze(1)
+            c = torch.where(live, c_new, c)
+            h = torch.where(live, h_new, h)
+        return h
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """x [B, NN_INPUT_SIZE] -> (logits_p [B, A], softmax_p [B, A], v [B])"""
+        x = x.to(torch.float32)
+        xn = (x - self.avg) / self.std if self.normalize else x
+        lengths = x[:, 0]
+        host = xn[:, 1:1 + self.HOST]
+        others = xn[:, 1 + self.HOST:].reshape(-1, self.max_others, self.OTHER)
+        h = self._lstm_final_h(others, lengths)
+        z = torch.relu(torch.addmm(self.layer1_bias, torch.cat([host, h], dim=1), self.layer1_kernel))
+        z = torch.relu(torch.addmm(self.layer2_bias, z, self.layer2_kernel))
+        z = torch.relu(torch.addmm(self.fc1_bias, z, self.fc1_kernel))
+        v = torch.addmm(self.v_bias, z, self.v_kernel).squeeze(1)
+        logits = torch.addmm(self.p_bias, z, self.p_kernel)
+        p = (torch.softmax(logits, dim=1) + self.min_policy) / (1.0 + self.min_policy * self.num_actions)
+        return logits, p, v
+
+    @torch.no_grad()
+    def predict_p_and_v(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """NetworkVPCore.predict_p_and_v (:175-176)."""
+        _, p, v = self.forward(x)
+        return p, v
+
+    def loss(self, x: torch.Tensor, y_r: torch.Tensor, a_onehot: torch.Tensor):
+        """cost_all = cost_p + cost_v of NetworkVPCore.py:71-100 (sums over the batch, not means)."""
+        _, p, v = self.forward(x)
+        y_r = y_r.to(torch.float32)
+        cost_v = 0.5 * torch.sum((y_r - v) ** 2)
+        selected = torch.sum(p * a_onehot, dim=1)
+        advant = torch.log(torch.clamp_min(selected, self.log_epsilon)) * (y_r - v.detach())
+        entropy = -self.beta * torch.sum(torch.log(torch.clamp_min(p, self.log_epsilon)) * p, dim=1)
+        cost_p = -(advant.sum() + entropy.sum())
+        return cost_p + cost_v, cost_p, cost_v
+
+
+def input_normalisation(config):
+    """NN_INPUT_AVG_VECTOR / NN_INPUT_STD_VECTOR exactly as Config.py:64-71 builds them."""
+    avg, std = [], []
+    for state in config.STATES_IN_OBS:
+        if state in config.STATES_NOT_USED_IN_POLICY:
+            continue
+        avg.append(np.asarray(config.STATE_INFO_DICT[state]["mean"]).flatten())
+        std.append(np.asarray(config.STATE_INFO_DICT[state]["std"]).flatten())
+    return np.hstack(avg), np.hstack(std)
+
+
+class A3CTrainer(object):
+    """``Server.train_model`` (Server.py:114-124) without the queue: one Adam step per batch."""
+
+    def __init__(self, model: NetworkVP_rnn, learning_rate: float = 2e-5):
+        self.model = model
+        self.opt = torch.optim.Adam(model.parameters(), lr=learning_rate, eps=1e-8)     # tf.train.AdamOptimizer defaults
+        self.training_step = 0
+        self.frame_counter = 0
+
+    def train(self, x: torch.Tensor, y_r: torch.Tensor, a_onehot: torch.Tensor) -> float:
+        self.opt.zero_grad(set_to_none=True)
+        total, _, _ = self.model.loss(x, y_r, a_onehot)
+        total.backward()
+        self.opt.step()
+        self.training_step += 1
+        self.frame_counter += int(x.shape[0])
+        return float(total.detach())

@@ -1,0 +1,77 @@
+"""PyTorch re-expression of NetworkVP_rnn (row N1): shapes, the dynamic_rnn sequence_length semantics
+against a plain per-row fp32 reference, the A3C loss against a NumPy statement of NetworkVPCore's
+formulas, and one optimiser step."""
+import numpy as np
+import torch
+
+from rl_collision_avoidance_amd.config import EnvConfig
+from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn, TF_VARIABLE_NAMES, input_normalisation
+
+
+def _cfg(N):
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+    return Cfg()
+
+
+def _batch(B, M, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 5 + 7 * M, generator=g)
+    x[:, 0] = torch.randint(0, M + 1, (B,), generator=g).float()
+    return x
+
+
+def test_shapes_and_normalisation_vectors():
+    cfg = _cfg(4)
+    avg, std = input_normalisation(cfg)
+    assert len(avg) == 26 and len(std) == 26 and avg[0] == 1.0 and std[1] == 5.0
+    net = NetworkVP_rnn(cfg)
+    assert set(TF_VARIABLE_NAMES) == {n for n, _ in net.named_parameters()}
+    logits, p, v = net(_batch(33, 3))
+    assert logits.shape == (33, 11) and p.shape == (33, 11) and v.shape == (33,)
+    assert torch.allclose(p.sum(1), torch.ones(33), atol=1e-6)
+    assert net.lstm_kernel.shape == (71, 256) and net.layer1_kernel.shape == (68, 256)
+    assert NetworkVP_rnn(_cfg(10)).input_size == 68
+
+
+def test_sequence_length_semantics_match_per_row_reference():
+    cfg = _cfg(10)
+    net = NetworkVP_rnn(cfg, seed=3)
+    x = _batch(40, 9, seed=1)
+    xn = (x - net.avg) / net.std
+    seq = xn[:, 5:].reshape(-1, 9, 7)
+    got = net._lstm_final_h(seq, x[:, 0])
+    W, b = net.lstm_kernel.detach(), net.lstm_bias.detach()
+    for row in range(40):                                  # plain fp32 reference: run exactly `len` steps
+        h = torch.zeros(64); c = torch.zeros(64)
+        for t in range(int(x[row, 0])):
+            gates = torch.cat([seq[row, t], h]) @ W + b
+            i, j, f, o = gates.chunk(4)
+            c = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+            h = torch.sigmoid(o) * torch.tanh(c)
+        assert torch.allclose(got[row], h, atol=1e-6), row
+    assert torch.all(got[x[:, 0] == 0] == 0)
+
+
+def test_loss_matches_numpy_statement_and_trains():
+    cfg = _cfg(4)
+    net = NetworkVP_rnn(cfg, seed=1)
+    x = _batch(64, 3, seed=2)
+    y = torch.randn(64)
+    a = torch.nn.functional.one_hot(torch.randint(0, 11, (64,)), 11).float()
+    total, cost_p, cost_v = net.loss(x, y, a)
+    with torch.no_grad():
+        _, p, v = net(x)
+    p, v, yn, an = p.numpy().astype(np.float64), v.numpy().astype(np.float64), y.numpy().astype(np.float64), a.numpy()
+    sel = (p * an).sum(1)
+    adv = np.log(np.maximum(sel, 1e-6)) * (yn - v)
+    ent = -1e-4 * (np.log(np.maximum(p, 1e-6)) * p).sum(1)
+    want = -(adv.sum() + ent.sum()) + 0.5 * ((yn - v) ** 2).sum()
+    assert abs(float(total) - want) < 1e-3 * max(1.0, abs(want))
+    tr = A3CTrainer(net, learning_rate=1e-3)
+    first = tr.train(x, y, a)
+    for _ in range(30):
+        last = tr.train(x, y, a)
+    assert last < first and tr.training_step == 31
