@@ -205,6 +205,20 @@ def main() -> None:
                 "kernel_us": kern_ms * 1e3, "stream_us_per_step": stream_ms * 1e3 / args.steps,
                 "algorithmic_bytes_per_launch": bytes_per_launch}
 
+    # `traffic`: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) -- those
+    # cannot be collected from inside this process, so the committed summary of the PMC run of THIS command
+    # is quoted when it is for the same kernel and shape (profiles/*_pmc_traffic.json), else null.
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+            pmc = json.load(open(path))
+            if pmc.get("worlds") == W and pmc.get("agents") == N:
+                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = os.path.relpath(path, ROOT)
+                break
+    except Exception:
+        pass
+
     extra = {}
     if args.gather and world_size > 1:
         width = env.obs_width
