@@ -101,7 +101,7 @@ typedef struct cavoid_cfg {
     double gen_nonlearning_fraction, gen_static_fraction, gen_goal_jitter, gen_angle_jitter;
     /* scenario pool: > 0 pre-generates that many GEN v1 scenarios at cavoid_seed() time (pool entry k
      * = generator world k, episode 0); the episode `ep` of global world `gw` then uses entry
-     * philox(gw, ep, 3, 0).x % pool_size -- a gather instead of the generator on the step's critical
+     * hash(seed, gw, ep) -> [0, pool_size) -- a gather instead of the generator on the step's critical
      * path (cf. the reference env's fixed test-case sets, NUM_TEST_CASES run-ws/config.yaml:136-138).
      * 0 = every episode runs the generator in-kernel with counter (gw, ep).  Default 65536. */
     int32_t gen_pool_size;

@@ -291,11 +291,13 @@ static void generate_world(const oracle_cfg *c, const oracle_gen *g, uint64_t se
     const int N = c->max_agents;
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, ctr[4] = {gw, ep, 0, 0}, r[4], a[4], b[4];
     if (g->pool_size > 0) {            /* scenario pool: pick the pool entry, which is generator world k, episode 0 */
-        ctr[2] = 3;
-        oracle_philox4x32(ctr, key, r);
-        ctr[0] = gw = r[0] % (uint32_t)g->pool_size;
+        /* splitmix64-style finaliser of (seed, gw, ep), reduced to [0, P) by multiply-shift */
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gw + 1ull) + 0xC2B2AE3D27D4EB4Full * ((uint64_t)ep + 1ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        ctr[0] = gw = (uint32_t)(((z >> 32) * (uint64_t)(uint32_t)g->pool_size) >> 32);
         ctr[1] = ep = 0;
-        ctr[2] = 0;
     }
     oracle_philox4x32(ctr, key, r);
     int span = g->max_agents - g->min_agents + 1;

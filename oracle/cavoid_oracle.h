@@ -30,7 +30,7 @@ typedef struct oracle_cfg {
 typedef struct oracle_gen {
     int32_t min_agents, max_agents;
     double nonlearning_fraction, static_fraction, goal_jitter, angle_jitter;
-    int32_t pool_size;   /* > 0: episode ep of world gw is generator world philox(gw,ep,3,0).x % pool_size, episode 0 */
+    int32_t pool_size;   /* > 0: episode ep of world gw is generator world pool_index(seed,gw,ep) (splitmix64 finaliser, multiply-shift), episode 0 */
     int32_t _pad;
 } oracle_gen;
 

@@ -415,7 +415,17 @@ class GenConfig:
     static_fraction: float = 0.5          # of those, P(static) (else non-cooperative)
     goal_jitter: float = 0.5              # half-width (m) of the uniform jitter on the antipodal goal
     angle_jitter: float = 0.25            # fraction of the angular slot
-    pool_size: int = 0                    # > 0: scenario pool (episode ep of world gw = pool entry philox(gw,ep,3,0)[0] % P)
+    pool_size: int = 0                    # > 0: scenario pool (episode ep of world gw = pool entry pool_index(seed, gw, ep, P))
+
+
+def pool_index(seed: int, world_id: int, episode: int, pool_size: int) -> int:
+    """splitmix64-style finaliser of (seed, global world id, episode), reduced to [0, P) by multiply-shift."""
+    m64 = 0xFFFFFFFFFFFFFFFF
+    z = (seed + 0x9E3779B97F4A7C15 * ((world_id & _MASK32) + 1) + 0xC2B2AE3D27D4EB4F * ((episode & _MASK32) + 1)) & m64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
+    z ^= z >> 31
+    return ((z >> 32) * pool_size) >> 32
 
 
 def generate_world(seed: int, world_id: int, episode: int, cfg: OracleConfig, gen: GenConfig) -> World:
@@ -424,7 +434,7 @@ def generate_world(seed: int, world_id: int, episode: int, cfg: OracleConfig, ge
     positions stay float64; heading points at the goal; time budget as in ``Agent``."""
     k0, k1 = seed & _MASK32, (seed >> 32) & _MASK32
     if gen.pool_size > 0:      # pool entry k is generator world k, episode 0
-        world_id = philox4x32(world_id & _MASK32, episode & _MASK32, 3, 0, k0, k1)[0] % gen.pool_size
+        world_id = pool_index(seed, world_id, episode, gen.pool_size)
         episode = 0
     w = philox4x32(world_id & _MASK32, episode & _MASK32, 0, 0, k0, k1)
     span = gen.max_agents - gen.min_agents + 1

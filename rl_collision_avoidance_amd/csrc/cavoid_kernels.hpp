@@ -53,6 +53,7 @@ struct KCfg {
     int32_t max_other, width, sort_method, dynamics, actions_fp32, timeout_enabled, num_actions;
     int32_t gen_min_agents, gen_max_agents;
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
+    int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
     const double *action_table;  // [num_actions][2]
@@ -242,103 +243,124 @@ __device__ __forceinline__ double time_to_impact(double rx, double ry, double vx
     return (bb - sqrt(disc)) / aa;
 }
 
-// E6: centre distances to every agent of the lane's world (from the LDS-staged positions), the
+// Others of host i, in ring order: o = 0..N-2  ->  agent j = (i + 1 + o) mod N.  Iterating the N-1
+// OTHERS (instead of all N agents with the host masked out) saves a sqrt and, with the symmetric
+// rank update below, three quarters of the key comparisons.
+template <int N>
+struct Others {
+    static constexpr int K = N > 1 ? N - 1 : 1;     // array extent (N == 1: one dummy, never valid)
+};
+
+__device__ __forceinline__ int other_index(int i, int o, int n) {
+    const int j = i + 1 + o;
+    return j >= n ? j - n : j;
+}
+
+// E6: centre distances to the other agents of the lane's world (from the LDS-staged positions), the
 // collision test and the nearest gap.  All 64 lanes call this together.
 template <int N>
 __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, bool present, int i, int base,
                                           const double *lds_px, const double *lds_py, const float *lds_r,
-                                          double (&dist)[N], uint32_t &others, bool &hit, double &min_gap) {
+                                          double (&dist)[Others<N>::K], uint32_t &others, bool &hit, double &min_gap) {
     const double ri = (double)a.radius;
     others = 0u;
     hit = false;
     min_gap = INFINITY;
+    dist[0] = 0.0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const float rjf = lds_r[base + j];
-        const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
+    for (int o = 0; o < N - 1; ++o) {
+        const int j = base + other_index(i, o, N);
+        const float rjf = lds_r[j];
+        const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
         const double d = sqrt(rx * rx + ry * ry);
-        dist[j] = d;
-        const bool other = present && (j != i) && (rjf >= 0.0f);
+        dist[o] = d;
+        const bool other = present && (rjf >= 0.0f);
         // unordered-pair gap d - (r_lo + r_hi): the sum is commutative, both ends agree bitwise
         const double gap_c = d - (ri + (double)rjf);
         min_gap = other ? fmin(min_gap, gap_c) : min_gap;
         hit = hit || (other && gap_c <= c.collision_dist);
-        others |= other ? (1u << j) : 0u;
+        others |= other ? (1u << o) : 0u;
     }
 }
 
 // E9: neighbour ordering by counting ranks + the lane's observation row into the LDS tile.
 template <int N>
-__device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int base,
+__device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
-                                             const double *lds_vy, const float *lds_r, const double (&dist)[N],
+                                             const double *lds_vy, const float *lds_r, const double (&dist)[Others<N>::K],
                                              uint32_t others, float *tile) {
+    constexpr int K = Others<N>::K, NO = N - 1;
     const int M = c.max_other, width = c.width;
     const bool present = active && (a.flags & CAVOID_F_PRESENT);
     const double ri = (double)a.radius;
     // sort criteria: gap rounded to centimetres (rint(gap*100) is order-isomorphic to round(gap,2)),
-    // then the lateral offset; its sign-preserving un-normalised form ry*tx - rx*ty orders the same
-    double gr[N], lat[N];
+    // then the lateral offset; its sign-preserving un-normalised form ry*tx - rx*ty orders the same;
+    // full ties fall back to the agent index (what a stable sort does)
+    double gr[K], lat[K];
+    int jj[K];
     uint32_t valid = 0u;
+    gr[0] = lat[0] = 0.0; jj[0] = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const double rj = (double)lds_r[base + j];
-        const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
-        gr[j] = rint((dist[j] - ri - rj) * 100.0);
-        lat[j] = ry * e.tx - rx * e.ty;
-        valid |= (((others >> j) & 1u) && !(dist[j] > c.horizon)) ? (1u << j) : 0u;
+    for (int o = 0; o < NO; ++o) {
+        jj[o] = other_index(i, o, N);
+        const int j = base + jj[o];
+        const double rj = (double)lds_r[j];
+        const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
+        gr[o] = rint((dist[o] - ri - rj) * 100.0);
+        lat[o] = ry * e.tx - rx * e.ty;
+        valid |= (((others >> o) & 1u) && !(dist[o] > c.horizon)) ? (1u << o) : 0u;
     }
     const int m = __popc(valid);
     const int first = m > M ? m - M : 0;
     const int kept = m - first;
-    int slot[N];
-    uint32_t keep = 0u;
+    int pos[K];
+#pragma unroll
+    for (int o = 0; o < K; ++o) pos[o] = 0;
     if (c.sort_method == CAVOID_SORT_TIME_TO_IMPACT) {
-        double tti[N];
+        double tti[K];
+        tti[0] = 0.0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
-            tti[j] = time_to_impact(rx, ry, a.vx - lds_vx[base + j], a.vy - lds_vy[base + j], ri + (double)lds_r[base + j]);
+        for (int o = 0; o < NO; ++o) {
+            const int j = base + jj[o];
+            tti[o] = time_to_impact(lds_px[j] - a.px, lds_py[j] - a.py, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + (double)lds_r[j]);
         }
 #pragma unroll
-        for (int j = 0; j < N; ++j) {       // far -> near: larger time first, then larger gap, then smaller lateral
-            int pos = 0;
+        for (int p = 0; p < NO; ++p)           // far -> near: larger time first, then larger gap, then smaller lateral
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                if (k == j) continue;
-                const bool before = (tti[k] > tti[j]) ||
-                                    (tti[k] == tti[j] && (gr[k] > gr[j] || (gr[k] == gr[j] && (lat[k] < lat[j] || (lat[k] == lat[j] && k < j)))));
-                pos += (before && ((valid >> k) & 1u)) ? 1 : 0;
+            for (int q = p + 1; q < NO; ++q) {
+                const bool p_first = (tti[p] > tti[q]) ||
+                                     (tti[p] == tti[q] && (gr[p] > gr[q] || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && jj[p] < jj[q])))));
+                pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
+                pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
             }
-            slot[j] = pos - first;
-            keep |= (((valid >> j) & 1u) && pos >= first) ? (1u << j) : 0u;
-        }
     } else {
 #pragma unroll
-        for (int j = 0; j < N; ++j) {       // far -> near: larger gap first, then smaller lateral, then index
-            int pos = 0;
+        for (int p = 0; p < NO; ++p)           // far -> near: larger gap first, then smaller lateral, then index
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                if (k == j) continue;
-                const bool before = (gr[k] > gr[j]) || (gr[k] == gr[j] && (lat[k] < lat[j] || (lat[k] == lat[j] && k < j)));
-                pos += (before && ((valid >> k) & 1u)) ? 1 : 0;
+            for (int q = p + 1; q < NO; ++q) {
+                const bool p_first = (gr[p] > gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && jj[p] < jj[q])));
+                pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
+                pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
             }
-            slot[j] = pos - first;
-            keep |= (((valid >> j) & 1u) && pos >= first) ? (1u << j) : 0u;
-        }
-        if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {
+    }
+    uint32_t keep = 0u;
+    int slot[K];
 #pragma unroll
-            for (int j = 0; j < N; ++j) {   // kept set re-ranked near -> far; full ties keep index order
-                int pos = 0;
+    for (int o = 0; o < K; ++o) {
+        slot[o] = pos[o] - first;
+        keep |= (((valid >> o) & 1u) && pos[o] >= first) ? (1u << o) : 0u;
+    }
+    if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {      // kept set re-ranked near -> far; full ties keep index order
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    if (k == j) continue;
-                    const bool before = (gr[k] < gr[j]) || (gr[k] == gr[j] && (lat[k] < lat[j] || (lat[k] == lat[j] && k < j)));
-                    pos += (before && ((keep >> k) & 1u)) ? 1 : 0;
-                }
-                slot[j] = pos;
+        for (int o = 0; o < K; ++o) slot[o] = 0;
+#pragma unroll
+        for (int p = 0; p < NO; ++p)
+#pragma unroll
+            for (int q = p + 1; q < NO; ++q) {
+                const bool p_first = (gr[p] < gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && jj[p] < jj[q])));
+                slot[q] += (p_first && ((keep >> p) & 1u)) ? 1 : 0;
+                slot[p] += (!p_first && ((keep >> q) & 1u)) ? 1 : 0;
             }
-        }
     }
 
     if (active) {
@@ -350,19 +372,20 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         row[4] = present ? a.pref : 0.0f;
         row[5] = present ? a.radius : 0.0f;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (!((keep >> j) & 1u)) continue;
-            const double rj = (double)lds_r[base + j];
-            const double rx = lds_px[base + j] - a.px, ry = lds_py[base + j] - a.py;
-            const double ovx = lds_vx[base + j], ovy = lds_vy[base + j];
-            float *f = row + 6 + 7 * slot[j];
+        for (int o = 0; o < NO; ++o) {
+            if (!((keep >> o) & 1u)) continue;
+            const int j = base + jj[o];
+            const double rj = (double)lds_r[j];
+            const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
+            const double ovx = lds_vx[j], ovy = lds_vy[j];
+            float *f = row + 6 + 7 * slot[o];
             f[0] = (float)(rx * e.prll_x + ry * e.prll_y);
             f[1] = (float)(ry * e.prll_x - rx * e.prll_y);
             f[2] = (float)(ovx * e.prll_x + ovy * e.prll_y);
             f[3] = (float)(ovy * e.prll_x - ovx * e.prll_y);
             f[4] = (float)rj;
             f[5] = (float)(ri + rj);
-            f[6] = (float)(dist[j] - ri - rj);
+            f[6] = (float)(dist[o] - ri - rj);
         }
         for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;   // unfilled slots
     }
@@ -404,13 +427,24 @@ __device__ __forceinline__ void store_agent(const KState &s, int64_t k, const Ag
     s.speed[k] = a.speed; s.flags[k] = a.flags;
 }
 
+// Pool entry used by episode `ep` of global world `gw`: a splitmix64-style finaliser of (seed, gw, ep)
+// reduced to [0, P) by multiply-shift (no division).  Cheap on purpose: it sits on the critical path
+// of every wavefront in which a world restarts.  (GEN v1 itself keeps Philox4x32-10.)
+__device__ __forceinline__ uint32_t pool_index(const KCfg &c, uint32_t gw, uint32_t ep) {
+    uint64_t z = ((uint64_t)c.seed_hi << 32 | c.seed_lo) + 0x9E3779B97F4A7C15ull * ((uint64_t)gw + 1ull) +
+                 0xC2B2AE3D27D4EB4Full * ((uint64_t)ep + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(((z >> 32) * (uint64_t)(uint32_t)c.pool_size) >> 32);
+}
+
 // Scenario of (global world gw, episode ep): a gather from the pre-generated pool (pool entry k is
 // GEN v1's world k, episode 0) or, with no pool, the generator itself.
 template <int N>
 __device__ __forceinline__ void new_episode(const KCfg &c, const KState &pool, uint32_t gw, uint32_t ep, int i, Agent &a) {
     if (c.pool_size > 0) {
-        const U4 r = philox4x32(gw, ep, 3u, 0u, c.seed_lo, c.seed_hi);
-        const int64_t k = (int64_t)(r.x % (uint32_t)c.pool_size) * N + i;
+        const int64_t k = (int64_t)pool_index(c, gw, ep) * N + i;
         load_agent(pool, k, a);
         a.vx = a.vy = 0.0;
         a.speed = 0.0f;
@@ -477,6 +511,37 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     }
     if (use_table) lds_tab[lane] = tab_v;
     CAVOID_STAMP(1);                                        // loads landed
+#ifdef CAVOID_ABLATE
+    // development aid: the memory skeleton of the step (same loads, same stores, no arithmetic) --
+    // the launch + memory floor the real kernel is measured against
+    if (stepping) {
+        if (use_table) lds_tab[lane] = tab_v;
+        if (active) {
+            float *row = tile + lane * width;
+            for (int k = 0; k < width; ++k) row[k] = (float)a.px + (float)k + (float)act;
+        }
+        wave_lds_sync();
+        int64_t worlds_here = c.num_worlds - w0;
+        if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
+        if (io.obs && worlds_here > 0) flush_tile(tile, io.obs + w0 * N * width, (int)worlds_here * N * width, lane);
+        if (active) {
+            io.rew[a_idx] = (float)a.py; io.done[a_idx] = 0;
+            if (i == 0) io.game_over[w] = 0;
+            s.px[a_idx] = a.px + 1.0; s.py[a_idx] = a.py + 1.0; s.heading[a_idx] = a.heading; s.t_rem[a_idx] = a.t_rem - 0.2;
+            s.speed[a_idx] = a.pref; s.flags[a_idx] = a.flags;
+        }
+        return;
+    }
+#endif
+    // small batches are latency bound: fetch the NEXT episode's pool entry up front, together with the
+    // state loads, so a restarting world does not pay a second dependent trip to memory
+    Agent nxt = a;
+    const bool prefetched = MODE == MODE_STEP_AUTORESET && c.prefetch_pool != 0 && c.pool_size > 0;
+    if (prefetched && active) {
+        load_agent(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
+        nxt.vx = nxt.vy = 0.0;
+        nxt.speed = 0.0f;
+    }
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
@@ -552,7 +617,7 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     lds_r[lane] = present ? a.radius : -1.0f;              // radius < 0 marks an absent row
     wave_lds_sync();
     Ego e = ego_frame_obs(a);
-    double dist[N];
+    double dist[Others<N>::K];
     uint32_t others;
     bool hit;
     double min_gap;
@@ -589,7 +654,8 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
                 wave_lds_sync();                           // every lane is done reading the old positions
                 if (restart) {
                     episode += 1u;
-                    new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
+                    if (prefetched) a = nxt;
+                    else new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
                     present = (a.flags & CAVOID_F_PRESENT) != 0u;
                     lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = 0.0; lds_vy[lane] = 0.0;
                     lds_r[lane] = present ? a.radius : -1.0f;
@@ -608,7 +674,7 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     CAVOID_STAMP(5);                                        // rewards / restart done
     // ---- E9 observation: once per step, after the restart decision -----------------------------------
     if (io.obs) {
-        assemble_obs<N>(c, a, e, active, lane, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, dist, others, tile);
+        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, dist, others, tile);
         wave_lds_sync();
         CAVOID_STAMP(6);                                    // obs rows assembled in LDS
         int64_t worlds_here = c.num_worlds - w0;
