@@ -87,28 +87,30 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
     net = NetworkVP_rnn(cfg).to(device)
     trainer = A3CTrainer(net)
-    roll = BatchedRollout(env, net.predict_p_and_v, capacity=8 * W * N + 4096, reflush_done=False)
+    train_every = 4                                          # env steps per hipGraph replay (even)
+    roll = BatchedRollout(env, net.predict_p_and_v, capacity=2 * train_every * W * N + 4096, reflush_done=False)
     roll.reset()
+    roll.capture(steps_per_graph=train_every)                # policy + sampling + env.step + bookkeeping as ONE graph
 
-    def run(n):
-        learner_steps = 0
-        for k in range(n):
-            learner_steps += int(W * N)                      # all agents learn in this workload
-            roll.step()
-            if (k + 1) % train_every == 0:
-                b = roll.drain()
-                if len(b) > 0:
-                    trainer.train(b.x[:max_rows], b.r[:max_rows], b.a[:max_rows])
-        return learner_steps
-    run(30)
+    def run(n_replays):
+        for _ in range(n_replays):
+            roll.replay(1)
+            b = roll.drain()
+            if len(b) > 0:
+                trainer.train(b.x[:max_rows], b.r[:max_rows], b.a[:max_rows])
+        return n_replays * train_every * W * N               # all agents learn in this workload
+    run(8)
     sync_all()
     t0 = time.perf_counter()
-    frames = run(steps)
+    frames = run(steps // train_every)
     sync_all()
     dt = time.perf_counter() - t0
+    steps = (steps // train_every) * train_every
     out = {"learning_agent_steps_per_s_per_gpu": frames / dt, "env_steps": steps, "ms_per_env_step": dt * 1e3 / steps,
-           "training_steps": trainer.training_step, "train_rows_cap": max_rows,
-           "note": "policy+sampling+env+rollout+Adam on one GPU; reference PPS datum: 563 (32 procs, laptop CPU)"}
+           "training_steps": trainer.training_step, "train_rows_cap": max_rows, "steps_per_graph": train_every,
+           "policy_dtype": "f32",
+           "note": "policy+sampling+env+rollout (one hipGraph per %d steps) + Adam on one GPU; reference PPS datum: 563 "
+                   "(32 procs, laptop CPU)" % train_every}
     roll.close()
     env.close()
     return out

@@ -164,7 +164,8 @@ int cavoid_step_autoreset_n_timed(cavoid_env *env, const int32_t *actions, int64
  *   actions   int32 [W,N], values float [W,N] (V(s_t) of the predictor), rewards/done/game_over from the step
  *   out_x float [capacity,D], out_r float [capacity], out_a int32 [capacity] (action index; the trainer's
  *   one-hot is eye(num_actions)[out_a]), out_src int32 [capacity,4] (world, agent, recorded-at, emitted-at)
- *   out_count int32 [2] (rows appended -- the caller zeroes it when it drains the batch --, rows dropped)
+ *   out_count int32 [4] (rows reserved, rows dropped, index of the first dropped row, unused): the caller resets it
+ *   to {0, 0, INT32_MAX, 0} when it drains the batch; valid rows = min(reserved, first dropped)
  *   ep_out float [ep_capacity,3] (world, total_reward, total_length), ep_count int32 [2]
  * reflush_done = 1 reproduces the reference: a done agent that is still reported learning re-flushes a
  * 2-row chunk on every later step of the episode; 0 records nothing more. */

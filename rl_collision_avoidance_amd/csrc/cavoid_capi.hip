@@ -250,7 +250,12 @@ static int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int grid_x,
     const dim3 grid(grid_x), block(64 * e->waves_per_block);
     const size_t lds = e->lds_bytes;
 #define CAVOID_CASE(NN) \
-    case NN: hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, k, st, e->pool, io); break;
+    case NN:                                                                                                            \
+        if (ev_start || ev_stop)                                                                                        \
+            hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, k, st, e->pool, io); \
+        else /* plain launch: capturable into a hipGraph */                                                             \
+            hipLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, k, st, e->pool, io);                         \
+        break;
     switch (e->cfg.max_agents) {
         CAVOID_CASE(1) CAVOID_CASE(2) CAVOID_CASE(3) CAVOID_CASE(4) CAVOID_CASE(5) CAVOID_CASE(6)
         CAVOID_CASE(7) CAVOID_CASE(8) CAVOID_CASE(9) CAVOID_CASE(10) CAVOID_CASE(11) CAVOID_CASE(12)
@@ -442,7 +447,7 @@ extern "C" int cavoid_rollout_create(int64_t num_worlds, int32_t max_agents, int
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_x = carve(L * S * D * sizeof(float)), o_r = carve(L * S * sizeof(double)), o_t = carve(L * S * sizeof(int32_t));
     const size_t o_a = carve(L * S), o_len = carve(S), o_since = carve(S), o_tr = carve(S), o_sc = carve(S * sizeof(double));
-    const size_t o_er = carve(W * sizeof(double)), o_el = carve(W * sizeof(int32_t));
+    const size_t o_er = carve(W * sizeof(double)), o_el = carve(W * sizeof(int32_t)), o_step = carve(sizeof(int32_t));
     if (hipMalloc(&r->slab, off) != hipSuccess) { delete r; return CAVOID_ENOMEM; }
     r->slab_bytes = off;
     if (hipMemset(r->slab, 0, off) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); cavoid_rollout_destroy(r); return CAVOID_EHIP; }
@@ -452,6 +457,7 @@ extern "C" int cavoid_rollout_create(int64_t num_worlds, int32_t max_agents, int
     r->s.len = b + o_len; r->s.since_flush = b + o_since; r->s.trained = b + o_tr;
     r->s.score = reinterpret_cast<double *>(b + o_sc);
     r->s.ep_reward = reinterpret_cast<double *>(b + o_er); r->s.ep_length = reinterpret_cast<int32_t *>(b + o_el);
+    r->s.step_counter = reinterpret_cast<int32_t *>(b + o_step);
     *out = r;
     return CAVOID_OK;
 }

@@ -38,6 +38,7 @@ struct RolloutState {
     double *score;           // [slots] reward_sum_logger[i]
     double *ep_reward;       // [W] total_reward of the running episode (ProcessAgent.py:236)
     int32_t *ep_length;      // [W] total_length (:237)
+    int32_t *step_counter;   // [1] device-side step index, used (and advanced) when the host passes step < 0
 };
 
 struct RolloutIO {
@@ -47,12 +48,12 @@ struct RolloutIO {
     const float *rewards;    // [slots]
     const uint8_t *done;     // [slots]
     const uint8_t *game_over;  // [W]
-    int32_t step;            // global step index (provenance)
+    int32_t step;            // global step index (provenance); < 0: use the device-side counter (graph replays)
     float *out_x;            // [capacity][D]
     float *out_r;            // [capacity]
     int32_t *out_a;          // [capacity]
     int32_t *out_src;        // [capacity][4]  world, agent, recorded-at step, emitted-at step
-    int32_t *out_count;      // [2]  rows appended, rows dropped for lack of capacity
+    int32_t *out_count;      // [4]  rows reserved, rows dropped for lack of capacity, first dropped row (INT_MAX: none), -
     float *ep_out;           // [ep_capacity][3]  world, total_reward, total_length
     int32_t *ep_count;       // [2]  records appended, dropped
 };
@@ -65,6 +66,7 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
     const int64_t slots = c.num_slots;
     const int64_t w = in_range ? a / N : 0;
     const int i = in_range ? (int)(a - w * N) : 0;
+    const int32_t step = io.step >= 0 ? io.step : *s.step_counter;
 
     bool learning = false, done = false, over = false;
     float reward = 0.f, value = 0.f;
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
         for (int k = 0; k < D; ++k) dst[k] = src[k];
         s.ring_r[(int64_t)pos * slots + a] = (double)reward;
         s.ring_a[(int64_t)pos * slots + a] = (uint8_t)action;
-        s.ring_t[(int64_t)pos * slots + a] = io.step;
+        s.ring_t[(int64_t)pos * slots + a] = step;
         len += 1;
         // ---- flush rule (:186, Python precedence: done OR (count == T_max AND NOT trained)) ------------
         flush = done || (since == c.time_max && !trained);
@@ -155,10 +157,11 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
                 io.out_src[4 * o + 0] = (int32_t)w;
                 io.out_src[4 * o + 1] = i;
                 io.out_src[4 * o + 2] = s.ring_t[e];
-                io.out_src[4 * o + 3] = io.step;
+                io.out_src[4 * o + 3] = step;
             }
-        } else {
+        } else {                                                 // batch full: rows below the first failure stay valid
             atomicAdd(io.out_count + 1, mine);
+            atomicMin(io.out_count + 2, (int32_t)(base < 0x7fffffff ? base : 0x7fffffff));
         }
         // episode totals: total_reward += score / n_learning ; total_length += len(r_) + 1 per chunk
         // (the leftover chunk adds its own (already zeroed) score and 1 + 1 frames, :199-202,236-237)
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
 __global__ void __launch_bounds__(256) rollout_episode_kernel(const RolloutCfg c, const RolloutState s, const RolloutIO io) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t W = c.num_slots / c.max_agents;
+    if (w == 0 && io.step < 0) *s.step_counter += 1;          // runs after every slot of the push kernel read it
     if (w >= W || io.game_over[w] == 0) return;
     const int slot = atomicAdd(io.ep_count, 1);
     if (slot < c.ep_capacity) {

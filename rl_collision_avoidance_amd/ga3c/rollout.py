@@ -57,7 +57,8 @@ class BatchedRollout(object):
         self.out_r = torch.empty((self.capacity,), dtype=torch.float32, device=dev)
         self.out_a = torch.empty((self.capacity,), dtype=torch.int32, device=dev)
         self.out_src = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
-        self.out_count = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self._count_init = torch.tensor([0, 0, 0x7FFFFFFF, 0], dtype=torch.int32, device=dev)
+        self.out_count = self._count_init.clone()
         self.ep_out = torch.empty((self.episode_capacity, 3), dtype=torch.float32, device=dev)
         self.ep_count = torch.zeros((2,), dtype=torch.int32, device=dev)
         self._obs_buffers = [env.obs, torch.zeros_like(env.obs)]
@@ -92,7 +93,7 @@ class BatchedRollout(object):
         self._cur = 0
         self.env.reset()
         _lib.check(self._lib.cavoid_rollout_reset(self._h, self.env._stream()), "cavoid_rollout_reset")
-        self.out_count.zero_()
+        self.out_count.copy_(self._count_init)
         self.ep_count.zero_()
         self.step_index = 0
         return self.obs
@@ -120,21 +121,51 @@ class BatchedRollout(object):
         _, rew, done, game_over = env.step_autoreset(actions, obs_out=nxt)
         p = BatchedCollisionAvoidanceEnv._ptr
         _lib.check(self._lib.cavoid_rollout_push(
-            self._h, p(obs), p(actions), p(values), p(rew), p(done), p(game_over), self.step_index,
+            self._h, p(obs), p(actions), p(values), p(rew), p(done), p(game_over), -1,      # -1: device-side step counter
             p(self.out_x), p(self.out_r), p(self.out_a), p(self.out_src), p(self.out_count), self.capacity,
             p(self.ep_out), p(self.ep_count), self.episode_capacity, env._stream()), "cavoid_rollout_push")
         self._cur = 1 - self._cur
         self.step_index += 1
         return rew, done, game_over
 
+    # -- hipGraph path ---------------------------------------------------------------------------------
+    def capture(self, steps_per_graph: int = 2) -> None:
+        """Capture ``steps_per_graph`` closed-loop steps -- policy forward, action sampling, env step and
+        experience bookkeeping -- into ONE hipGraph (HIP streams and graphs instead of a tracing
+        compiler).  The per-step launch train (tens of small kernels) then costs one graph replay.
+        Must be even: the two observation buffers alternate."""
+        if steps_per_graph < 2 or steps_per_graph % 2:
+            raise ValueError("steps_per_graph must be a positive even number")
+        if self.policy is None:
+            raise ValueError("capture() needs a policy")
+        side = torch.cuda.Stream(device=self.env.device)
+        side.wait_stream(torch.cuda.current_stream(self.env.device))
+        with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy inits)
+            for _ in range(2):
+                self.step()
+        torch.cuda.current_stream(self.env.device).wait_stream(side)
+        torch.cuda.synchronize(self.env.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            for _ in range(steps_per_graph):
+                self.step()
+        self.step_index -= steps_per_graph                # capture records, it does not execute
+        self._graph_steps = steps_per_graph
+
+    def replay(self, n_replays: int = 1) -> None:
+        """Run ``n_replays * steps_per_graph`` env steps of every world."""
+        for _ in range(n_replays):
+            self._graph.replay()
+        self.step_index += n_replays * self._graph_steps
+
     def drain(self) -> TrainingBatch:
         """Hand the flushed rows to the trainer (``training_q.put((x_, r_, a_))``, :238) and empty the
         device batch.  Synchronises (the row count comes back to the host)."""
-        n, dropped = [int(v) for v in self.out_count.tolist()]
-        n = min(n, self.capacity)
+        reserved, dropped, first_dropped, _ = [int(v) for v in self.out_count.tolist()]
+        n = min(reserved, first_dropped, self.capacity)     # rows below the first overflow are all valid
         batch = TrainingBatch(self.out_x[:n].clone(), self.out_r[:n].clone(), self.out_a[:n].clone(),
                               self.out_src[:n].clone(), self.env.num_actions, dropped)
-        self.out_count.zero_()
+        self.out_count.copy_(self._count_init)
         self.frames += n
         return batch
 

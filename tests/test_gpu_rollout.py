@@ -106,6 +106,34 @@ def test_rollout_matches_oracle(N, gen_min, nonl, reflush):
     env.close()
 
 
+def test_graph_replay_equals_eager_steps():
+    """A hipGraph of closed-loop steps replays to the same state / rows as stepping eagerly."""
+    from rl_collision_avoidance_amd.ga3c.network import NetworkVP_rnn
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    W, N = 512, 4
+    outs = []
+    for graphed in (False, True):
+        env = _make(W, N, 5)
+        net = NetworkVP_rnn(env.config, seed=1).cuda()
+        roll = BatchedRollout(env, net.predict_p_and_v, greedy=True, reflush_done=False, capacity=400000)   # argmax: no RNG in the loop
+        roll.reset()
+        if graphed:
+            roll.capture(steps_per_graph=4)             # 2 warm-up steps happen here
+            roll.replay(12)
+        else:
+            for _ in range(2 + 48):
+                roll.step()
+        b = roll.drain()
+        assert b.dropped == 0
+        order = torch.argsort(b.src[:, 0].long() * 10**9 + b.src[:, 1].long() * 10**7 + b.src[:, 3].long() * 10**3 + b.src[:, 2].long() % 1000)
+        outs.append((roll.obs.clone(), [t.clone() for t in env.get_state()], b.x[order], b.r[order], b.a_index[order], roll.step_index))
+        roll.close(); env.close()
+    (o0, s0, x0, r0, a0, n0), (o1, s1, x1, r1, a1, n1) = outs
+    assert n0 == n1 == 50
+    assert torch.equal(o0, o1) and all(torch.equal(u, v) for u, v in zip(s0, s1))
+    assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(a0, a1) and len(r0) > 0
+
+
 def test_rollout_with_policy_and_one_hot():
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
     W, N = 256, 4
@@ -126,4 +154,13 @@ def test_rollout_with_policy_and_one_hot():
     eps = roll.drain_episodes()
     assert eps.shape[1] == 3 and len(eps) > 0
     assert len(roll.drain()) == 0
+    # overflow: rows below the first dropped one stay valid, the rest is reported as dropped
+    small = BatchedRollout(env, policy, generator=gen, capacity=3000)
+    small.reset()
+    for _ in range(60):
+        small.step()
+    b = small.drain()
+    assert b.dropped > 0 and 0 < len(b) <= 3000
+    assert torch.all(b.x[:, 3] > 0) and torch.all(b.a.sum(dim=1) == 1)       # pref_speed column: every kept row is a real one
+    small.close()
     roll.close(); env.close()
