@@ -159,24 +159,28 @@ int cavoid_step_autoreset_n_timed(cavoid_env *env, const int32_t *actions, int64
  * Stands in for one ProcessAgent per world: ProcessAgent.run_episode / _accumulate_rewards /
  * convert_to_nparray (ga3c/GA3C/ProcessAgent.py:54-87,105-211) and the training_q / episode_log_q
  * puts (:238,243).  cavoid_rollout_push records one env step for every learning (world, agent) slot
- * and appends the flushed training rows (x, y_r, action) to a caller-owned device batch.
- *   prev_obs  float [W,N,1+D]  the observation the policy acted on (Environment.previous_state plus col 0)
- *   actions   int32 [W,N], values float [W,N] (V(s_t) of the predictor), rewards/done/game_over from the step
- *   out_x float [capacity,D], out_r float [capacity], out_a int32 [capacity] (action index; the trainer's
- *   one-hot is eye(num_actions)[out_a]), out_src int32 [capacity,4] (world, agent, recorded-at, emitted-at)
- *   out_count int32 [4] (rows reserved, rows dropped, index of the first dropped row, unused): the caller resets it
- *   to {0, 0, INT32_MAX, 0} when it drains the batch; valid rows = min(reserved, first dropped)
- *   ep_out float [ep_capacity,3] (world, total_reward, total_length), ep_count int32 [2]
- * reflush_done = 1 reproduces the reference: a done agent that is still reported learning re-flushes a
- * 2-row chunk on every later step of the episode; 0 records nothing more. */
+ * in a caller-owned TIME-MAJOR experience store of `ring_len` step blocks (block = step % ring_len):
+ *   x float [ring_len,W*N,D] (state the policy acted on), val double [ring_len,W*N] (reward -> n-step
+ *   return, working value), ret float [ring_len,W*N] (y_r the row was emitted with), act u8, valid u8
+ *   (1 = a training row), emit_t int32 (step of emission).  A block is final once it is older than
+ *   time_max + 1 steps; the caller compacts `valid` rows of final blocks into (x, y_r, action) batches
+ *   (the trainer's one-hot is eye(num_actions)[act]).
+ *   prev_obs float [W,N,1+D] = the observation the policy acted on (Environment.previous_state plus col 0),
+ *   actions int32 [W,N], values float [W,N] (V(s_t)), rewards/done/game_over = what the step returned.
+ *   dup_* : append buffer for the rows only the reference's post-done re-flush quirk produces
+ *   (reflush_done = 1: a done agent that is still reported learning re-emits its kept experience with
+ *   every later step); dup_count int32 [2] = (appended, dropped), reset by the caller.
+ *   ep_out float [ep_capacity,3] (world, total_reward, total_length), ep_count int32 [2].
+ *   step < 0: use (and advance) the handle's device-side step counter (hipGraph replays). */
 typedef struct cavoid_rollout cavoid_rollout;
 int cavoid_rollout_create(int64_t num_worlds, int32_t max_agents, int32_t obs_width, int32_t time_max, double discount,
-                          int32_t reflush_done, int device, cavoid_rollout **out);
+                          int32_t reflush_done, int32_t ring_len, int device, cavoid_rollout **out);
 void cavoid_rollout_destroy(cavoid_rollout *r);
 int cavoid_rollout_reset(cavoid_rollout *r, void *stream);
 int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t *actions, const float *values,
                         const float *rewards, const uint8_t *done, const uint8_t *game_over, int32_t step,
-                        float *out_x, float *out_r, int32_t *out_a, int32_t *out_src, int32_t *out_count, int64_t capacity,
+                        float *x, double *val, float *ret, uint8_t *act, uint8_t *valid, int32_t *emit_t,
+                        float *dup_x, float *dup_r, int32_t *dup_a, int32_t *dup_src, int32_t *dup_count, int64_t dup_capacity,
                         float *ep_out, int32_t *ep_count, int64_t ep_capacity, void *stream);
 
 /* kernel timing helper: HIP events recorded on `stream` around the launches of the calls made

@@ -10,12 +10,16 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
-SOURCES = [os.path.join(CSRC, "cavoid_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "cavoid_kernels.hpp"), os.path.join(CSRC, "cavoid_rollout.hpp"),
-               os.path.join(ROOT, "include", "cavoid.h")]
+SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip")]
+HEADERS = {
+    "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_host.hpp"],
+    "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_host.hpp"],
+}
+DEPS = SOURCES + [os.path.join(CSRC, h) for hs in HEADERS.values() for h in hs] + [os.path.join(ROOT, "include", "cavoid.h")]
+OBJ_DIR = os.path.join(PKG_DIR, "build")
 # -ffp-contract=off: the reference env is unfused NumPy float64; keep mul/add separate so that the
 # only numerical difference from the CPU oracle is the transcendental library.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
@@ -33,12 +37,34 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+def _compile_objects(extra_flags, tag: str, force: bool, verbose: bool):
+    """One object per translation unit, rebuilt only when it (or a header it includes) changed."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        name = os.path.basename(src)
+        obj = os.path.join(OBJ_DIR, name.replace(".hip", tag + ".o"))
+        deps = [src, os.path.join(ROOT, "include", "cavoid.h")] + [os.path.join(CSRC, h) for h in HEADERS[name]]
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+            cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    return objs
+
+
+def _link(objs, out: str, verbose: bool) -> str:
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
-        cmd = [hipcc()] + FLAGS + SOURCES + ["-o", LIB_PATH]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        _link(_compile_objects([], "", force, verbose), LIB_PATH, verbose)
     return LIB_PATH
 
 
@@ -46,11 +72,7 @@ def build_trace(verbose: bool = False) -> str:
     """Development variant with in-kernel phase time stamps (tools/trace_step.py); never loaded by
     the product (select it with CAVOID_LIB=<path>)."""
     out = os.path.join(PKG_DIR, "libcavoid_hip_trace.so")
-    cmd = [hipcc()] + FLAGS + ["-DCAVOID_TRACE"] + SOURCES + ["-o", out]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return out
+    return _link(_compile_objects(["-DCAVOID_TRACE"], ".trace", False, verbose), out, verbose)
 
 
 if __name__ == "__main__":

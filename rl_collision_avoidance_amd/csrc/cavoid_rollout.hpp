@@ -1,15 +1,24 @@
-// cavoid_rollout.hpp -- gfx950 kernel of the batched GA3C actor bookkeeping: what
+// cavoid_rollout.hpp -- gfx950 kernels of the batched GA3C actor bookkeeping: what
 // ProcessAgent.run_episode / _accumulate_rewards / convert_to_nparray do per actor process
 // (/root/reference/ga3c/GA3C/ProcessAgent.py:54-87,105-211; rows R3-R5 of SURVEY.md section 8a),
 // for every (world, agent) slot at once, on the device, with no queue hop.
 //
-// One lane per (world, agent) slot (flat index a = w*N + i, so per-slot arrays are read and
-// written coalesced).  Each slot owns a ring of T_max+1 experiences in HBM, laid out
-// [entry][slot] so that all lanes touch the same entry row together.  A step appends one
-// experience; a flush runs the backward n-step return over <= T_max+1 entries and appends the
-// resulting training rows to a device-side batch through one atomic reservation per wavefront.
-// HBM-bound integer/float bookkeeping: no MFMA, no LDS (nothing is shared between slots except
-// the world-level episode counters, reduced with wave ballots / DPP-free shuffles).
+// Layout: TIME-MAJOR experience store.  The training batch is a ring of `ring_len` step blocks
+//   x   float  [ring_len][slots][D]   state the policy acted on at that step (copied coalesced, once)
+//   val double [ring_len][slots]      single-step reward, overwritten by the n-step return at flush time (working value)
+//   ret float  [ring_len][slots]      the return the row was emitted with (y_r of the training row)
+//   act u8     [ring_len][slots]      action index
+//   valid u8   [ring_len][slots]      0 = pending / nothing recorded, 1 = emitted (a training row)
+//   emit_t i32 [ring_len][slots]      provenance: step at which the row was emitted
+// An experience is written where it will be trained from; a flush only walks the slot's <= T_max+1
+// pending returns (one coalesced load burst, the recurrence in registers, one store burst).  The
+// reference's "keep the last experience as the seed of the next chunk" costs nothing here: the
+// seed simply stays pending.  Closed blocks (older than T_max+1 steps) are compacted by the host.
+// Only the reference's post-done re-flush quirk produces rows that are not 1:1 with (step, slot);
+// those rare duplicates go to a small append buffer.
+//
+// One lane per (world, agent) slot, flat index a = w*N + i: every per-slot array is coalesced.
+// HBM-bound bookkeeping: no MFMA, no LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,17 +31,15 @@ struct RolloutCfg {
     int32_t obs_width;       // 1 + D (column 0 = is_learning)
     int32_t time_max;        // T_max (Config.TIME_MAX, Config.py:104)
     int32_t reflush_done;    // 1: reference behaviour -- a done agent keeps flushing 2-long chunks
+    int32_t ring_len;        // step blocks in the experience store (> T_max + 1)
+    int32_t _pad;
     double discount;         // Config.DISCOUNT (Config.py:103)
-    int64_t capacity;        // rows the output batch can hold
+    int64_t dup_capacity;    // rows the duplicate (re-flush) buffer can hold
     int64_t ep_capacity;     // episode-log records
 };
 
 struct RolloutState {
-    float *ring_x;           // [T_max+1][slots][D]
-    double *ring_r;          // [T_max+1][slots]   single-step reward, overwritten by the n-step return
-    int32_t *ring_t;         // [T_max+1][slots]   provenance: global step at which it was recorded
-    uint8_t *ring_a;         // [T_max+1][slots]
-    uint8_t *len;            // [slots] experiences held
+    uint8_t *len;            // [slots] pending experiences
     uint8_t *since_flush;    // [slots] time_counts[i]
     uint8_t *trained;        // [slots] which_agents_done_and_trained[i]
     double *score;           // [slots] reward_sum_logger[i]
@@ -48,29 +55,66 @@ struct RolloutIO {
     const float *rewards;    // [slots]
     const uint8_t *done;     // [slots]
     const uint8_t *game_over;  // [W]
-    int32_t step;            // global step index (provenance); < 0: use the device-side counter (graph replays)
-    float *out_x;            // [capacity][D]
-    float *out_r;            // [capacity]
-    int32_t *out_a;          // [capacity]
-    int32_t *out_src;        // [capacity][4]  world, agent, recorded-at step, emitted-at step
-    int32_t *out_count;      // [4]  rows reserved, rows dropped for lack of capacity, first dropped row (INT_MAX: none), -
+    int32_t step;            // global step index; < 0: use the device-side counter (graph replays)
+    float *x;                // [ring_len][slots][D]
+    double *val;             // [ring_len][slots]
+    float *ret;              // [ring_len][slots]
+    uint8_t *act;            // [ring_len][slots]
+    uint8_t *valid;          // [ring_len][slots]
+    int32_t *emit_t;         // [ring_len][slots]
+    float *dup_x;            // [dup_capacity][D]   re-flushed duplicates (reference quirk only)
+    float *dup_r;            // [dup_capacity]
+    int32_t *dup_a;          // [dup_capacity]
+    int32_t *dup_src;        // [dup_capacity][4]  world, agent, recorded-at step, emitted-at step
+    int32_t *dup_count;      // [2]  rows appended, rows dropped for lack of capacity
     float *ep_out;           // [ep_capacity][3]  world, total_reward, total_length
     int32_t *ep_count;       // [2]  records appended, dropped
 };
+
+constexpr int kMaxRing = 32;   // T_max + 1 <= 32: the backward pass runs in registers (else a serial fallback)
 
 __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, const RolloutState s, const RolloutIO io) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in_range = a < c.num_slots;
-    const int N = c.max_agents, D = c.obs_width - 1, L = c.time_max + 1;
+    const int N = c.max_agents, D = c.obs_width - 1, L = c.time_max + 1, RL = c.ring_len;
     const int64_t slots = c.num_slots;
     const int64_t w = in_range ? a / N : 0;
     const int i = in_range ? (int)(a - w * N) : 0;
     const int32_t step = io.step >= 0 ? io.step : *s.step_counter;
+    const int blk = step % RL;
+
+    // ---- the step's state rows -> x[blk]: a coalesced sweep of the wavefront's 64 contiguous rows --------
+    {
+        const int64_t a0 = a - lane;                             // first slot of this wavefront
+        int64_t rows = slots - a0;
+        rows = rows > 64 ? 64 : (rows < 0 ? 0 : rows);
+        const int total = (int)rows * D;
+        const float *src = io.prev_obs + a0 * c.obs_width;
+        float *dst = io.x + ((int64_t)blk * slots + a0) * D;
+        for (int i0 = lane; i0 < total; i0 += 64 * 8) {          // 8 loads in flight per lane, then 8 stores
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + 64 * u;
+                const int r = idx / D, q = idx - r * D;
+                v[u] = idx < total ? src[r * c.obs_width + 1 + q] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + 64 * u;
+                if (idx < total) dst[idx] = v[u];
+            }
+        }
+    }
 
     bool learning = false, done = false, over = false;
     float reward = 0.f, value = 0.f;
     int action = 0;
+    int len = 0, since = 0;
+    bool trained = false;
+    double score = 0.0;
+    int n_learning = 0;
     if (in_range) {
         learning = io.prev_obs[a * c.obs_width] > 0.5f;      // is_learning column (ProcessAgent.py:130)
         done = io.done[a] != 0;
@@ -78,34 +122,29 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
         reward = io.rewards[a];
         value = io.values[a];
         action = io.actions[a];
-    }
-    int len = 0, since = 0;
-    bool trained = false;
-    double score = 0.0;
-    if (in_range) { len = s.len[a]; since = s.since_flush[a]; trained = s.trained[a] != 0; score = s.score[a]; }
-
-    // number of learning agents of this lane's world (the divisor of the chunk score, :157,195);
-    // a world's N slots are adjacent lanes but may straddle a wavefront edge, so count via memory-free
-    // neighbour reads of the is_learning column instead of a ballot
-    int n_learning = 0;
-    if (in_range)
+        len = s.len[a]; since = s.since_flush[a]; trained = s.trained[a] != 0; score = s.score[a];
+        // learning agents of this lane's world: the divisor of the chunk score (:157,195).  A world's N slots
+        // are adjacent lanes but may straddle a wavefront edge, so read the is_learning column directly
         for (int k = 0; k < N; ++k) n_learning += io.prev_obs[(w * N + k) * c.obs_width] > 0.5f ? 1 : 0;
+    }
+    const bool was_trained = trained;
 
     int n_rows = 0;            // rows of the main chunk
     bool leftover = false;     // + one separate 1-row chunk
     int count = 0;             // entries the backward pass covers
     bool flush = false;
     const bool frozen = !c.reflush_done && trained;          // cleaned mode: a trained agent records nothing more
-    if (learning && !frozen) {
-        score += (double)reward;
+    const bool record = learning && !frozen;
+    const int64_t cur = (int64_t)blk * slots + a;
+    if (in_range) {
         // ---- append (Experience(previous_state[0,i,:], action, prediction, reward, done), :172-177) ----
-        const int pos = len;
-        const float *src = io.prev_obs + a * c.obs_width + 1;
-        float *dst = s.ring_x + ((int64_t)pos * slots + a) * D;
-        for (int k = 0; k < D; ++k) dst[k] = src[k];
-        s.ring_r[(int64_t)pos * slots + a] = (double)reward;
-        s.ring_a[(int64_t)pos * slots + a] = (uint8_t)action;
-        s.ring_t[(int64_t)pos * slots + a] = step;
+        io.val[cur] = (double)reward;
+        io.act[cur] = (uint8_t)action;
+        io.valid[cur] = 0;                                   // pending (or: nothing recorded at this step)
+        io.emit_t[cur] = -1;
+    }
+    if (record) {
+        score += (double)reward;
         len += 1;
         // ---- flush rule (:186, Python precedence: done OR (count == T_max AND NOT trained)) ------------
         flush = done || (since == c.time_max && !trained);
@@ -116,72 +155,85 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
             else { n_rows = len - 1; count = len - 1; }
         }
     }
-
-    // ---- reserve output rows: wave-level exclusive scan + one atomic per wavefront ----------------------
     const int mine = n_rows + (leftover ? 1 : 0);
-    int prefix = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(prefix, off);
-        if (lane >= off) prefix += v;
-    }
-    const int wave_total = __shfl(prefix, 63);
-    int64_t base = 0;
-    if (wave_total > 0) {
-        int wave_base = 0;
-        if (lane == 63) wave_base = atomicAdd(io.out_count, wave_total);
-        wave_base = __shfl(wave_base, 63);
-        base = (int64_t)wave_base + (prefix - mine);
-    }
+    const int newest = len - 1;                              // the entry appended in this launch
+    // pending entry k (0 = oldest) was recorded at step  step - newest + k
+    // the reference's quirk: once trained, the kept (already emitted) seed is emitted AGAIN with every later
+    // step's experience -- such a duplicate cannot live in the (step, slot) store
+    const bool dup0 = flush && was_trained && len >= 2;
 
     if (flush) {
         // ---- n-step return, newest to oldest, overwriting the stored rewards (:54-79) ------------------
         double R = done ? 0.0 : (double)value;
         if (done) trained = true;
-        for (int k = count - 1; k >= 0; --k) {
-            const int64_t e = (int64_t)k * slots + a;
-            R = c.discount * R + s.ring_r[e];
-            s.ring_r[e] = R;
-        }
-        // ---- emit rows (convert_to_nparray, :82-87) -----------------------------------------------------
-        const bool fits = base + mine <= c.capacity;
-        if (fits) {
-            for (int k = 0; k < mine; ++k) {                     // the leftover row is entry len-1
-                const int64_t e = (int64_t)k * slots + a;
-                const int64_t o = base + k;
-                const float *src = s.ring_x + e * D;
-                float *dst = io.out_x + o * D;
-                for (int q = 0; q < D; ++q) dst[q] = src[q];
-                io.out_r[o] = (float)s.ring_r[e];
-                io.out_a[o] = (int32_t)s.ring_a[e];
-                io.out_src[4 * o + 0] = (int32_t)w;
-                io.out_src[4 * o + 1] = i;
-                io.out_src[4 * o + 2] = s.ring_t[e];
-                io.out_src[4 * o + 3] = step;
+        double r0 = 0.0;                                      // return of the oldest pending entry (duplicate path)
+        if (L <= kMaxRing) {
+            // all pending rewards in flight at once, then the recurrence in registers
+            double rr[kMaxRing];
+#pragma unroll
+            for (int k = 0; k < kMaxRing; ++k) {
+                const int tk = step - newest + k;
+                rr[k] = (k < newest) ? io.val[(int64_t)(tk % RL) * slots + a] : (double)reward;
             }
-        } else {                                                 // batch full: rows below the first failure stay valid
-            atomicAdd(io.out_count + 1, mine);
-            atomicMin(io.out_count + 2, (int32_t)(base < 0x7fffffff ? base : 0x7fffffff));
+#pragma unroll
+            for (int k = kMaxRing - 1; k >= 0; --k)
+                if (k < count) { R = c.discount * R + rr[k]; rr[k] = R; }
+#pragma unroll
+            for (int k = 0; k < kMaxRing; ++k) {
+                const int tk = step - newest + k;
+                const int64_t e = (int64_t)(tk % RL) * slots + a;
+                if (k < count) io.val[e] = rr[k];
+                if (k < mine && !(dup0 && k == 0)) {            // convert_to_nparray (:82-87): the row goes live
+                    io.ret[e] = (float)rr[k]; io.valid[e] = 1; io.emit_t[e] = step;
+                }
+            }
+            r0 = rr[0];
+        } else {
+            for (int k = count - 1; k >= 0; --k) {
+                const int64_t e = (int64_t)((step - newest + k) % RL) * slots + a;
+                R = c.discount * R + (k == newest ? (double)reward : io.val[e]);
+                io.val[e] = R;
+                if (k == 0) r0 = R;
+            }
+            for (int k = 0; k < mine; ++k) {
+                const int64_t e = (int64_t)((step - newest + k) % RL) * slots + a;
+                if (!(dup0 && k == 0)) { io.ret[e] = (float)(k == newest && k >= count ? (double)reward : io.val[e]); io.valid[e] = 1; io.emit_t[e] = step; }
+            }
+        }
+        if (dup0) {                                          // rare: one appended duplicate row
+            const int slot = atomicAdd(io.dup_count, 1);
+            if (slot < c.dup_capacity) {
+                const int t0 = step - newest;
+                const float *src = io.x + ((int64_t)(t0 % RL) * slots + a) * D;
+                float *dst = io.dup_x + (int64_t)slot * D;
+                for (int k0 = 0; k0 < D; k0 += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = (k0 + u < D) ? src[k0 + u] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (k0 + u < D) dst[k0 + u] = v[u];
+                }
+                io.dup_r[slot] = (float)r0;
+                io.dup_a[slot] = (int32_t)io.act[(int64_t)(t0 % RL) * slots + a];
+                io.dup_src[4 * slot + 0] = (int32_t)w;
+                io.dup_src[4 * slot + 1] = i;
+                io.dup_src[4 * slot + 2] = t0;
+                io.dup_src[4 * slot + 3] = step;
+            } else {
+                atomicAdd(io.dup_count + 1, 1);
+            }
         }
         // episode totals: total_reward += score / n_learning ; total_length += len(r_) + 1 per chunk
         // (the leftover chunk adds its own (already zeroed) score and 1 + 1 frames, :199-202,236-237)
-        atomicAdd(s.ep_reward + w, score / (double)n_learning);
+        unsafeAtomicAdd(s.ep_reward + w, score / (double)n_learning);
         atomicAdd(s.ep_length + w, n_rows + 1 + (leftover ? 2 : 0));
         score = 0.0;
-        // ---- keep the newest experience as the seed of the next chunk (:205-208) ------------------------
-        if (len > 1) {
-            const int64_t last = (int64_t)(len - 1) * slots + a, first = a;
-            const float *src = s.ring_x + last * D;
-            float *dst = s.ring_x + first * D;
-            for (int q = 0; q < D; ++q) dst[q] = src[q];
-            s.ring_r[first] = s.ring_r[last];
-            s.ring_a[first] = s.ring_a[last];
-            s.ring_t[first] = s.ring_t[last];
-        }
+        // the newest experience stays pending as the seed of the next chunk (:205-208)
         len = 1;
         since = 0;
     }
-    if (learning && !frozen) since += 1;
+    if (record) since += 1;
 
     if (in_range) {
         if (over) {                                            // the episode is over: run_episode starts afresh

@@ -6,9 +6,11 @@ return of ``_accumulate_rewards`` (:54-79), ``convert_to_nparray`` (:82-87) and 
 puts of ``run`` (:233-243).  Nothing crosses a process boundary: the policy is called once per
 step on the whole ``[W*N, D]`` observation matrix (what 128-row ``ThreadPredictor`` batches
 approximate, ThreadPredictor.py:40-75), the env steps in one kernel launch, and a second kernel
-(csrc/cavoid_rollout.hpp) keeps the experience rings and appends flushed training rows to a device
-batch that ``drain()`` hands to the trainer in the shapes ``Server.train_model(x_, r_, a_)``
-takes (Server.py:114-124; x [n, D], r [n], a one-hot float32 [n, num_actions])."""
+(csrc/cavoid_rollout.hpp) keeps a TIME-MAJOR experience store: step t's states, actions and
+(later) n-step returns live in block ``t % ring_len``; a row becomes a training row the moment
+the reference would have yielded it.  ``drain()`` compacts the final blocks into the shapes
+``Server.train_model(x_, r_, a_)`` takes (Server.py:114-124; x [n, D], r [n], a one-hot f32
+[n, num_actions])."""
 from __future__ import annotations
 
 import ctypes as C
@@ -23,7 +25,7 @@ Policy = Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]   # x[B, D]
 
 
 class TrainingBatch(object):
-    """Rows flushed since the last drain: ``x`` f32 [n, D], ``r`` f32 [n] (n-step returns),
+    """Rows that became final since the last drain: ``x`` f32 [n, D], ``r`` f32 [n] (n-step returns),
     ``a_index`` int32 [n], ``src`` int32 [n, 4] (world, agent, recorded-at step, emitted-at step)."""
 
     def __init__(self, x, r, a_index, src, num_actions: int, dropped: int):
@@ -40,9 +42,10 @@ class TrainingBatch(object):
 
 
 class BatchedRollout(object):
-    def __init__(self, env: BatchedCollisionAvoidanceEnv, policy: Policy, time_max: Optional[int] = None,
-                 discount: float = 0.97, capacity: Optional[int] = None, episode_capacity: Optional[int] = None,
-                 reflush_done: bool = True, greedy: bool = False, generator: Optional[torch.Generator] = None):
+    def __init__(self, env: BatchedCollisionAvoidanceEnv, policy: Optional[Policy], time_max: Optional[int] = None,
+                 discount: float = 0.97, ring_len: Optional[int] = None, dup_capacity: Optional[int] = None,
+                 episode_capacity: Optional[int] = None, reflush_done: bool = True, greedy: bool = False,
+                 generator: Optional[torch.Generator] = None):
         self.env, self.policy = env, policy
         cfg = env.config
         self.time_max = int(time_max if time_max is not None else getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
@@ -50,26 +53,42 @@ class BatchedRollout(object):
         self.greedy = greedy                     # PLAY_MODE / EVALUATE_MODE: argmax instead of sampling (:98-103)
         self.generator = generator
         W, N, D = env.num_worlds, env.max_agents, env.obs_width - 1
-        self.capacity = int(capacity if capacity is not None else 4 * W * N + 4096)
+        self.slots = W * N
+        # a block is final T_max + 2 steps after it was written; keep twice that between drains
+        self.margin = self.time_max + 2
+        self.ring_len = int(ring_len if ring_len is not None else 2 * self.margin + 8)
+        if self.ring_len < self.margin + 2:
+            raise ValueError("ring_len must exceed time_max + 3")
+        self.dup_capacity = int(dup_capacity if dup_capacity is not None else 2 * self.slots + 1024)
         self.episode_capacity = int(episode_capacity if episode_capacity is not None else 4 * W + 1024)
         dev = env.device
-        self.out_x = torch.empty((self.capacity, D), dtype=torch.float32, device=dev)
-        self.out_r = torch.empty((self.capacity,), dtype=torch.float32, device=dev)
-        self.out_a = torch.empty((self.capacity,), dtype=torch.int32, device=dev)
-        self.out_src = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
-        self._count_init = torch.tensor([0, 0, 0x7FFFFFFF, 0], dtype=torch.int32, device=dev)
-        self.out_count = self._count_init.clone()
+        R, S = self.ring_len, self.slots
+        self.x = torch.zeros((R, S, D), dtype=torch.float32, device=dev)
+        self.val = torch.zeros((R, S), dtype=torch.float64, device=dev)
+        self.ret = torch.zeros((R, S), dtype=torch.float32, device=dev)
+        self.act_ring = torch.zeros((R, S), dtype=torch.uint8, device=dev)
+        self.valid = torch.zeros((R, S), dtype=torch.uint8, device=dev)
+        self.emit_t = torch.full((R, S), -1, dtype=torch.int32, device=dev)
+        self.dup_x = torch.empty((self.dup_capacity, D), dtype=torch.float32, device=dev)
+        self.dup_r = torch.empty((self.dup_capacity,), dtype=torch.float32, device=dev)
+        self.dup_a = torch.empty((self.dup_capacity,), dtype=torch.int32, device=dev)
+        self.dup_src = torch.empty((self.dup_capacity, 4), dtype=torch.int32, device=dev)
+        self.dup_count = torch.zeros((2,), dtype=torch.int32, device=dev)
         self.ep_out = torch.empty((self.episode_capacity, 3), dtype=torch.float32, device=dev)
         self.ep_count = torch.zeros((2,), dtype=torch.int32, device=dev)
         self._obs_buffers = [env.obs, torch.zeros_like(env.obs)]
         self._cur = 0
-        self.step_index = 0
-        self.frames = 0                           # learning-agent steps emitted (the reference's PPS numerator)
+        self.step_index = 0                       # pushes done so far == the next step's index
+        self.drained_until = 0                    # blocks with step < drained_until were handed out
+        self.frames = 0                           # rows handed to the trainer (the reference's PPS numerator)
+        self.lost_blocks = 0                      # blocks overwritten before a drain (drain more often / larger ring_len)
         self._lib = _lib.lib()
         h = C.c_void_p()
         _lib.check(self._lib.cavoid_rollout_create(W, N, env.obs_width, self.time_max, self.discount,
-                                                   1 if reflush_done else 0, dev.index, C.byref(h)), "cavoid_rollout_create")
+                                                   1 if reflush_done else 0, self.ring_len, dev.index, C.byref(h)),
+                   "cavoid_rollout_create")
         self._h = h
+        self._graph = None
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
@@ -93,9 +112,11 @@ class BatchedRollout(object):
         self._cur = 0
         self.env.reset()
         _lib.check(self._lib.cavoid_rollout_reset(self._h, self.env._stream()), "cavoid_rollout_reset")
-        self.out_count.copy_(self._count_init)
+        self.valid.zero_()
+        self.dup_count.zero_()
         self.ep_count.zero_()
         self.step_index = 0
+        self.drained_until = 0
         return self.obs
 
     def act(self, obs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -122,7 +143,8 @@ class BatchedRollout(object):
         p = BatchedCollisionAvoidanceEnv._ptr
         _lib.check(self._lib.cavoid_rollout_push(
             self._h, p(obs), p(actions), p(values), p(rew), p(done), p(game_over), -1,      # -1: device-side step counter
-            p(self.out_x), p(self.out_r), p(self.out_a), p(self.out_src), p(self.out_count), self.capacity,
+            p(self.x), p(self.val), p(self.ret), p(self.act_ring), p(self.valid), p(self.emit_t),
+            p(self.dup_x), p(self.dup_r), p(self.dup_a), p(self.dup_src), p(self.dup_count), self.dup_capacity,
             p(self.ep_out), p(self.ep_count), self.episode_capacity, env._stream()), "cavoid_rollout_push")
         self._cur = 1 - self._cur
         self.step_index += 1
@@ -133,7 +155,8 @@ class BatchedRollout(object):
         """Capture ``steps_per_graph`` closed-loop steps -- policy forward, action sampling, env step and
         experience bookkeeping -- into ONE hipGraph (HIP streams and graphs instead of a tracing
         compiler).  The per-step launch train (tens of small kernels) then costs one graph replay.
-        Must be even: the two observation buffers alternate."""
+        Must be even: the two observation buffers alternate.  The experience store is addressed by the
+        handle's device-side step counter, so a replay lands in the right blocks."""
         if steps_per_graph < 2 or steps_per_graph % 2:
             raise ValueError("steps_per_graph must be a positive even number")
         if self.policy is None:
@@ -158,15 +181,54 @@ class BatchedRollout(object):
             self._graph.replay()
         self.step_index += n_replays * self._graph_steps
 
-    def drain(self) -> TrainingBatch:
-        """Hand the flushed rows to the trainer (``training_q.put((x_, r_, a_))``, :238) and empty the
-        device batch.  Synchronises (the row count comes back to the host)."""
-        reserved, dropped, first_dropped, _ = [int(v) for v in self.out_count.tolist()]
-        n = min(reserved, first_dropped, self.capacity)     # rows below the first overflow are all valid
-        batch = TrainingBatch(self.out_x[:n].clone(), self.out_r[:n].clone(), self.out_a[:n].clone(),
-                              self.out_src[:n].clone(), self.env.num_actions, dropped)
-        self.out_count.copy_(self._count_init)
-        self.frames += n
+    # -- hand-over to the trainer ------------------------------------------------------------------------
+    def pending_final_steps(self) -> Tuple[int, int]:
+        """[lo, hi): steps whose blocks are final (no slot can still hold a pending return in them)."""
+        hi = max(self.step_index - self.margin, self.drained_until)
+        lo = self.drained_until
+        oldest_alive = self.step_index - self.ring_len       # anything older has been overwritten
+        if lo < oldest_alive:
+            self.lost_blocks += oldest_alive - lo
+            lo = oldest_alive
+        return lo, hi
+
+    def drain(self, flush_all: bool = False) -> TrainingBatch:
+        """Hand the final rows to the trainer (``training_q.put((x_, r_, a_))``, :238).  ``flush_all``
+        also takes the not-yet-final blocks' emitted rows (end of a run / tests).  One device-side
+        compaction (boolean-mask gather); synchronises."""
+        lo, hi = self.pending_final_steps()
+        if flush_all:
+            hi = self.step_index
+        W, N = self.env.num_worlds, self.env.max_agents
+        xs, rs, as_, srcs = [], [], [], []
+        if hi > lo:
+            steps = torch.arange(lo, hi, device=self.env.device)
+            blocks = steps % self.ring_len
+            valid = self.valid[blocks] != 0                                  # [k, slots]
+            idx = valid.nonzero(as_tuple=False)                              # [n, 2] (block position, slot)
+            b, sl = blocks[idx[:, 0]], idx[:, 1]
+            xs.append(self.x[b, sl])
+            rs.append(self.ret[b, sl])
+            as_.append(self.act_ring[b, sl].to(torch.int32))
+            srcs.append(torch.stack([(sl // N).to(torch.int32), (sl % N).to(torch.int32), steps[idx[:, 0]].to(torch.int32),
+                                     self.emit_t[b, sl]], dim=1))
+            if flush_all:
+                self.valid[b, sl] = 0                                        # do not hand these out twice
+            self.drained_until = hi if not flush_all else self.drained_until
+            if not flush_all:
+                self.drained_until = hi
+        n_dup, dropped = [int(v) for v in self.dup_count.tolist()]
+        n_dup = min(n_dup, self.dup_capacity)
+        if n_dup:
+            xs.append(self.dup_x[:n_dup].clone()); rs.append(self.dup_r[:n_dup].clone())
+            as_.append(self.dup_a[:n_dup].clone()); srcs.append(self.dup_src[:n_dup].clone())
+        self.dup_count.zero_()
+        D = self.env.obs_width - 1
+        dev = self.env.device
+        cat = lambda parts, shape, dt: torch.cat(parts) if parts else torch.empty(shape, dtype=dt, device=dev)
+        batch = TrainingBatch(cat(xs, (0, D), torch.float32), cat(rs, (0,), torch.float32), cat(as_, (0,), torch.int32),
+                              cat(srcs, (0, 4), torch.int32), self.env.num_actions, dropped + 0)
+        self.frames += len(batch)
         return batch
 
     def drain_episodes(self) -> torch.Tensor:

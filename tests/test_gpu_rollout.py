@@ -30,7 +30,8 @@ def test_rollout_matches_oracle(N, gen_min, nonl, reflush):
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
     W, steps, seed, T_MAX, GAMMA = 96, 260, 3, 20, 0.97
     env = _make(W, N, seed, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
-    roll = BatchedRollout(env, policy=None, time_max=T_MAX, discount=GAMMA, reflush_done=reflush, capacity=1000000)
+    roll = BatchedRollout(env, policy=None, time_max=T_MAX, discount=GAMMA, reflush_done=reflush, ring_len=steps + 8,
+                          dup_capacity=1000000)
     roll.reset()
     rng = np.random.default_rng(seed)
     rec = []
@@ -41,7 +42,7 @@ def test_rollout_matches_oracle(N, gen_min, nonl, reflush):
         vals = np.round(rng.normal(0, 0.5, size=(W, N)), 3).astype(np.float32)
         rew, done, over = roll.step(torch.from_numpy(acts).cuda(), torch.from_numpy(vals).cuda())
         rec.append((obs, acts, vals, rew.cpu().numpy().copy(), done.cpu().numpy().astype(bool), over.cpu().numpy().astype(bool)))
-    batch = roll.drain()
+    batch = roll.drain(flush_all=True)
     episodes = roll.drain_episodes().cpu().numpy()
     assert batch.dropped == 0 and len(batch) > W * 20
     x, r, a, src = [v.cpu().numpy() for v in (batch.x, batch.r, batch.a_index, batch.src)]
@@ -115,7 +116,7 @@ def test_graph_replay_equals_eager_steps():
     for graphed in (False, True):
         env = _make(W, N, 5)
         net = NetworkVP_rnn(env.config, seed=1).cuda()
-        roll = BatchedRollout(env, net.predict_p_and_v, greedy=True, reflush_done=False, capacity=400000)   # argmax: no RNG in the loop
+        roll = BatchedRollout(env, net.predict_p_and_v, greedy=True, reflush_done=False, ring_len=64)   # argmax: no RNG in the loop
         roll.reset()
         if graphed:
             roll.capture(steps_per_graph=4)             # 2 warm-up steps happen here
@@ -123,8 +124,8 @@ def test_graph_replay_equals_eager_steps():
         else:
             for _ in range(2 + 48):
                 roll.step()
-        b = roll.drain()
-        assert b.dropped == 0
+        b = roll.drain(flush_all=True)
+        assert b.dropped == 0 and roll.lost_blocks == 0
         order = torch.argsort(b.src[:, 0].long() * 10**9 + b.src[:, 1].long() * 10**7 + b.src[:, 3].long() * 10**3 + b.src[:, 2].long() % 1000)
         outs.append((roll.obs.clone(), [t.clone() for t in env.get_state()], b.x[order], b.r[order], b.a_index[order], roll.step_index))
         roll.close(); env.close()
@@ -146,21 +147,25 @@ def test_rollout_with_policy_and_one_hot():
         return torch.full((B, 11), 1.0 / 11, device=x.device), torch.zeros(B, device=x.device)
     roll = BatchedRollout(env, policy, generator=gen)
     roll.reset()
-    for _ in range(120):
+    total = 0
+    for k in range(120):
         roll.step()
-    b = roll.drain()
+        if k % 10 == 9:
+            total += len(roll.drain())
+    b = roll.drain(flush_all=True)
+    assert total > 0 and roll.lost_blocks == 0
     assert len(b) > 0 and b.x.shape == (len(b), 26) and b.a.shape == (len(b), 11) and b.a.dtype == torch.float32
     assert torch.all(b.a.sum(dim=1) == 1) and torch.isfinite(b.r).all() and torch.isfinite(b.x).all()
     eps = roll.drain_episodes()
     assert eps.shape[1] == 3 and len(eps) > 0
-    assert len(roll.drain()) == 0
-    # overflow: rows below the first dropped one stay valid, the rest is reported as dropped
-    small = BatchedRollout(env, policy, generator=gen, capacity=3000)
+    assert len(roll.drain(flush_all=True)) == 0
+    # a ring that is too short for the drain cadence loses blocks and says so
+    small = BatchedRollout(env, policy, generator=gen, ring_len=26)
     small.reset()
-    for _ in range(60):
+    for _ in range(80):
         small.step()
     b = small.drain()
-    assert b.dropped > 0 and 0 < len(b) <= 3000
+    assert small.lost_blocks > 0 and len(b) > 0
     assert torch.all(b.x[:, 3] > 0) and torch.all(b.a.sum(dim=1) == 1)       # pref_speed column: every kept row is a real one
     small.close()
     roll.close(); env.close()
