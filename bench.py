@@ -88,7 +88,7 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     net = NetworkVP_rnn(cfg).to(device)
     trainer = A3CTrainer(net)
     train_every = 4                                          # env steps per hipGraph replay (even)
-    roll = BatchedRollout(env, net.predict_p_and_v, capacity=2 * train_every * W * N + 4096, reflush_done=False)
+    roll = BatchedRollout(env, net.predict_p_and_v, reflush_done=False)
     roll.reset()
     roll.capture(steps_per_graph=train_every)                # policy + sampling + env.step + bookkeeping as ONE graph
 
@@ -130,6 +130,10 @@ def main() -> None:
                     help="also time BASELINE configs[4]: batched env + NetworkVP_rnn policy + rollout bookkeeping + Adam steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 code path)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="dry run: every rank uses cuda:0 (exercises the multi-rank logic on a 1-GPU box; needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -144,11 +148,16 @@ def main() -> None:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world_size))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     N, W = args.agents, args.worlds
 
@@ -191,7 +200,7 @@ def main() -> None:
     sync_all()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps

@@ -215,6 +215,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     int wpb = (int)((size_t)65536 / per_wave);
     if (wpb < 1) { cavoid_destroy(e); return CAVOID_EUNSUPPORTED; }
     if (wpb > 4) wpb = 4;
+    if (const char *ov = std::getenv("CAVOID_WAVES_PER_BLOCK")) { int v = std::atoi(ov); if (v >= 1 && v <= wpb) wpb = v; }
     e->waves_per_block = wpb;
     e->lds_bytes = per_wave * wpb;
     e->grid = grid_for(e, num_worlds);

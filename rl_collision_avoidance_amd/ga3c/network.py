@@ -132,18 +132,45 @@ def input_normalisation(config):
 
 
 class A3CTrainer(object):
-    """``Server.train_model`` (Server.py:114-124) without the queue: one Adam step per batch."""
+    """``Server.train_model`` (Server.py:114-124) without the queue: one Adam step per batch.
 
-    def __init__(self, model: NetworkVP_rnn, learning_rate: float = 2e-5):
+    Multi-GPU (one process per GPU, a policy replica each): pass ``group`` (or rely on the default
+    process group) and every step sums the replicas' gradients with ONE all-reduce of a flat buffer
+    -- the model is 0.6 MB, one bucket is the right bucketing for the per-link-bound xGMI rings -- so
+    the replicas take the identical Adam step a single trainer would take on the concatenated batch
+    (the A3C loss is a SUM over rows, NetworkVPCore.py:71-100)."""
+
+    def __init__(self, model: NetworkVP_rnn, learning_rate: float = 2e-5, group=None, distributed: Optional[bool] = None):
+        import torch.distributed as dist
         self.model = model
         self.opt = torch.optim.Adam(model.parameters(), lr=learning_rate, eps=1e-8)     # tf.train.AdamOptimizer defaults
         self.training_step = 0
         self.frame_counter = 0
+        self.group = group
+        self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) \
+            if distributed is None else distributed
+        self._params = [p for p in model.parameters()]
+        self._flat = None
+
+    def _allreduce_grads(self) -> None:
+        import torch.distributed as dist
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._params]
+        if self._flat is None:
+            self._flat = torch.empty(sum(g.numel() for g in grads), dtype=grads[0].dtype, device=grads[0].device)
+        torch.cat([g.reshape(-1) for g in grads], out=self._flat)
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for p, g in zip(self._params, grads):
+            n = g.numel()
+            p.grad = self._flat[off:off + n].view_as(p).clone()
+            off += n
 
     def train(self, x: torch.Tensor, y_r: torch.Tensor, a_onehot: torch.Tensor) -> float:
         self.opt.zero_grad(set_to_none=True)
         total, _, _ = self.model.loss(x, y_r, a_onehot)
         total.backward()
+        if self.distributed:
+            self._allreduce_grads()
         self.opt.step()
         self.training_step += 1
         self.frame_counter += int(x.shape[0])

@@ -79,3 +79,47 @@ def test_two_rank_gloo_gather_equals_unsharded(total):
     for rank in range(size):
         assert ret[rank].shape == want.shape
         assert np.array_equal(ret[rank], want), rank       # every rank holds the global result, bitwise
+
+
+def _dp_worker(rank, size, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        from rl_collision_avoidance_amd.config import EnvConfig
+        from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
+        torch.manual_seed(0)
+        net = NetworkVP_rnn(EnvConfig(), seed=4)
+        tr = A3CTrainer(net, learning_rate=1e-3)
+        assert tr.distributed
+        g = torch.Generator().manual_seed(100)
+        x = torch.randn(64, 26, generator=g); x[:, 0] = torch.randint(0, 4, (64,), generator=g).float()
+        y = torch.randn(64, generator=g)
+        a = torch.nn.functional.one_hot(torch.randint(0, 11, (64,), generator=g), 11).float()
+        half = slice(rank * 32, (rank + 1) * 32)
+        for _ in range(5):
+            tr.train(x[half], y[half], a[half])
+        ret[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_trainer_matches_single_trainer():
+    """Replica per rank + one flat gradient all-reduce == a single trainer on the concatenated batch."""
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
+    port = 29700 + (os.getpid() % 1000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert np.array_equal(ret[0], ret[1])                       # replicas stay in lock step
+    net = NetworkVP_rnn(EnvConfig(), seed=4)
+    tr = A3CTrainer(net, learning_rate=1e-3, distributed=False)
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(64, 26, generator=g); x[:, 0] = torch.randint(0, 4, (64,), generator=g).float()
+    y = torch.randn(64, generator=g)
+    a = torch.nn.functional.one_hot(torch.randint(0, 11, (64,), generator=g), 11).float()
+    for _ in range(5):
+        tr.train(x, y, a)
+    single = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    np.testing.assert_allclose(ret[0], single, rtol=0, atol=2e-5)
