@@ -8,8 +8,8 @@ A "step" = one pass of the hot path (cavoid_step_autoreset: decode, dynamics, pa
 rewards, done flags, sorted observation, in-kernel restart of finished worlds) over one batch of
 synthetic worlds: BASELINE configs[1], 4 agents x 8192 worlds per GPU, unicycle dynamics, random
 actions pre-generated on the device.  Weak scaling: every rank steps its own 8192 worlds (RNG
-keyed on global world ids); no data-path collective (the obs all-gather of configs[2] is
-measured separately with --gather).  Rank 0 prints ONE JSON line.
+keyed on global world ids); no data-path collective in the headline region (for N>1 the obs
+all-gather of configs[2] is timed afterwards and reported under "extra").  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -124,7 +124,8 @@ def main() -> None:
     ap.add_argument("--worlds", type=int, default=8192, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--slices", type=int, default=64, help="distinct pre-generated action slices")
-    ap.add_argument("--gather", action="store_true", help="also time the per-step RCCL all-gather of (obs,reward,done)")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N>1: skip the extra measurement of the per-step RCCL all-gather of (obs,reward,done) (configs[2])")
     ap.add_argument("--sweep", action="store_true", help="add a worlds-per-GPU saturation sweep to the JSON line")
     ap.add_argument("--full-loop", action="store_true",
                     help="also time BASELINE configs[4]: batched env + NetworkVP_rnn policy + rollout bookkeeping + Adam steps")
@@ -231,24 +232,39 @@ def main() -> None:
         pass
 
     extra = {}
-    if args.gather and world_size > 1:
-        width = env.obs_width
-        packed = torch.empty((W, N, width + 2), dtype=torch.float32, device=device)
-        out = torch.empty((world_size * W, N, width + 2), dtype=torch.float32, device=device)
-        def gather_once():
-            packed[..., :width] = env.obs
-            packed[..., width] = env.rewards
-            packed[..., width + 1] = env.done
-            dist.all_gather_into_tensor(out, packed)
-        for _ in range(20):
-            gather_once()
-        sync_all()
-        tg = time.perf_counter()
-        for _ in range(200):
-            gather_once()
-        sync_all()
-        extra["allgather_ms_per_step"] = (time.perf_counter() - tg) * 1e3 / 200
-        extra["allgather_bytes_per_rank"] = packed.numel() * 4
+    if world_size > 1 and args.backend == "nccl" and not args.no_gather:
+        # BASELINE configs[2]: the one real exchange of the path -- (obs | reward | done) of every world back to
+        # every rank in ONE packed RCCL all-gather per step.  Timed OUTSIDE the headline region (the headline is
+        # the sharded step with no data-path collective); a failure here must not cost the headline number.
+        try:
+            from rl_collision_avoidance_amd.sharding import pack_step_outputs
+            width = env.obs_width
+            packed = torch.empty((W, N, width + 2), dtype=torch.float32, device=device)
+            out = torch.empty((world_size * W, N, width + 2), dtype=torch.float32, device=device)
+
+            def gather_once(step_too):
+                if step_too:
+                    env.step_autoreset(acts[0])
+                pack_step_outputs(env.obs, env.rewards, env.done, packed)
+                dist.all_gather_into_tensor(out, packed)
+            for _ in range(20):
+                gather_once(True)
+            sync_all()
+            tg = time.perf_counter()
+            for _ in range(200):
+                gather_once(False)
+            sync_all()
+            t_gather = (time.perf_counter() - tg) / 200
+            tg = time.perf_counter()
+            for _ in range(200):
+                gather_once(True)
+            sync_all()
+            t_both = (time.perf_counter() - tg) / 200
+            extra["allgather"] = {"ms_per_step_pack_and_gather": t_gather * 1e3, "ms_per_step_with_env_step": t_both * 1e3,
+                                  "bytes_per_rank": packed.numel() * 4, "bytes_received_per_rank": out.numel() * 4,
+                                  "agent_steps_per_s_with_gather": world_size * W * N / t_both}
+        except Exception as exc:      # noqa: BLE001 -- report, never lose the headline
+            extra["allgather"] = {"error": repr(exc)}
 
     if args.full_loop:
         extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, Cfg(), device, W, N, rank, world_size, sync_all)
