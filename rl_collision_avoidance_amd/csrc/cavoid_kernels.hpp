@@ -54,6 +54,7 @@ struct KCfg {
     int32_t gen_min_agents, gen_max_agents;
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
+    int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
     const double *action_table;  // [num_actions][2]
@@ -283,12 +284,38 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, bool pr
     }
 }
 
-// E9: neighbour ordering by counting ranks + the lane's observation row into the LDS tile.
+// Coalesced write-out of the wave's obs tile: n_floats contiguous floats starting at dst.
+__device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_floats, int lane) {
+    if ((n_floats & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(tile);
+        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+        const int n4 = n_floats >> 2;
+        for (int k0 = lane; k0 < n4; k0 += 64 * 8) {       // 8 LDS reads in flight, then 8 stores
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u;
+                v[u] = k < n4 ? src4[k] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u;
+                if (k < n4) dst4[k] = v[u];
+            }
+        }
+    } else {
+        for (int k = lane; k < n_floats; k += 64) dst[k] = tile[k];
+    }
+}
+
+// E9: neighbour ordering by counting ranks, the lane's observation row into the LDS tile, and the
+// coalesced write-out.  The tile holds c.tile_rows rows; wide rows (large N) go out in several passes so
+// that the LDS footprint -- and with it the wavefronts resident per CU -- does not scale with N*(1+D).
 template <int N>
 __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
                                              const double *lds_vy, const float *lds_r, const double (&dist)[Others<N>::K],
-                                             uint32_t others, float *tile) {
+                                             uint32_t others, float *tile, float *obs_dst, int rows_active) {
     constexpr int K = Others<N>::K, NO = N - 1;
     const int M = c.max_other, width = c.width;
     const bool present = active && (a.flags & CAVOID_F_PRESENT);
@@ -363,8 +390,10 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
             }
     }
 
-    if (active) {
-        float *row = tile + lane * width;
+    const int rpp = c.tile_rows;                                 // rows per pass
+    for (int p0 = 0; p0 < rows_active; p0 += rpp) {
+    if (active && lane >= p0 && lane < p0 + rpp) {
+        float *row = tile + (lane - p0) * width;
         row[0] = (present && (a.flags & CAVOID_F_LEARNING)) ? 1.0f : 0.0f;
         row[1] = (float)kept;                                   // 0 for an absent agent (others == 0)
         row[2] = present ? (float)e.dist : 0.0f;
@@ -389,29 +418,10 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         }
         for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;   // unfilled slots
     }
-}
-
-// Coalesced write-out of the wave's obs tile: n_floats contiguous floats starting at dst.
-__device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_floats, int lane) {
-    if ((n_floats & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(tile);
-        float4 *dst4 = reinterpret_cast<float4 *>(dst);
-        const int n4 = n_floats >> 2;
-        for (int k0 = lane; k0 < n4; k0 += 64 * 8) {       // 8 LDS reads in flight, then 8 stores
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 64 * u;
-                v[u] = k < n4 ? src4[k] : float4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 64 * u;
-                if (k < n4) dst4[k] = v[u];
-            }
-        }
-    } else {
-        for (int k = lane; k < n_floats; k += 64) dst[k] = tile[k];
+    wave_lds_sync();
+    const int rows_here = rows_active - p0 < rpp ? rows_active - p0 : rpp;
+    flush_tile(tile, obs_dst + (int64_t)p0 * width, rows_here * width, lane);
+    if (p0 + rpp < rows_active) wave_lds_sync();                 // the next pass overwrites the tile
     }
 }
 
@@ -461,7 +471,7 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int width = c.width;
-    const int tile_floats = (G::kLanes * width + 3) & ~3;
+    const int tile_floats = (c.tile_rows * width + 3) & ~3;
     const int per_wave_floats = lds_floats_fixed() + tile_floats;
     float *wbase = reinterpret_cast<float *>(smem) + (size_t)wave_in_block * per_wave_floats;
     double *lds_px = reinterpret_cast<double *>(wbase);
@@ -516,7 +526,7 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     // the launch + memory floor the real kernel is measured against
     if (stepping) {
         if (use_table) lds_tab[lane] = tab_v;
-        if (active) {
+        if (active && lane < c.tile_rows) {
             float *row = tile + lane * width;
             for (int k = 0; k < width; ++k) row[k] = (float)a.px + (float)k + (float)act;
         }
@@ -674,12 +684,12 @@ __global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, 
     CAVOID_STAMP(5);                                        // rewards / restart done
     // ---- E9 observation: once per step, after the restart decision -----------------------------------
     if (io.obs) {
-        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, dist, others, tile);
-        wave_lds_sync();
-        CAVOID_STAMP(6);                                    // obs rows assembled in LDS
         int64_t worlds_here = c.num_worlds - w0;
         if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
-        if (worlds_here > 0) flush_tile(tile, io.obs + w0 * N * width, (int)worlds_here * N * width, lane);
+        if (worlds_here < 0) worlds_here = 0;
+        CAVOID_STAMP(6);
+        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, dist, others, tile,
+                        io.obs + w0 * N * width, (int)worlds_here * N);
     }
 
     CAVOID_STAMP(7);                                        // tile flushed
