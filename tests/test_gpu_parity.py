@@ -288,3 +288,55 @@ def test_errors_are_codes_not_crashes():
     env.step(torch.full((8, 4), 999, dtype=torch.int32, device="cuda"))
     assert torch.isfinite(env.obs).all()
     env.close(); h.close()
+
+
+def test_single_world_facade_and_environment_mirror_on_gpu():
+    """create_env() -> the VecEnv-of-one facade over a real 1-world GPU env, driven like ProcessAgent does
+    (BASELINE configs[0] plumbing), against the oracle stepping the same world."""
+    from rl_collision_avoidance_amd.env_utils import create_env, run_episode
+    from rl_collision_avoidance_amd.ga3c.environment import Environment
+    seed = 4000
+    game, one_env = create_env(seed=seed, gen_pool_size=0)
+    env = Environment(0, game=game)
+    ocfg, ogen = _oracle(4, None, 2, 0.0, pool=0)
+    st = co.State.empty(1, 4)
+    ep = np.zeros(1, np.uint32)
+    rng = np.random.default_rng(1)
+    for episode in range(3):
+        env.reset()
+        ep[0] = episode
+        co.generate(ocfg, ogen, seed, st, ep)
+        np.testing.assert_allclose(env.latest_observations, co.observe(ocfg, st)[0], rtol=0, atol=OBS_TOL)
+        assert env.previous_state is None or env.current_state.shape == (1, 4, 26)
+        over, t = False, 0
+        while not over:
+            acts = {i: int(rng.integers(0, 11)) for i in range(4) if env.latest_observations[i, 0]}
+            full = np.zeros((1, 4), np.int32)
+            for i, a in acts.items():
+                full[0, i] = a
+            rewards, over, info = env.step([acts], 0, t)
+            oobs, orew, odone, ogo = co.step(ocfg, st, full)
+            n = len(info[0]["which_agents_done"])
+            assert over == bool(ogo[0]) and [info[0]["which_agents_done"][i] for i in range(n)] == list(odone[0, :n].astype(bool))
+            np.testing.assert_allclose(rewards[0], orew[0, :n], rtol=0, atol=OBS_TOL)
+            d = np.abs(env.latest_observations - oobs[0])
+            d[:, 3] = np.minimum(d[:, 3], np.abs(d[:, 3] - 2 * np.pi))
+            assert d.max() <= OBS_TOL
+            assert env.current_state.shape == (1, 4, 26) and env.previous_state.shape == (1, 4, 26)
+            t += 1
+        assert t > 1
+    total, steps = run_episode(game, one_env)
+    assert steps > 0 and np.isfinite(total)
+    one_env.close()
+
+
+def test_seeding_is_reproducible_and_distinct():
+    a = _env(256, 4, seed=1)
+    b = _env(256, 4, seed=1)
+    c = _env(256, 4, seed=2)
+    oa, ob, oc = a.reset().clone(), b.reset().clone(), c.reset().clone()
+    assert torch.equal(oa, ob) and not torch.equal(oa, oc)
+    a.seed(2)                                   # re-seeding refills the scenario pool and restarts the episode counters
+    assert torch.equal(a.reset(), oc)
+    for e in (a, b, c):
+        e.close()
