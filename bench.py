@@ -266,6 +266,19 @@ def main() -> None:
         except Exception as exc:      # noqa: BLE001 -- report, never lose the headline
             extra["allgather"] = {"error": repr(exc)}
 
+    if rank == 0:
+        # transparency: the same step with NO scenario pool (every restart runs GEN v1 in-kernel, exact (world,
+        # episode) scenarios) -- the pool only moves scenario generation (E2) off the step's critical path
+        try:
+            e0 = BatchedCollisionAvoidanceEnv(W, Cfg(), device=device, world_offset=rank * W, seed=7, gen_pool_size=0)
+            e0.reset()
+            run_steps(e0, acts, 100)
+            k0 = e0.kernel_time_ms(acts, 300)
+            extra["no_scenario_pool"] = {"kernel_us": k0 * 1e3, "agent_steps_per_s": W * N / (k0 * 1e-3)}
+            e0.close()
+        except Exception as exc:      # noqa: BLE001
+            extra["no_scenario_pool"] = {"error": repr(exc)}
+
     if args.full_loop:
         extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, Cfg(), device, W, N, rank, world_size, sync_all)
 

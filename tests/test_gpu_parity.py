@@ -340,3 +340,48 @@ def test_seeding_is_reproducible_and_distinct():
     assert torch.equal(a.reset(), oc)
     for e in (a, b, c):
         e.close()
+
+
+def test_hip_path_reproduces_committed_env_golden():
+    """The committed fixture (oracle-generated regression anchor, see tests/golden/make_env_golden.py): flags, done
+    and game_over bit-exact, observations / rewards within 1e-5 (heading on the circle)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "env_golden.npz"))
+    for name in g["cases"]:
+        N, M, sort, gmin, W, steps, seed = [int(v) for v in g[name + "_cfg"]]
+        env = _env(W, N, M, sort_method=sort)
+        st = co.State(g[name + "_f64"].copy(), g[name + "_f32"].copy(), g[name + "_flags0"].copy())
+        _push(env, st)
+        for t in range(steps):
+            obs, rew, done, go = [x.cpu().numpy() for x in env.step(torch.from_numpy(g[name + "_actions"][t]).cuda())]
+            assert np.array_equal(done, g[name + "_done"][t]) and np.array_equal(go, g[name + "_over"][t]), (name, t)
+            assert np.array_equal(_pull(env)[2].reshape(W, N), g[name + "_flags"][t]), (name, t)
+            d = np.abs(obs.astype(np.float64) - g[name + "_obs"][t])
+            d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2 * np.pi))
+            assert d.max() <= OBS_TOL + 2e-6, (name, t, d.max())          # + float32 storage of the fixture
+            assert np.abs(rew - g[name + "_rew"][t]).max() <= OBS_TOL
+        env.close()
+
+
+def test_worlds_without_agents_and_single_agent_worlds():
+    """Edge shapes: an empty world (no agent present) and one-agent worlds inside a batch."""
+    W, N = 64, 4
+    env = _env(W, N, gen_min_agents=1)
+    env.reset()
+    f64, f32, fl = [x.clone() for x in env.get_state()]
+    fl = fl.view(W, N)
+    fl[0] = 0                                          # world 0: nobody
+    fl[1, 1:] = 0                                      # world 1: a single agent
+    env.set_state(f64, f32, fl.reshape(-1))
+    st = co.State(f64.cpu().numpy(), f32.cpu().numpy(), fl.reshape(-1).cpu().numpy().view(np.uint32))
+    ocfg, _ = _oracle(N)
+    obs0 = env.observe().cpu().numpy()
+    assert np.all(obs0[0] == 0) and obs0[1, 0, 1] == 0 and np.all(obs0[1, 1:] == 0)
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        acts = _goal_seeking_actions(rng, W, N)
+        out = env.step(torch.from_numpy(acts).cuda())
+        _compare_step(("edge", t), out, co.step(ocfg, st, acts), env, st)
+    obs, rew, done, go = [x.cpu().numpy() for x in out]
+    assert go[0] == 1 and np.all(done[0] == 1) and np.all(rew[0] == 0) and np.all(np.isfinite(obs))
+    env.close()

@@ -195,3 +195,21 @@ def test_worlds_are_independent_and_permutation_equivariant():
     o1, r1, d1, g1 = co.step(cfg, one, acts[w:w + 1, perm])
     assert np.array_equal(r1[0], rew[w][perm]) and np.array_equal(d1[0], done[w][perm])
     np.testing.assert_allclose(o1[0][:, :6], obs[w][perm][:, :6], rtol=0, atol=0)
+
+
+def test_c_oracle_reproduces_committed_env_golden():
+    """tests/golden/env_golden.npz was generated by the reference-STYLE Python oracle (parity unpinned: it is a
+    regression anchor, not a reference output).  The C oracle must reproduce it (obs/rewards are stored as
+    float32, flags exactly)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "env_golden.npz"))
+    for name in g["cases"]:
+        N, M, sort, gmin, W, steps, seed = [int(v) for v in g[name + "_cfg"]]
+        cfg = co.default_cfg(N, M, sort_method=sort)
+        st = co.State(g[name + "_f64"].copy(), g[name + "_f32"].copy(), g[name + "_flags0"].copy())
+        for t in range(steps):
+            obs, rew, done, go = co.step(cfg, st, g[name + "_actions"][t])
+            assert np.array_equal(obs.astype(np.float32), g[name + "_obs"][t]), (name, t)
+            assert np.array_equal(rew.astype(np.float32), g[name + "_rew"][t]), (name, t)
+            assert np.array_equal(done, g[name + "_done"][t]) and np.array_equal(go, g[name + "_over"][t])
+            assert np.array_equal(st.flags.reshape(W, N), g[name + "_flags"][t])
