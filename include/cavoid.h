@@ -160,10 +160,10 @@ int cavoid_step_autoreset_n_timed(cavoid_env *env, const int32_t *actions, int64
  * convert_to_nparray (ga3c/GA3C/ProcessAgent.py:54-87,105-211) and the training_q / episode_log_q
  * puts (:238,243).  cavoid_rollout_push records one env step for every learning (world, agent) slot
  * in a caller-owned TIME-MAJOR experience store of `ring_len` step blocks (block = step % ring_len):
- *   x float [ring_len,W*N,D] (state the policy acted on), val double [ring_len,W*N] (reward -> n-step
- *   return, working value), ret float [ring_len,W*N] (y_r the row was emitted with), act u8, valid u8
- *   (1 = a training row), emit_t int32 (step of emission).  A block is final once it is older than
- *   time_max + 1 steps; the caller compacts `valid` rows of final blocks into (x, y_r, action) batches
+ *   x float [ring_len,W*N,D] (state the policy acted on), val double [ring_len,W*N] (the step's reward),
+ *   ret float [ring_len,W*N] (n-step return y_r the row was emitted with), act u8, emit_t int32 (-1 = pending
+ *   or nothing recorded, >= 0 = a training row, emitted at that step).  A block is final once it is older than
+ *   time_max + 1 steps; the caller compacts the emit_t >= 0 rows of final blocks into (x, y_r, action) batches
  *   (the trainer's one-hot is eye(num_actions)[act]).
  *   prev_obs float [W,N,1+D] = the observation the policy acted on (Environment.previous_state plus col 0),
  *   actions int32 [W,N], values float [W,N] (V(s_t)), rewards/done/game_over = what the step returned.
@@ -179,7 +179,7 @@ void cavoid_rollout_destroy(cavoid_rollout *r);
 int cavoid_rollout_reset(cavoid_rollout *r, void *stream);
 int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t *actions, const float *values,
                         const float *rewards, const uint8_t *done, const uint8_t *game_over, int32_t step,
-                        float *x, double *val, float *ret, uint8_t *act, uint8_t *valid, int32_t *emit_t,
+                        float *x, double *val, float *ret, uint8_t *act, int32_t *emit_t,
                         float *dup_x, float *dup_r, int32_t *dup_a, int32_t *dup_src, int32_t *dup_count, int64_t dup_capacity,
                         float *ep_out, int32_t *ep_count, int64_t ep_capacity, void *stream);
 

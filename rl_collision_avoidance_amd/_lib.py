@@ -76,7 +76,7 @@ SYMBOLS = [
     ("cavoid_rollout_create", C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int, C.POINTER(_P)]),
     ("cavoid_rollout_destroy", None, [_P]),
     ("cavoid_rollout_reset", C.c_int, [_P, _P]),
-    ("cavoid_rollout_push", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32] + [_P] * 11 + [C.c_int64, _P, _P, C.c_int64, _P]),
+    ("cavoid_rollout_push", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32] + [_P] * 10 + [C.c_int64, _P, _P, C.c_int64, _P]),
     ("cavoid_timer_begin", C.c_int, [_P, _P]),
     ("cavoid_timer_end", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
 ]

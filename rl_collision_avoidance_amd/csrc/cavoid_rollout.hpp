@@ -5,13 +5,15 @@
 //
 // Layout: TIME-MAJOR experience store.  The training batch is a ring of `ring_len` step blocks
 //   x   float  [ring_len][slots][D]   state the policy acted on at that step (copied coalesced, once)
-//   val double [ring_len][slots]      single-step reward, overwritten by the n-step return at flush time (working value)
-//   ret float  [ring_len][slots]      the return the row was emitted with (y_r of the training row)
+//   val double [ring_len][slots]      single-step reward of the step
+//   ret float  [ring_len][slots]      the n-step return the row was emitted with (y_r of the training row)
 //   act u8     [ring_len][slots]      action index
-//   valid u8   [ring_len][slots]      0 = pending / nothing recorded, 1 = emitted (a training row)
-//   emit_t i32 [ring_len][slots]      provenance: step at which the row was emitted
+//   emit_t i32 [ring_len][slots]      -1 = pending / nothing recorded; >= 0 = a training row, emitted at that step
 // An experience is written where it will be trained from; a flush only walks the slot's <= T_max+1
-// pending returns (one coalesced load burst, the recurrence in registers, one store burst).  The
+// pending rewards (one load burst, the recurrence in registers, one store burst).  The reference
+// overwrites Experience.reward with the return in place; no overwritten value is ever read again
+// except the kept seed's, whose overwrite is the identity (bootstrap 0: R = 0*gamma + r), so the
+// store keeps raw rewards in `val` and the emitted returns in `ret`.  The
 // reference's "keep the last experience as the seed of the next chunk" costs nothing here: the
 // seed simply stays pending.  Closed blocks (older than T_max+1 steps) are compacted by the host.
 // Only the reference's post-done re-flush quirk produces rows that are not 1:1 with (step, slot);
@@ -60,7 +62,6 @@ struct RolloutIO {
     double *val;             // [ring_len][slots]
     float *ret;              // [ring_len][slots]
     uint8_t *act;            // [ring_len][slots]
-    uint8_t *valid;          // [ring_len][slots]
     int32_t *emit_t;         // [ring_len][slots]
     float *dup_x;            // [dup_capacity][D]   re-flushed duplicates (reference quirk only)
     float *dup_r;            // [dup_capacity]
@@ -90,6 +91,7 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
         int64_t rows = slots - a0;
         rows = rows > 64 ? 64 : (rows < 0 ? 0 : rows);
         const int total = (int)rows * D;
+        const uint32_t inv_d = (uint32_t)((1ull << 32) / (uint32_t)D) + 1u;   // idx / D by multiply-shift (idx < 2^16)
         const float *src = io.prev_obs + a0 * c.obs_width;
         float *dst = io.x + ((int64_t)blk * slots + a0) * D;
         for (int i0 = lane; i0 < total; i0 += 64 * 8) {          // 8 loads in flight per lane, then 8 stores
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int idx = i0 + 64 * u;
-                const int r = idx / D, q = idx - r * D;
+                const int r = (int)(((uint64_t)(uint32_t)idx * inv_d) >> 32), q = idx - r * D;
                 v[u] = idx < total ? src[r * c.obs_width + 1 + q] : 0.f;
             }
 #pragma unroll
@@ -140,8 +142,7 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
         // ---- append (Experience(previous_state[0,i,:], action, prediction, reward, done), :172-177) ----
         io.val[cur] = (double)reward;
         io.act[cur] = (uint8_t)action;
-        io.valid[cur] = 0;                                   // pending (or: nothing recorded at this step)
-        io.emit_t[cur] = -1;
+        io.emit_t[cur] = -1;                                 // pending (or: nothing recorded at this step)
     }
     if (record) {
         score += (double)reward;
@@ -170,21 +171,21 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
         if (L <= kMaxRing) {
             // all pending rewards in flight at once, then the recurrence in registers
             double rr[kMaxRing];
+            const int b0 = (step - newest) % RL;                 // block of the oldest pending entry; k-th: b0 + k (mod RL)
 #pragma unroll
             for (int k = 0; k < kMaxRing; ++k) {
-                const int tk = step - newest + k;
-                rr[k] = (k < newest) ? io.val[(int64_t)(tk % RL) * slots + a] : (double)reward;
+                const int bk = b0 + k >= RL ? b0 + k - RL : b0 + k;
+                rr[k] = (k < newest) ? io.val[(int64_t)bk * slots + a] : (double)reward;
             }
 #pragma unroll
             for (int k = kMaxRing - 1; k >= 0; --k)
                 if (k < count) { R = c.discount * R + rr[k]; rr[k] = R; }
 #pragma unroll
             for (int k = 0; k < kMaxRing; ++k) {
-                const int tk = step - newest + k;
-                const int64_t e = (int64_t)(tk % RL) * slots + a;
-                if (k < count) io.val[e] = rr[k];
+                const int bk = b0 + k >= RL ? b0 + k - RL : b0 + k;
+                const int64_t e = (int64_t)bk * slots + a;
                 if (k < mine && !(dup0 && k == 0)) {            // convert_to_nparray (:82-87): the row goes live
-                    io.ret[e] = (float)rr[k]; io.valid[e] = 1; io.emit_t[e] = step;
+                    io.ret[e] = (float)rr[k]; io.emit_t[e] = step;
                 }
             }
             r0 = rr[0];
@@ -192,12 +193,12 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
             for (int k = count - 1; k >= 0; --k) {
                 const int64_t e = (int64_t)((step - newest + k) % RL) * slots + a;
                 R = c.discount * R + (k == newest ? (double)reward : io.val[e]);
-                io.val[e] = R;
                 if (k == 0) r0 = R;
+                if (!(dup0 && k == 0)) { io.ret[e] = (float)R; io.emit_t[e] = step; }
             }
-            for (int k = 0; k < mine; ++k) {
+            for (int k = count; k < mine; ++k) {                  // rows outside the pass keep their raw reward
                 const int64_t e = (int64_t)((step - newest + k) % RL) * slots + a;
-                if (!(dup0 && k == 0)) { io.ret[e] = (float)(k == newest && k >= count ? (double)reward : io.val[e]); io.valid[e] = 1; io.emit_t[e] = step; }
+                io.ret[e] = (float)(k == newest ? (double)reward : io.val[e]); io.emit_t[e] = step;
             }
         }
         if (dup0) {                                          // rare: one appended duplicate row

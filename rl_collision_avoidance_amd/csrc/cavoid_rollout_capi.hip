@@ -66,10 +66,10 @@ extern "C" int cavoid_rollout_reset(cavoid_rollout *r, void *stream) {
 
 extern "C" int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t *actions, const float *values,
                                    const float *rewards, const uint8_t *done, const uint8_t *game_over, int32_t step,
-                                   float *x, double *val, float *ret, uint8_t *act, uint8_t *valid, int32_t *emit_t,
+                                   float *x, double *val, float *ret, uint8_t *act, int32_t *emit_t,
                                    float *dup_x, float *dup_r, int32_t *dup_a, int32_t *dup_src, int32_t *dup_count,
                                    int64_t dup_capacity, float *ep_out, int32_t *ep_count, int64_t ep_capacity, void *stream) {
-    if (!r || !prev_obs || !actions || !values || !rewards || !done || !game_over || !x || !val || !ret || !act || !valid ||
+    if (!r || !prev_obs || !actions || !values || !rewards || !done || !game_over || !x || !val || !ret || !act ||
         !emit_t || !dup_x || !dup_r || !dup_a || !dup_src || !dup_count || !ep_out || !ep_count || dup_capacity < 1 || ep_capacity < 1)
         return CAVOID_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -77,7 +77,7 @@ extern "C" int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, con
     c.dup_capacity = dup_capacity; c.ep_capacity = ep_capacity;
     RolloutIO io{};
     io.prev_obs = prev_obs; io.actions = actions; io.values = values; io.rewards = rewards; io.done = done; io.game_over = game_over;
-    io.step = step; io.x = x; io.val = val; io.ret = ret; io.act = act; io.valid = valid; io.emit_t = emit_t;
+    io.step = step; io.x = x; io.val = val; io.ret = ret; io.act = act; io.emit_t = emit_t;
     io.dup_x = dup_x; io.dup_r = dup_r; io.dup_a = dup_a; io.dup_src = dup_src; io.dup_count = dup_count;
     io.ep_out = ep_out; io.ep_count = ep_count;
     const int64_t W = c.num_slots / c.max_agents;

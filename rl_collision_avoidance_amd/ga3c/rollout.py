@@ -7,7 +7,7 @@ puts of ``run`` (:233-243).  Nothing crosses a process boundary: the policy is c
 step on the whole ``[W*N, D]`` observation matrix (what 128-row ``ThreadPredictor`` batches
 approximate, ThreadPredictor.py:40-75), the env steps in one kernel launch, and a second kernel
 (csrc/cavoid_rollout.hpp) keeps a TIME-MAJOR experience store: step t's states, actions and
-(later) n-step returns live in block ``t % ring_len``; a row becomes a training row the moment
+(later) n-step returns live in block ``t % ring_len``; a row becomes a training row (emit_t >= 0) the moment
 the reference would have yielded it.  ``drain()`` compacts the final blocks into the shapes
 ``Server.train_model(x_, r_, a_)`` takes (Server.py:114-124; x [n, D], r [n], a one-hot f32
 [n, num_actions])."""
@@ -67,7 +67,6 @@ class BatchedRollout(object):
         self.val = torch.zeros((R, S), dtype=torch.float64, device=dev)
         self.ret = torch.zeros((R, S), dtype=torch.float32, device=dev)
         self.act_ring = torch.zeros((R, S), dtype=torch.uint8, device=dev)
-        self.valid = torch.zeros((R, S), dtype=torch.uint8, device=dev)
         self.emit_t = torch.full((R, S), -1, dtype=torch.int32, device=dev)
         self.dup_x = torch.empty((self.dup_capacity, D), dtype=torch.float32, device=dev)
         self.dup_r = torch.empty((self.dup_capacity,), dtype=torch.float32, device=dev)
@@ -112,7 +111,7 @@ class BatchedRollout(object):
         self._cur = 0
         self.env.reset()
         _lib.check(self._lib.cavoid_rollout_reset(self._h, self.env._stream()), "cavoid_rollout_reset")
-        self.valid.zero_()
+        self.emit_t.fill_(-1)
         self.dup_count.zero_()
         self.ep_count.zero_()
         self.step_index = 0
@@ -143,7 +142,7 @@ class BatchedRollout(object):
         p = BatchedCollisionAvoidanceEnv._ptr
         _lib.check(self._lib.cavoid_rollout_push(
             self._h, p(obs), p(actions), p(values), p(rew), p(done), p(game_over), -1,      # -1: device-side step counter
-            p(self.x), p(self.val), p(self.ret), p(self.act_ring), p(self.valid), p(self.emit_t),
+            p(self.x), p(self.val), p(self.ret), p(self.act_ring), p(self.emit_t),
             p(self.dup_x), p(self.dup_r), p(self.dup_a), p(self.dup_src), p(self.dup_count), self.dup_capacity,
             p(self.ep_out), p(self.ep_count), self.episode_capacity, env._stream()), "cavoid_rollout_push")
         self._cur = 1 - self._cur
@@ -204,7 +203,7 @@ class BatchedRollout(object):
         if hi > lo:
             steps = torch.arange(lo, hi, device=self.env.device)
             blocks = steps % self.ring_len
-            valid = self.valid[blocks] != 0                                  # [k, slots]
+            valid = self.emit_t[blocks] >= 0                                 # [k, slots]: emitted rows
             idx = valid.nonzero(as_tuple=False)                              # [n, 2] (block position, slot)
             b, sl = blocks[idx[:, 0]], idx[:, 1]
             xs.append(self.x[b, sl])
@@ -213,7 +212,7 @@ class BatchedRollout(object):
             srcs.append(torch.stack([(sl // N).to(torch.int32), (sl % N).to(torch.int32), steps[idx[:, 0]].to(torch.int32),
                                      self.emit_t[b, sl]], dim=1))
             if flush_all:
-                self.valid[b, sl] = 0                                        # do not hand these out twice
+                self.emit_t[b, sl] = -2                                      # do not hand these out twice
             self.drained_until = hi if not flush_all else self.drained_until
             if not flush_all:
                 self.drained_until = hi
