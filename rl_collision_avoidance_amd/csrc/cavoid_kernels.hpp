@@ -323,17 +323,19 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     // sort criteria: gap rounded to centimetres (rint(gap*100) is order-isomorphic to round(gap,2)),
     // then the lateral offset; its sign-preserving un-normalised form ry*tx - rx*ty orders the same;
     // full ties fall back to the agent index (what a stable sort does)
-    double gr[K], lat[K];
-    int jj[K];
+    int gr[K];                                                   // integer-valued: exact in int32 (|gap| < 2e7 m)
+    double lat[K];
     uint32_t valid = 0u;
-    gr[0] = lat[0] = 0.0; jj[0] = 0;
+    gr[0] = 0; lat[0] = 0.0;
+    // index tie-break without an index array: others run in ring order j = (i+1+o) mod N, so for p < q
+    // j_p < j_q unless the wrap (at o = N-1-i) falls between them
+    const int wrap_o = N - 1 - i;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-        jj[o] = other_index(i, o, N);
-        const int j = base + jj[o];
+        const int j = base + other_index(i, o, N);
         const double rj = (double)lds_r[j];
         const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
-        gr[o] = rint((dist[o] - ri - rj) * 100.0);
+        gr[o] = (int)rint((dist[o] - ri - rj) * 100.0);
         lat[o] = ry * e.tx - rx * e.ty;
         valid |= (((others >> o) & 1u) && !(dist[o] > c.horizon)) ? (1u << o) : 0u;
     }
@@ -348,15 +350,16 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         tti[0] = 0.0;
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
-            const int j = base + jj[o];
+            const int j = base + other_index(i, o, N);
             tti[o] = time_to_impact(lds_px[j] - a.px, lds_py[j] - a.py, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + (double)lds_r[j]);
         }
 #pragma unroll
         for (int p = 0; p < NO; ++p)           // far -> near: larger time first, then larger gap, then smaller lateral
 #pragma unroll
             for (int q = p + 1; q < NO; ++q) {
+                const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
                 const bool p_first = (tti[p] > tti[q]) ||
-                                     (tti[p] == tti[q] && (gr[p] > gr[q] || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && jj[p] < jj[q])))));
+                                     (tti[p] == tti[q] && (gr[p] > gr[q] || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && idx_lt)))));
                 pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
                 pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
             }
@@ -365,28 +368,29 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         for (int p = 0; p < NO; ++p)           // far -> near: larger gap first, then smaller lateral, then index
 #pragma unroll
             for (int q = p + 1; q < NO; ++q) {
-                const bool p_first = (gr[p] > gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && jj[p] < jj[q])));
+                const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
+                const bool p_first = (gr[p] > gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && idx_lt)));
                 pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
                 pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
             }
     }
     uint32_t keep = 0u;
-    int slot[K];
 #pragma unroll
     for (int o = 0; o < K; ++o) {
-        slot[o] = pos[o] - first;
         keep |= (((valid >> o) & 1u) && pos[o] >= first) ? (1u << o) : 0u;
+        pos[o] -= first;                                         // pos now IS the slot (closest_last / time_to_impact)
     }
     if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {      // kept set re-ranked near -> far; full ties keep index order
 #pragma unroll
-        for (int o = 0; o < K; ++o) slot[o] = 0;
+        for (int o = 0; o < K; ++o) pos[o] = 0;
 #pragma unroll
         for (int p = 0; p < NO; ++p)
 #pragma unroll
             for (int q = p + 1; q < NO; ++q) {
-                const bool p_first = (gr[p] < gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && jj[p] < jj[q])));
-                slot[q] += (p_first && ((keep >> p) & 1u)) ? 1 : 0;
-                slot[p] += (!p_first && ((keep >> q) & 1u)) ? 1 : 0;
+                const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
+                const bool p_first = (gr[p] < gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && idx_lt)));
+                pos[q] += (p_first && ((keep >> p) & 1u)) ? 1 : 0;
+                pos[p] += (!p_first && ((keep >> q) & 1u)) ? 1 : 0;
             }
     }
 
@@ -403,11 +407,11 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
             if (!((keep >> o) & 1u)) continue;
-            const int j = base + jj[o];
+            const int j = base + other_index(i, o, N);
             const double rj = (double)lds_r[j];
             const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
             const double ovx = lds_vx[j], ovy = lds_vy[j];
-            float *f = row + 6 + 7 * slot[o];
+            float *f = row + 6 + 7 * pos[o];
             f[0] = (float)(rx * e.prll_x + ry * e.prll_y);
             f[1] = (float)(ry * e.prll_x - rx * e.prll_y);
             f[2] = (float)(ovx * e.prll_x + ovy * e.prll_y);
@@ -466,7 +470,9 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const KState &pool, u
 enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESET = 3 };
 
 template <int N, int MODE>
-__global__ void __launch_bounds__(256) env_kernel(const KCfg c, const KState s, const KState pool, const KIO io) {
+// (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
+//  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
+__global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c, const KState s, const KState pool, const KIO io) {
     using G = Geometry<N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
