@@ -127,6 +127,7 @@ int32_t cavoid_obs_width(const cavoid_env *env);
 int cavoid_seed(cavoid_env *env, uint64_t seed, const uint32_t *episode, void *stream);
 int cavoid_get_episode(cavoid_env *env, uint32_t *episode_out, void *stream);
 
+/* the agents of a world must be packed: CAVOID_F_PRESENT rows first (indices 0..n-1), absent rows after */
 int cavoid_set_state(cavoid_env *env, const double *state_f64, const float *state_f32, const uint32_t *flags, void *stream);
 int cavoid_get_state(cavoid_env *env, double *state_f64, float *state_f32, uint32_t *flags, void *stream);
 

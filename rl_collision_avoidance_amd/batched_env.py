@@ -168,6 +168,20 @@ class BatchedCollisionAvoidanceEnv(object):
                    "cavoid_get_state")
         return f64, f32, fl
 
+    def state_dict(self) -> dict:
+        """Everything needed to resume this env bit-for-bit (the reference never checkpoints env state,
+        SURVEY.md section 5; here it is three tensors + the episode counters + the seed)."""
+        f64, f32, flags = self.get_state()
+        return {"state_f64": f64, "state_f32": f32, "flags": flags, "episode": self.episode, "seed": self._seed,
+                "num_worlds": self.num_worlds, "max_agents": self.max_agents, "world_offset": self.world_offset}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if (sd["num_worlds"], sd["max_agents"]) != (self.num_worlds, self.max_agents):
+            raise ValueError("checkpoint is for %dx%d worlds x agents, env is %dx%d"
+                             % (sd["num_worlds"], sd["max_agents"], self.num_worlds, self.max_agents))
+        self.seed(sd["seed"], sd["episode"].to(self.device))
+        self.set_state(sd["state_f64"].to(self.device), sd["state_f32"].to(self.device), sd["flags"].to(self.device))
+
     # -- the gym-style surface ---------------------------------------------------------------------
     def reset(self, world_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Start the next episode in the masked worlds (all if None); returns obs [W,N,1+D]."""

@@ -385,3 +385,24 @@ def test_worlds_without_agents_and_single_agent_worlds():
     obs, rew, done, go = [x.cpu().numpy() for x in out]
     assert go[0] == 1 and np.all(done[0] == 1) and np.all(rew[0] == 0) and np.all(np.isfinite(obs))
     env.close()
+
+
+def test_checkpoint_resume_is_bit_exact():
+    """state_dict() mid-run -> a fresh env continues with identical observations, rewards and restarts."""
+    W, N, seed = 700, 4, 77
+    rng = np.random.default_rng(0)
+    acts = torch.from_numpy(rng.integers(0, 11, size=(120, W, N)).astype(np.int32)).cuda()
+    a = _env(W, N, seed=seed)
+    a.reset()
+    for t in range(60):
+        a.step_autoreset(acts[t])
+    sd = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in a.state_dict().items()}      # as if written to disk
+    b = _env(W, N, seed=123)                     # different seed on purpose: the checkpoint carries its own
+    b.load_state_dict(sd)
+    assert torch.equal(b.observe(), a.obs)
+    for t in range(60, 120):
+        oa, ra, da, ga = a.step_autoreset(acts[t])
+        ob, rb, db, gb = b.step_autoreset(acts[t])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ga, gb)
+    assert torch.equal(a.episode, b.episode) and a.episode.max().item() >= 1
+    a.close(); b.close()
