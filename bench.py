@@ -56,6 +56,27 @@ def cpu_baseline(N: int, W: int, budget_s: float, pool_size: int):
                       % (N, W, n, dt)}
 
 
+def cpu_baseline_all_cores(N: int, W: int, budget_s: float, pool_size: int, max_procs: int = 64):
+    """the same C oracle on many host cores at once (one process per core, the worlds split
+    evenly -- how the reference scales: one env per ProcessAgent process, ProcessAgent.py:221).  Plain
+    subprocesses (`bench.py --cpu-worker ...`): nothing is forked from the process that holds the HIP context."""
+    import subprocess
+    procs = max(1, min(max_procs, os.cpu_count() or 1))
+    per = max(1, W // procs)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(N), str(per), str(budget_s), str(pool_size)]
+    children = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
+    vals = []
+    deadline = time.time() + budget_s + 90.0
+    for ch in children:
+        try:
+            out, _ = ch.communicate(timeout=max(1.0, deadline - time.time()))
+            vals.append(float(out.strip().splitlines()[-1]))
+        except Exception:      # noqa: BLE001 -- a straggler must not cost the headline
+            ch.kill()
+    return {"value": float(sum(vals)), "unit": "agent-steps/s", "cores": len(vals), "kind": "port",
+            "sample": "C float64 oracle, %d processes x %d worlds x %d agents, %.1f s each" % (len(vals), per, N, budget_s)}
+
+
 def python_baseline(N: int, budget_s: float):
     """Reference-style per-object Python/NumPy oracle, one world, one process (baseline B1)."""
     import numpy as np
@@ -117,6 +138,9 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
 
 
 def main() -> None:
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":        # child of cpu_baseline_all_cores: no torch, no GPU
+        print(cpu_baseline(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]))["value"])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -311,6 +335,10 @@ def main() -> None:
         line["cpu_baseline"] = cpu_baseline(N, W, args.cpu_seconds, int(env.cfg.gen_pool_size))
         line["cpu_baseline"]["host_cpus"] = os.cpu_count()
         extra["python_reference_style_baseline"] = python_baseline(N, min(3.0, args.cpu_seconds))
+        try:
+            extra["cpu_baseline_all_cores"] = cpu_baseline_all_cores(N, W, min(4.0, args.cpu_seconds), int(env.cfg.gen_pool_size))
+        except Exception as exc:      # noqa: BLE001
+            extra["cpu_baseline_all_cores"] = {"error": repr(exc)}
     if extra:
         line["extra"] = extra
     env.close()
