@@ -81,7 +81,7 @@ typedef struct cavoid_cfg {
     int32_t actions_fp32;      /* joint action array is float32 (default 1) */
     int32_t timeout_enabled;   /* default 1 */
     int32_t num_actions;       /* NUM_ACTIONS (Config.py:79) */
-    int32_t _pad;
+    int32_t evaluate_mode;     /* 0 (TRAIN_MODE): game over when every LEARNING agent is done; 1 (EVALUATE_MODE): every agent */
     double dt;                 /* DT 0.2 */
     double near_goal_threshold;/* 0.2 */
     double max_time_ratio;     /* 2.0 */

@@ -24,7 +24,7 @@ class OracleCfg(C.Structure):
         "reward_at_goal", "reward_collision", "reward_getting_close", "reward_time_step",
         "sensing_horizon", "close_penalty_slope", "max_turn_rate", "reward_clip_lo", "reward_clip_hi")] + [
         (n, C.c_int32) for n in ("max_agents", "max_other", "sort_method", "actions_fp32",
-                                 "timeout_enabled", "dynamics", "num_actions", "_pad")] + [
+                                 "timeout_enabled", "dynamics", "num_actions", "evaluate_mode")] + [
         ("actions", (C.c_double * 2) * MAX_ACTIONS)]
 
 

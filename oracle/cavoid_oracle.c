@@ -245,7 +245,7 @@ static void step_world(const oracle_cfg *c, agent_t *ag, int n, const int32_t *a
     int all_done = 1;
     for (int i = 0; i < n; ++i) {
         done[i] = (ag[i].flags & F_DONE_MASK) ? 1 : 0;
-        if ((ag[i].flags & F_LEARNING) && !done[i]) all_done = 0;
+        if (((ag[i].flags & F_LEARNING) || c->evaluate_mode) && !done[i]) all_done = 0;
     }
     *game_over = (uint8_t)all_done;
 }

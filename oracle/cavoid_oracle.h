@@ -23,7 +23,7 @@ typedef struct oracle_cfg {
     int32_t timeout_enabled;
     int32_t dynamics;          /* 0 unicycle, 1 unicycle max-turn-rate, 2 holonomic */
     int32_t num_actions;
-    int32_t _pad;
+    int32_t evaluate_mode;     /* game over when EVERY agent is done (EVALUATE_MODE) instead of every learning agent */
     double actions[ORACLE_MAX_ACTIONS][2];
 } oracle_cfg;
 

@@ -94,6 +94,7 @@ class OracleConfig:
     timeout_enabled: bool = True         # U1
     dynamics: int = DYN_UNICYCLE         # U3
     max_turn_rate: float = 3.0           # rad/s, only DYN_UNICYCLE_MAX_TURN
+    evaluate_mode: bool = False          # EVALUATE_MODE: the episode ends when EVERY agent is done
     # min/max of the env's list of possible reward values; rewards are clipped into it
     reward_clip_lo: float = -0.25
     reward_clip_hi: float = 1.0
@@ -287,8 +288,8 @@ class World:
         obs = self.observe()
         done = {i: ag.is_done for i, ag in enumerate(self.agents)}
         learning = {i: ag.is_learning for i, ag in enumerate(self.agents)}
-        learners = [ag.is_done for ag in self.agents if ag.is_learning]
-        game_over = bool(np.all(learners))       # TRAIN_MODE: every *learning* agent done
+        learners = [ag.is_done for ag in self.agents if ag.is_learning or cfg.evaluate_mode]
+        game_over = bool(np.all(learners))       # TRAIN_MODE: every *learning* agent done (EVALUATE_MODE: every agent)
         return obs, rewards, game_over, {"which_agents_done": done, "which_agents_learning": learning}
 
     # -- E6: pairwise gaps / collisions ----------------------------------------------------------

@@ -27,7 +27,7 @@ class CavoidCfg(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
         ("max_agents", C.c_int32), ("max_other", C.c_int32), ("sort_method", C.c_int32), ("dynamics", C.c_int32),
-        ("actions_fp32", C.c_int32), ("timeout_enabled", C.c_int32), ("num_actions", C.c_int32), ("_pad", C.c_int32),
+        ("actions_fp32", C.c_int32), ("timeout_enabled", C.c_int32), ("num_actions", C.c_int32), ("evaluate_mode", C.c_int32),
         ("dt", C.c_double), ("near_goal_threshold", C.c_double), ("max_time_ratio", C.c_double),
         ("collision_dist", C.c_double), ("getting_close_range", C.c_double), ("reward_at_goal", C.c_double),
         ("reward_collision", C.c_double), ("reward_getting_close", C.c_double), ("reward_time_step", C.c_double),

@@ -44,6 +44,7 @@ def make_cfg(config: Optional[EnvConfig] = None, **overrides) -> _lib.CavoidCfg:
     cfg.reward_collision = config.REWARD_COLLISION_WITH_AGENT
     cfg.reward_getting_close = config.REWARD_GETTING_CLOSE
     cfg.reward_time_step = config.REWARD_TIME_STEP
+    cfg.evaluate_mode = 1 if getattr(config, "EVALUATE_MODE", False) else 0
     possible = [config.REWARD_AT_GOAL, config.REWARD_COLLISION_WITH_AGENT, config.REWARD_TIME_STEP,
                 config.REWARD_COLLISION_WITH_WALL, config.REWARD_WIGGLY_BEHAVIOR]
     cfg.reward_clip_lo, cfg.reward_clip_hi = min(possible), max(possible)

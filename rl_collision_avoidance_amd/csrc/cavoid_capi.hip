@@ -199,6 +199,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
     k.gen_min_agents = cfg->gen_min_agents; k.gen_max_agents = cfg->gen_max_agents;
     k.pool_size = cfg->gen_pool_size;
+    k.evaluate_mode = cfg->evaluate_mode ? 1 : 0;
     // latency mode: with at most ~2 wavefronts per SIMD the step is latency bound and every lane
     // pre-loads its next pool entry (+52 B read per agent-step) to keep a restart off a second
     // dependent trip to memory; larger batches are bandwidth bound and gather on demand

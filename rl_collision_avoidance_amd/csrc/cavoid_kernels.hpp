@@ -55,6 +55,7 @@ struct KCfg {
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
+    int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
     const double *action_table;  // [num_actions][2]
@@ -656,7 +657,7 @@ __global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c
             done = (a.flags & CAVOID_F_DONE_MASK) != 0u;
         }
         // game over <=> no learning agent of the world is still running
-        const unsigned long long running = __ballot(present && (a.flags & CAVOID_F_LEARNING) && !done);
+        const unsigned long long running = __ballot(present && ((a.flags & CAVOID_F_LEARNING) || c.evaluate_mode) && !done);
         const unsigned long long wmask = ((1ull << N) - 1ull) << base;
         const bool game_over = (running & wmask) == 0ull;
         if (active) {

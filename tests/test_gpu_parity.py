@@ -406,3 +406,25 @@ def test_checkpoint_resume_is_bit_exact():
         assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ga, gb)
     assert torch.equal(a.episode, b.episode) and a.episode.max().item() >= 1
     a.close(); b.close()
+
+
+def test_evaluate_mode_game_over_needs_every_agent():
+    """EVALUATE_MODE: the episode ends when EVERY agent is done, not only the learning ones."""
+    W, N, steps, seed = 300, 4, 120, 6
+    ocfg, ogen = _oracle(N, None, 2, 0.6, evaluate_mode=1)
+    env = _env(W, N, seed=seed, evaluate_mode=1)
+    st = co.State.empty(W, N)
+    co.generate(ocfg, ogen, seed, st, np.zeros(W, np.uint32))
+    _push(env, st)
+    rng = np.random.default_rng(seed)
+    train_cfg, _ = _oracle(N, None, 2, 0.6)
+    differs = False
+    for t in range(steps):
+        acts = _goal_seeking_actions(rng, W, N)
+        shadow = st.copy()
+        out = env.step(torch.from_numpy(acts).cuda())
+        ora = co.step(ocfg, st, acts)
+        _compare_step(("eval", t), out, ora, env, st)
+        differs |= bool((co.step(train_cfg, shadow, acts)[3] != ora[3]).any())
+    assert differs          # the two rules really disagree on this workload (scripted agents outlive the learners)
+    env.close()
