@@ -428,3 +428,40 @@ def test_evaluate_mode_game_over_needs_every_agent():
         differs |= bool((co.step(train_cfg, shadow, acts)[3] != ora[3]).any())
     assert differs          # the two rules really disagree on this workload (scripted agents outlive the learners)
     env.close()
+
+
+def test_baseline_config0_two_agent_single_world_1000_steps():
+    """BASELINE configs[0]: 2-agent single world, 1000 steps of plumbing through create_env()'s facade, checked
+    against the oracle stepping the same world (episodes restart through reset(), as ProcessAgent does)."""
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.env_utils import create_env
+
+    class TwoAgents(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = 2
+            EnvConfig.__init__(self)
+    seed = 12000
+    game, one_env = create_env(TwoAgents(), seed=seed, gen_pool_size=0, gen_min_agents=2)
+    ocfg, ogen = _oracle(2, None, 2, 0.0, pool=0)
+    st = co.State.empty(1, 2)
+    ep = np.zeros(1, np.uint32)
+    rng = np.random.default_rng(3)
+    steps, episode = 0, 0
+    while steps < 1000:
+        obs = game.reset()[0]
+        ep[0] = episode
+        co.generate(ocfg, ogen, seed, st, ep)
+        assert obs.shape == (2, 13)
+        over = False
+        while not over and steps < 1000:
+            acts = {i: (2 if rng.random() < 0.7 else int(rng.integers(0, 11))) for i in range(2)}
+            o, r, over, info = game.step([acts])
+            oo, orew, odone, ogo = co.step(ocfg, st, np.array([[acts[0], acts[1]]], np.int32))
+            assert over == bool(ogo[0]) and [info[0]["which_agents_done"][i] for i in range(2)] == list(odone[0].astype(bool))
+            d = np.abs(o[0] - oo[0])
+            d[:, 3] = np.minimum(d[:, 3], np.abs(d[:, 3] - 2 * np.pi))
+            assert d.max() <= OBS_TOL and np.abs(r[0] - orew[0]).max() <= OBS_TOL
+            steps += 1
+        episode += 1
+    assert episode >= 5
+    one_env.close()
