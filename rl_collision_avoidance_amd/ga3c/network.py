@@ -28,6 +28,7 @@ from torch import nn
 
 TF_VARIABLE_NAMES = {
     "lstm_kernel": "rnn/lstm_cell/kernel:0", "lstm_bias": "rnn/lstm_cell/bias:0",
+    "other_kernel": "other_agent_layer1/kernel:0", "other_bias": "other_agent_layer1/bias:0",
     "layer1_kernel": "layer1/kernel:0", "layer1_bias": "layer1/bias:0",
     "layer2_kernel": "layer2/kernel:0", "layer2_bias": "layer2/bias:0",
     "fc1_kernel": "fullyconnected1/kernel:0", "fc1_bias": "fullyconnected1/bias:0",
@@ -44,8 +45,16 @@ def _glorot(shape, gen) -> torch.Tensor:
 class NetworkVP_rnn(nn.Module):
     HOST, OTHER, HIDDEN, WIDTH = 4, 7, 64, 256
 
-    def __init__(self, config, num_actions: Optional[int] = None, seed: int = 0):
+    def __init__(self, config, num_actions: Optional[int] = None, seed: int = 0, arch: Optional[str] = None):
         super().__init__()
+        # MULTI_AGENT_ARCH (Config.py:43-49): 'rnn' (LSTM over the others) or 'weight_sharing' (one shared dense filter
+        # per observed agent, NetworkVP_rnn.py:69-92)
+        if arch is None:
+            ws = getattr(config, "MULTI_AGENT_ARCH_WEIGHT_SHARING", None)
+            arch = "weight_sharing" if ws is not None and getattr(config, "MULTI_AGENT_ARCH", None) == ws else "rnn"
+        if arch not in ("rnn", "weight_sharing"):
+            raise ValueError("arch must be 'rnn' or 'weight_sharing'")
+        self.arch = arch
         self.num_actions = int(num_actions if num_actions is not None else getattr(config, "NUM_ACTIONS", 11))
         self.max_others = int(config.MAX_NUM_OTHER_AGENTS_OBSERVED)
         self.input_size = 1 + self.HOST + self.OTHER * self.max_others
@@ -64,9 +73,15 @@ class NetworkVP_rnn(nn.Module):
         # TF gate order (i, j, f, o) -> ATen fused-cell order (i, f, g, o)
         self.register_buffer("gate_perm", torch.cat([torch.arange(0, H), torch.arange(2 * H, 3 * H), torch.arange(H, 2 * H),
                                                      torch.arange(3 * H, 4 * H)]), persistent=False)
-        self.lstm_kernel = nn.Parameter(_glorot((self.OTHER + H, 4 * H), g))
-        self.lstm_bias = nn.Parameter(torch.zeros(4 * H))
-        self.layer1_kernel = nn.Parameter(_glorot((self.HOST + H, Wd), g)); self.layer1_bias = nn.Parameter(torch.zeros(Wd))
+        if self.arch == "rnn":
+            self.lstm_kernel = nn.Parameter(_glorot((self.OTHER + H, 4 * H), g))
+            self.lstm_bias = nn.Parameter(torch.zeros(4 * H))
+            summary = H
+        else:
+            self.other_kernel = nn.Parameter(_glorot((self.OTHER + 1, H), g))       # 'other_agent_layer1', shared by all slots
+            self.other_bias = nn.Parameter(torch.zeros(H))
+            summary = H * self.max_others
+        self.layer1_kernel = nn.Parameter(_glorot((self.HOST + summary, Wd), g)); self.layer1_bias = nn.Parameter(torch.zeros(Wd))
         self.layer2_kernel = nn.Parameter(_glorot((Wd, Wd), g)); self.layer2_bias = nn.Parameter(torch.zeros(Wd))
         self.fc1_kernel = nn.Parameter(_glorot((Wd, Wd), g)); self.fc1_bias = nn.Parameter(torch.zeros(Wd))
         self.v_kernel = nn.Parameter(_glorot((Wd, 1), g)); self.v_bias = nn.Parameter(torch.zeros(1))
@@ -89,6 +104,15 @@ class NetworkVP_rnn(nn.Module):
             h = torch.where(live, h_new, h)
         return h
 
+    def _weight_sharing_summary(self, others: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """NetworkVP_rnn.py:69-92: every observed-agent slot goes through the SAME dense(8 -> 64, relu) filter
+        (its 7 features + an 'is this slot filled' flag); the M outputs are concatenated."""
+        B, M = others.shape[0], self.max_others
+        slot = torch.arange(1, M + 1, device=others.device, dtype=lengths.dtype)
+        is_on = (lengths.unsqueeze(1) >= slot).to(others.dtype).unsqueeze(2)              # [B, M, 1]
+        inp = torch.cat([others, is_on], dim=2).reshape(B * M, self.OTHER + 1)
+        return torch.relu(torch.addmm(self.other_bias, inp, self.other_kernel)).reshape(B, M * self.HIDDEN)
+
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """x [B, NN_INPUT_SIZE] -> (logits_p [B, A], softmax_p [B, A], v [B])"""
         x = x.to(torch.float32)
@@ -96,7 +120,7 @@ class NetworkVP_rnn(nn.Module):
         lengths = x[:, 0]
         host = xn[:, 1:1 + self.HOST]
         others = xn[:, 1 + self.HOST:].reshape(-1, self.max_others, self.OTHER)
-        h = self._lstm_final_h(others, lengths)
+        h = self._lstm_final_h(others, lengths) if self.arch == "rnn" else self._weight_sharing_summary(others, lengths)
         z = torch.relu(torch.addmm(self.layer1_bias, torch.cat([host, h], dim=1), self.layer1_kernel))
         z = torch.relu(torch.addmm(self.layer2_bias, z, self.layer2_kernel))
         z = torch.relu(torch.addmm(self.fc1_bias, z, self.fc1_kernel))
@@ -135,7 +159,7 @@ class NetworkVP_rnn(nn.Module):
         xn = (x - self.avg) / self.std if self.normalize else x
         host = xn[:, 1:1 + self.HOST]
         others = xn[:, 1 + self.HOST:].reshape(-1, self.max_others, self.OTHER)
-        h = self._lstm_final_h_fused(others, x[:, 0])
+        h = self._lstm_final_h_fused(others, x[:, 0]) if self.arch == "rnn" else self._weight_sharing_summary(others, x[:, 0])
         z = torch.relu_(torch.addmm(self.layer1_bias, torch.cat([host, h], dim=1), self.layer1_kernel))
         z = torch.relu_(torch.addmm(self.layer2_bias, z, self.layer2_kernel))
         z = torch.relu_(torch.addmm(self.fc1_bias, z, self.fc1_kernel))

@@ -28,7 +28,7 @@ def test_shapes_and_normalisation_vectors():
     avg, std = input_normalisation(cfg)
     assert len(avg) == 26 and len(std) == 26 and avg[0] == 1.0 and std[1] == 5.0
     net = NetworkVP_rnn(cfg)
-    assert set(TF_VARIABLE_NAMES) == {n for n, _ in net.named_parameters()}
+    assert {n for n, _ in net.named_parameters()} <= set(TF_VARIABLE_NAMES)
     logits, p, v = net(_batch(33, 3))
     assert logits.shape == (33, 11) and p.shape == (33, 11) and v.shape == (33,)
     assert torch.allclose(p.sum(1), torch.ones(33), atol=1e-6)
@@ -89,3 +89,31 @@ def test_episode_stats_rolling_window_and_line_format():
     line = st.line(0.0)
     assert re.match(r"\[Time: +\d+\] \[Episode: +4 Score: +0\.0000\] \[RScore: +0\.0833 RPPS: +\d+\] "
                     r"\[PPS: +\d+ TPS: +\d+\] \[NT: +1 NP: +1 NA: +0\]", line), line
+
+
+def test_weight_sharing_architecture():
+    """MULTI_AGENT_ARCH_WEIGHT_SHARING (NetworkVP_rnn.py:69-92): shared per-slot filter with an is-on flag."""
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = 4
+            self.MAX_NUM_OTHER_AGENTS_OBSERVED = 7          # Config.py:46-47
+            EnvConfig.__init__(self)
+    cfg = Cfg()
+    net = NetworkVP_rnn(cfg, seed=5, arch="weight_sharing")
+    assert net.input_size == 54 and net.layer1_kernel.shape == (4 + 7 * 64, 256) and net.other_kernel.shape == (8, 64)
+    x = _batch(16, 7, seed=9)
+    logits, p, v = net(x)
+    assert p.shape == (16, 11) and torch.allclose(p.sum(1), torch.ones(16), atol=1e-6)
+    # per-row reference of the summary
+    xn = (x - net.avg) / net.std
+    others = xn[:, 5:].reshape(16, 7, 7)
+    got = net._weight_sharing_summary(others, x[:, 0])
+    for row in range(16):
+        parts = []
+        for k in range(7):
+            on = 1.0 if x[row, 0] >= k + 1 else 0.0
+            parts.append(torch.relu(torch.cat([others[row, k], torch.tensor([on])]) @ net.other_kernel + net.other_bias))
+        assert torch.allclose(got[row], torch.cat(parts).detach(), atol=1e-6)
+    total, _, _ = net.loss(x, torch.randn(16), torch.nn.functional.one_hot(torch.randint(0, 11, (16,)), 11).float())
+    total.backward()
+    assert net.other_kernel.grad is not None
