@@ -69,7 +69,7 @@ def main(argv=None) -> None:
     while True:
         roll.replay(1)
         batch = roll.drain()
-        if len(batch) > 0:
+        if len(batch) > 0 or size > 1:            # multi-GPU: every rank must enter the gradient all-reduce
             n = min(len(batch), args.train_rows)
             trainer.train(batch.x[:n], batch.r[:n], batch.a[:n])
             stats.add_training_steps(1)
