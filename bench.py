@@ -290,7 +290,7 @@ def main() -> None:
         except Exception as exc:      # noqa: BLE001 -- report, never lose the headline
             extra["allgather"] = {"error": repr(exc)}
 
-    if rank == 0:
+    if rank == 0 and args.sweep:
         # transparency: the same step with NO scenario pool (every restart runs GEN v1 in-kernel, exact (world,
         # episode) scenarios) -- the pool only moves scenario generation (E2) off the step's critical path
         try:

@@ -23,7 +23,8 @@ struct cavoid_env {
     cavoid_cfg cfg{};
     KCfg k{};
     KState st{};
-    KState pool{};               // pre-generated scenarios (GEN v1 worlds 0..P-1, episode 0)
+    PoolRec *pool = nullptr;     // pre-generated scenarios (GEN v1 worlds 0..P-1, episode 0), 64-byte records
+    uint32_t *pool_episode = nullptr;   // [P] scratch episode counters for the fill launch
     int64_t pool_size = 0;
     void *slab = nullptr;
     void *pool_slab = nullptr;
@@ -165,11 +166,16 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     e->cfg = *cfg;
 
     const size_t W = (size_t)e->W;
-    size_t o_act = 0, o_unused = 0;
+    size_t o_act = 0;
     rc = alloc_state(W, (size_t)cfg->max_agents, CAVOID_MAX_ACTIONS * 2 * sizeof(double), &e->slab, &e->st, &o_act);
     if (rc == CAVOID_OK && cfg->gen_pool_size > 0) {
         e->pool_size = cfg->gen_pool_size;
-        rc = alloc_state((size_t)e->pool_size, (size_t)cfg->max_agents, 0, &e->pool_slab, &e->pool, &o_unused);
+        const size_t recs = (size_t)e->pool_size * (size_t)cfg->max_agents * sizeof(PoolRec);
+        if (hipMalloc(&e->pool_slab, recs + (size_t)e->pool_size * sizeof(uint32_t)) != hipSuccess) rc = CAVOID_ENOMEM;
+        else {
+            e->pool = static_cast<PoolRec *>(e->pool_slab);
+            e->pool_episode = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(e->pool_slab) + recs);
+        }
     }
     if (rc != CAVOID_OK) { g_last_hip_error = (int)hipGetLastError(); cavoid_destroy(e); return rc; }
     e->d_actions = reinterpret_cast<double *>(static_cast<unsigned char *>(e->slab) + o_act);
@@ -277,13 +283,16 @@ static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_sta
 // worlds 0..P-1, episode 0, generator in-kernel
 static int fill_pool(cavoid_env *e, hipStream_t s) {
     if (e->pool_size <= 0) return CAVOID_OK;
-    HIP_TRY(hipMemsetAsync(e->pool.episode, 0xFF, (size_t)e->pool_size * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(e->pool_episode, 0xFF, (size_t)e->pool_size * sizeof(uint32_t), s));
     KCfg k = e->k;
     k.num_worlds = e->pool_size;
     k.world_offset = 0;
     k.pool_size = 0;
+    KState st{};
+    st.episode = e->pool_episode;                              // the only world-buffer field the fill launch touches
     KIO io{};
-    return launch_on<MODE_RESET>(e, k, e->pool, grid_for(e, e->pool_size), io, s, nullptr, nullptr);
+    io.pool_out = e->pool;
+    return launch_on<MODE_RESET>(e, k, st, grid_for(e, e->pool_size), io, s, nullptr, nullptr);
 }
 
 extern "C" int cavoid_seed(cavoid_env *e, uint64_t seed, const uint32_t *episode, void *stream) {

@@ -68,7 +68,19 @@ struct KState {
     uint32_t *episode;  // [W]
 };
 
+// One pre-generated agent of the scenario pool: a 64-byte record, because the pool is only ever GATHERED
+// (one random entry per restarting world) -- an array-of-records costs one cache line per agent where the
+// field-major world buffer layout would cost one line per field.
+struct alignas(64) PoolRec {
+    double px, py, heading, t_rem;
+    float gx, gy, radius, pref;
+    uint32_t flags;
+    uint32_t pad[3];
+};
+static_assert(sizeof(PoolRec) == 64, "pool record must be one 64-byte line");
+
 struct KIO {
+    PoolRec *pool_out;       // MODE_RESET only: write the generated agents here (pool fill) instead of the world buffer
     const int32_t *actions;  // [W,N] or null
     const float *cont;       // [W,N,2] or null
     const uint8_t *mask;     // reset mask [W] or null
@@ -456,13 +468,19 @@ __device__ __forceinline__ uint32_t pool_index(const KCfg &c, uint32_t gw, uint3
 
 // Scenario of (global world gw, episode ep): a gather from the pre-generated pool (pool entry k is
 // GEN v1's world k, episode 0) or, with no pool, the generator itself.
+__device__ __forceinline__ void load_pool(const PoolRec *pool, int64_t k, Agent &a) {
+    const PoolRec r = pool[k];                                  // four 16-byte loads, one cache line
+    a.px = r.px; a.py = r.py; a.heading = r.heading; a.t_rem = r.t_rem;
+    a.gx = r.gx; a.gy = r.gy; a.radius = r.radius; a.pref = r.pref;
+    a.flags = r.flags;
+    a.vx = a.vy = 0.0;
+    a.speed = 0.0f;
+}
+
 template <int N>
-__device__ __forceinline__ void new_episode(const KCfg &c, const KState &pool, uint32_t gw, uint32_t ep, int i, Agent &a) {
+__device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, uint32_t gw, uint32_t ep, int i, Agent &a) {
     if (c.pool_size > 0) {
-        const int64_t k = (int64_t)pool_index(c, gw, ep) * N + i;
-        load_agent(pool, k, a);
-        a.vx = a.vy = 0.0;
-        a.speed = 0.0f;
+        load_pool(pool, (int64_t)pool_index(c, gw, ep) * N + i, a);
     } else {
         generate_agent<N>(c, gw, ep, i, a);
     }
@@ -473,7 +491,7 @@ enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESE
 template <int N, int MODE>
 // (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
 //  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
-__global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c, const KState s, const KState pool, const KIO io) {
+__global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     using G = Geometry<N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -555,9 +573,7 @@ __global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c
     Agent nxt = a;
     const bool prefetched = MODE == MODE_STEP_AUTORESET && c.prefetch_pool != 0 && c.pool_size > 0;
     if (prefetched && active) {
-        load_agent(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
-        nxt.vx = nxt.vy = 0.0;
-        nxt.speed = 0.0f;
+        load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
     }
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
@@ -714,7 +730,13 @@ __global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c
         }
     }
     if (MODE == MODE_RESET) {
-        if (fresh) {
+        if (fresh && io.pool_out) {                            // pool fill: one 64-byte record per agent
+            PoolRec r;
+            r.px = a.px; r.py = a.py; r.heading = a.heading; r.t_rem = a.t_rem;
+            r.gx = a.gx; r.gy = a.gy; r.radius = a.radius; r.pref = a.pref;
+            r.flags = a.flags; r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+            io.pool_out[a_idx] = r;
+        } else if (fresh) {
             store_agent(s, a_idx, a);
             if (i == 0) s.episode[w] = episode;
         }
