@@ -308,7 +308,7 @@ def main() -> None:
 
     if args.sweep and rank == 0:
         sweep = []
-        for Ws in (1024, 8192, 65536, 262144, 1048576):
+        for Ws in (1024, 8192, 65536, 262144, 1048576, 4194304):
             e2, a2 = make(Ws)
             run_steps(e2, a2, 50)
             k_ms = e2.kernel_time_ms(a2, 200)
