@@ -184,6 +184,43 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
                         float *dup_x, float *dup_r, int32_t *dup_a, int32_t *dup_src, int32_t *dup_count, int64_t dup_capacity,
                         float *ep_out, int32_t *ep_count, int64_t ep_capacity, void *stream);
 
+/* ---- fused policy inference (the actors' predict + select_action) ------------------------------------
+ * Stands in for `NetworkVPCore.predict_p_and_v(x)` (ga3c/GA3C/NetworkVPCore.py:175-176) on the graph
+ * `NetworkVP_rnn._create_graph` builds for MULTI_AGENT_ARCH 'RNN' (ga3c/GA3C/NetworkVP_rnn.py:50-67,103-105;
+ * NetworkVPCore.py:66-75) and, optionally, `ProcessAgent.select_action` (ga3c/GA3C/ProcessAgent.py:89-103),
+ * for every agent row of the batched env in ONE kernel on the matrix cores (float32 in, float32 accumulate).
+ *   cavoid_policy_load   : hand over the variables in the reference checkpoint's layout (device pointers; dense
+ *                          kernels [in,out], LSTM kernel [7+64, 4*64] in gate order i,j,f,o); they are re-packed
+ *                          into MFMA fragment order inside the handle.  Call again whenever the trainer has
+ *                          updated the weights.  avg/std = NN_INPUT_AVG_VECTOR / NN_INPUT_STD_VECTOR
+ *                          (Config.py:64-71), both NULL = NORMALIZE_INPUT off.
+ *   cavoid_policy_forward: x = first policy input (num_other_agents) of row 0, `row_stride` floats between
+ *                          rows -- pass `obs + 1, 1 + D` to run straight on the env's observation tensor.
+ *                          p_out float [rows, num_actions] (softmax_p incl. MIN_POLICY), v_out float [rows].
+ *                          actions_out (nullable) int32 [rows]: greedy != 0 -> argmax p (PLAY_MODE /
+ *                          EVALUATE_MODE), else one inverse-CDF sample per row from Philox4x32-10 keyed on
+ *                          (seed, row, launch counter); the counter lives on the device (hipGraph replays). */
+typedef struct cavoid_policy cavoid_policy;
+typedef struct cavoid_policy_weights {
+    int32_t struct_size;             /* sizeof(cavoid_policy_weights) */
+    float min_policy;                /* Config.MIN_POLICY */
+    float forget_bias;               /* tf.contrib.rnn.LSTMCell default: 1.0 */
+    int32_t reserved;
+    const float *avg, *std;          /* [5 + 7*max_other] or both NULL */
+    const float *lstm_kernel, *lstm_bias;       /* rnn/lstm_cell/kernel [71,256], bias [256] */
+    const float *layer1_kernel, *layer1_bias;   /* layer1 [68,256], [256] */
+    const float *layer2_kernel, *layer2_bias;   /* layer2 [256,256], [256] */
+    const float *fc1_kernel, *fc1_bias;         /* fullyconnected1 [256,256], [256] */
+    const float *p_kernel, *p_bias;             /* logits_p [256,A], [A] */
+    const float *v_kernel, *v_bias;             /* logits_v [256,1], [1] */
+} cavoid_policy_weights;
+int cavoid_policy_create(int32_t max_other, int32_t num_actions, int device, cavoid_policy **out);
+void cavoid_policy_destroy(cavoid_policy *p);
+int cavoid_policy_load(cavoid_policy *p, const cavoid_policy_weights *w, void *stream);
+int cavoid_policy_seed(cavoid_policy *p, uint64_t seed, void *stream);
+int cavoid_policy_forward(cavoid_policy *p, const float *x, int64_t rows, int64_t row_stride, float *p_out, float *v_out,
+                          int32_t *actions_out, int32_t greedy, void *stream);
+
 /* kernel timing helper: HIP events recorded on `stream` around the launches of the calls made
  * between begin and end; end synchronises and returns elapsed milliseconds */
 int cavoid_timer_begin(cavoid_env *env, void *stream);

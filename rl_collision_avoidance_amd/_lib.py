@@ -41,6 +41,13 @@ class CavoidCfg(C.Structure):
     ]
 
 
+class CavoidPolicyWeights(C.Structure):
+    """Mirror of ``struct cavoid_policy_weights`` (include/cavoid.h)."""
+    _fields_ = [("struct_size", C.c_int32), ("min_policy", C.c_float), ("forget_bias", C.c_float), ("reserved", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("avg", "std", "lstm_kernel", "lstm_bias", "layer1_kernel", "layer1_bias", "layer2_kernel",
+                                  "layer2_bias", "fc1_kernel", "fc1_bias", "p_kernel", "p_bias", "v_kernel", "v_bias")]
+
+
 class CavoidError(RuntimeError):
     def __init__(self, code: int, where: str):
         msg = lib().cavoid_strerror(code).decode()
@@ -77,6 +84,11 @@ SYMBOLS = [
     ("cavoid_rollout_destroy", None, [_P]),
     ("cavoid_rollout_reset", C.c_int, [_P, _P]),
     ("cavoid_rollout_push", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32] + [_P] * 10 + [C.c_int64, _P, _P, C.c_int64, _P]),
+    ("cavoid_policy_create", C.c_int, [C.c_int32, C.c_int32, C.c_int, C.POINTER(_P)]),
+    ("cavoid_policy_destroy", None, [_P]),
+    ("cavoid_policy_load", C.c_int, [_P, C.POINTER(CavoidPolicyWeights), _P]),
+    ("cavoid_policy_seed", C.c_int, [_P, C.c_uint64, _P]),
+    ("cavoid_policy_forward", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32, _P]),
     ("cavoid_timer_begin", C.c_int, [_P, _P]),
     ("cavoid_timer_end", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
 ]

@@ -10,10 +10,12 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
-SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip")]
+SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
+           os.path.join(CSRC, "cavoid_policy_capi.hip")]
 HEADERS = {
     "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_host.hpp"],
     "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_host.hpp"],
+    "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_host.hpp"],
 }
 DEPS = SOURCES + [os.path.join(CSRC, h) for hs in HEADERS.values() for h in hs] + [os.path.join(ROOT, "include", "cavoid.h")]
 OBJ_DIR = os.path.join(PKG_DIR, "build")

@@ -1,0 +1,395 @@
+// cavoid_policy.hpp -- NetworkVP_rnn inference (the actors' predict_p_and_v) as ONE gfx950 kernel.
+//
+// What it computes (citations: /root/reference/ga3c/GA3C):
+//   x [rows, 5+7M] -> (x - avg) / std                                        NetworkVP_rnn.py:50-53
+//   num_other = x[:,0] raw; host = xn[:,1:5]; others = xn[:,5:] as [M,7]      :58-61
+//   LSTMCell(64) over the others, state frozen past each row's own length      :64-66
+//   [host | h] -> dense256 relu (layer1) -> dense256 relu (layer2)             :67,103-105
+//   -> dense256 relu (fullyconnected1) -> logits_v, logits_p                   NetworkVPCore.py:66-75
+//   softmax_p = (softmax(logits_p) + MIN_POLICY) / (1 + MIN_POLICY * A)         :75
+//
+// This part of the path IS a dense contraction (280 kFLOP per row, 9.2 GFLOP per step at 4 x 8192), so
+// it runs on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate -- the reference policy
+// is float32 TensorFlow, no precision is given up).  One workgroup = 64 rows x 4 wavefronts:
+//   * activations live in ONE LDS buffer [64][260] floats (stride 260: ds_read_b128 of the A
+//     fragments and ds_write_b32 of the C fragments are both bank-conflict free);
+//   * wavefront w owns output columns 64w..64w+63 of every layer (4 row tiles x 4 column tiles of
+//     16x16, 64 accumulator registers); for the LSTM the columns are permuted so that its 4 column
+//     tiles are the i, j, f, o gates of hidden units 16w..16w+15 -- the cell update is then per lane,
+//     the cell state never leaves registers;
+//   * weights are read from a fragment-ordered copy (policy_pack_kernel): one global_load_dwordx4 per
+//     lane feeds 4 MFMAs, 1 KB contiguous per wave instruction, L2-resident (688 KB in all);
+//   * a K chunk is 16 wide: lane group g = lane/16 supplies k = 16*chunk + 4g + s in MFMA s = 0..3
+//     (any fixed bijection of k works as long as A and B agree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cavoid {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPolRows = 64;           // rows per workgroup
+constexpr int kPolStride = 260;        // LDS row stride in floats (260 % 64 == 4)
+constexpr int kPolHidden = 64, kPolWidth = 256, kPolHost = 4, kPolOther = 7;
+constexpr int kPolMaxOthers = 24;      // x columns parked at LDS columns 80.. must fit: 80 + 5 + 7M <= 256
+constexpr int kPolXCol = 80;           // first LDS column of the normalised input row
+constexpr size_t kPolLdsBytes = (size_t)(kPolRows * kPolStride + 4) * sizeof(float);
+
+// chunk counts (16 k each) and fragment offsets (in float4 = one lane's 4 k-values) of the packed weights
+constexpr int kChLstm = 5, kChL1 = 5, kChWide = 16, kChHead = 16;
+constexpr int64_t kFragPerChunk = 16 * 64;                     // 16 column tiles x 64 lanes
+constexpr int64_t kOffLstm = 0;
+constexpr int64_t kOffL1 = kOffLstm + kChLstm * kFragPerChunk;
+constexpr int64_t kOffL2 = kOffL1 + kChL1 * kFragPerChunk;
+constexpr int64_t kOffFc1 = kOffL2 + kChWide * kFragPerChunk;
+constexpr int64_t kOffHead = kOffFc1 + kChWide * kFragPerChunk;  // one column tile only: 64 frags per chunk
+constexpr int64_t kPackFrags = kOffHead + kChHead * 64;
+// biases, in packed column order: lstm 256 (forget bias folded in), l1 256, l2 256, fc1 256, head 16
+constexpr int kBiasLstm = 0, kBiasL1 = 256, kBiasL2 = 512, kBiasFc1 = 768, kBiasHead = 1024, kBiasFloats = 1040;
+
+struct PolicyWeights {                 // device pointers, TensorFlow layout ([in, out] kernels)
+    const float *lstm_kernel, *lstm_bias;      // [7+64, 256] rows: 7 inputs then 64 hidden; gate order i, j, f, o
+    const float *layer1_kernel, *layer1_bias;  // [4+64, 256] rows: 4 host then 64 hidden
+    const float *layer2_kernel, *layer2_bias;  // [256, 256]
+    const float *fc1_kernel, *fc1_bias;        // [256, 256]
+    const float *p_kernel, *p_bias;            // [256, A]
+    const float *v_kernel, *v_bias;            // [256, 1]
+    int num_actions;
+    float forget_bias;
+};
+
+// ---- weight packing -----------------------------------------------------------------------------------
+// packed frag (layer, chunk, column tile ct, lane) = 4 floats, s = 0..3:
+//     W_layer[ kmap(16*chunk + 4*(lane/16) + s) ][ cmap(16*ct + lane%16) ]
+__device__ __forceinline__ float policy_weight(const PolicyWeights &w, int layer, int k, int col) {
+    switch (layer) {
+    case 0: {                                               // LSTM: k 0..63 hidden, 64..70 input; col tiles = (wave, gate)
+        const int wave = col >> 6, gate = (col >> 4) & 3, u = col & 15;
+        const int src_col = gate * kPolHidden + 16 * wave + u;
+        if (k < kPolHidden) return w.lstm_kernel[(int64_t)(kPolOther + k) * 256 + src_col];
+        if (k < kPolHidden + kPolOther) return w.lstm_kernel[(int64_t)(k - kPolHidden) * 256 + src_col];
+        return 0.0f;
+    }
+    case 1:                                                 // layer1: k 0..63 hidden, 64..67 host
+        if (k < kPolHidden) return w.layer1_kernel[(int64_t)(kPolHost + k) * 256 + col];
+        if (k < kPolHidden + kPolHost) return w.layer1_kernel[(int64_t)(k - kPolHidden) * 256 + col];
+        return 0.0f;
+    case 2: return w.layer2_kernel[(int64_t)k * 256 + col];
+    case 3: return w.fc1_kernel[(int64_t)k * 256 + col];
+    default:                                                // heads: columns 0..A-1 logits_p, column A logits_v
+        if (col < w.num_actions) return w.p_kernel[(int64_t)k * w.num_actions + col];
+        if (col == w.num_actions) return w.v_kernel[k];
+        return 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) policy_pack_kernel(const PolicyWeights w, f32x4 *frags, float *bias) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < kPackFrags) {
+        int layer, chunk, ct, lane;
+        if (f >= kOffHead) {
+            const int64_t r = f - kOffHead;
+            layer = 4; chunk = (int)(r >> 6); ct = 0; lane = (int)(r & 63);
+        } else {
+            const int64_t base = f >= kOffFc1 ? kOffFc1 : f >= kOffL2 ? kOffL2 : f >= kOffL1 ? kOffL1 : kOffLstm;
+            layer = f >= kOffFc1 ? 3 : f >= kOffL2 ? 2 : f >= kOffL1 ? 1 : 0;
+            const int64_t r = f - base;
+            chunk = (int)(r / kFragPerChunk); ct = (int)((r >> 6) & 15); lane = (int)(r & 63);
+        }
+        const int k0 = 16 * chunk + 4 * (lane >> 4), col = 16 * ct + (lane & 15);
+        f32x4 v;
+        v.x = policy_weight(w, layer, k0 + 0, col); v.y = policy_weight(w, layer, k0 + 1, col);
+        v.z = policy_weight(w, layer, k0 + 2, col); v.w = policy_weight(w, layer, k0 + 3, col);
+        frags[f] = v;
+    }
+    if (f < kBiasFloats) {
+        const int i = (int)f;
+        float b;
+        if (i < kBiasL1) {
+            const int wave = i >> 6, gate = (i >> 4) & 3, u = i & 15;
+            b = w.lstm_bias[gate * kPolHidden + 16 * wave + u] + (gate == 2 ? w.forget_bias : 0.0f);
+        } else if (i < kBiasL2) b = w.layer1_bias[i - kBiasL1];
+        else if (i < kBiasFc1) b = w.layer2_bias[i - kBiasL2];
+        else if (i < kBiasHead) b = w.fc1_bias[i - kBiasFc1];
+        else {
+            const int c = i - kBiasHead;
+            b = c < w.num_actions ? w.p_bias[c] : (c == w.num_actions ? w.v_bias[0] : 0.0f);
+        }
+        bias[i] = b;
+    }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------
+struct PolicyArgs {
+    const float *x;                    // first policy input of row 0 (the env's obs row + 1: 'is_learning' skipped)
+    int64_t rows, stride;              // stride between rows, in floats
+    int max_other, num_actions, in_size;
+    const float *avg, *std;            // [in_size]; nullptr = NORMALIZE_INPUT off
+    const f32x4 *frags;
+    const float *bias;
+    float min_policy;
+    float *p_out;                      // [rows, A]
+    float *v_out;                      // [rows]
+    // optional select_action (ProcessAgent.py:89-103): sample from p (or argmax when greedy) in the same launch
+    int32_t *actions_out;              // [rows] or nullptr
+    int greedy;
+    uint32_t seed_lo, seed_hi;
+    int32_t *step_counter;             // device-side: keys the random stream, advanced once per launch
+    uint32_t *blocks_done;
+};
+
+// Philox4x32-10, the same generator the scenario generator uses (cavoid_kernels.hpp)
+__device__ __forceinline__ uint32_t policy_philox_x(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+// One 16-wide K chunk of fragments: 4 row tiles of A (LDS) and 4 column tiles of B (packed weights, L2).
+struct PolicyFrag { f32x4 a[4], b[4]; };
+
+__device__ __forceinline__ void policy_load_frag(PolicyFrag &f, const float *arow, const f32x4 *brow, int ch) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.b[t] = brow[(int64_t)ch * kFragPerChunk + 64 * t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.a[t] = *reinterpret_cast<const f32x4 *>(arow + 16 * t * kPolStride + 16 * ch);
+}
+
+__device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag &f, f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[rt][s], f.b[ct][s], acc[rt][ct], 0, 0, 0);
+}
+
+// acc[rt][ct] += A(rows 16rt.., k chunks [c0, c1)) x B(column tiles ct0..ct0+3 of the packed layer).
+// Two fragment sets ping-pong: the loads of chunk n+1 are issued before the 64 MFMAs (2048 cycles) of chunk n
+// and are first needed after them, so neither the L2 nor the LDS latency is exposed.
+__device__ __forceinline__ void policy_gemm(const float *act, const f32x4 *layer, int c0, int c1, int ct0, int lane,
+                                            f32x4 (&acc)[4][4]) {
+    const float *arow = act + (lane & 15) * kPolStride + 4 * (lane >> 4);
+    const f32x4 *brow = layer + (int64_t)ct0 * 64 + lane;
+    PolicyFrag f0, f1;
+    policy_load_frag(f0, arow, brow, c0);
+    int ch = c0;
+    while (true) {
+        policy_load_frag(f1, arow, brow, ch + 1 < c1 ? ch + 1 : ch);      // unconditional (the last one is a harmless
+        __builtin_amdgcn_sched_barrier(0);                                  // re-read): a branch here would make the
+        policy_mfma_chunk(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 >= c1) break;
+        policy_load_frag(f0, arow, brow, ch + 2 < c1 ? ch + 2 : ch);      // compiler wait for the prefetch at the join
+        __builtin_amdgcn_sched_barrier(0);
+        policy_mfma_chunk(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        ch += 2;
+        if (ch >= c1) break;
+    }
+}
+
+__device__ __forceinline__ void policy_init_acc(const float *bias, int ct0, int lane, f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const float b = bias[16 * (ct0 + ct) + (lane & 15)];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = f32x4{b, b, b, b};
+    }
+}
+
+// relu(acc) -> act[row][col]: lane holds col = 16*(ct0+ct) + lane%16, rows 16rt + 4*(lane/16) + r
+__device__ __forceinline__ void policy_store_relu(float *act, int ct0, int lane, const f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * (ct0 + ct) + (lane & 15)] = fmaxf(acc[rt][ct][r], 0.0f);
+}
+
+__global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float act[];          // [kPolRows][kPolStride] + 1 int (66 564 B: dynamic)
+    int &tile_max_len = *reinterpret_cast<int *>(act + kPolRows * kPolStride);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t row0 = (int64_t)blockIdx.x * kPolRows;
+    const int rows_here = p.rows - row0 < kPolRows ? (int)(p.rows - row0) : kPolRows;
+    const int M = p.max_other, in_size = p.in_size;
+    const int step = p.actions_out ? *p.step_counter : 0;
+
+    // ---- input tile: normalise, park at columns kPolXCol.. (column kPolXCol holds the RAW num_other) ----
+    if (tid == 0) tile_max_len = 0;
+    __syncthreads();
+    {
+        const float *src = p.x + row0 * p.stride;
+        const int n = rows_here * (int)p.stride;
+        int local_max = 0;
+        for (int e = tid; e < kPolRows * (int)p.stride; e += 256) {
+            const int r = e / (int)p.stride, cidx = e - r * (int)p.stride;
+            if (cidx >= in_size) continue;
+            float v = 0.0f;
+            if (e < n && r < rows_here) {
+                v = src[e];
+                if (cidx == 0) {
+                    int len = (int)v;
+                    len = len < 0 ? 0 : (len > M ? M : len);
+                    local_max = local_max > len ? local_max : len;
+                } else if (p.avg) {
+                    v = (v - p.avg[cidx]) / p.std[cidx];
+                }
+            }
+            act[r * kPolStride + kPolXCol + cidx] = v;
+        }
+        if (local_max > 0) atomicMax(&tile_max_len, local_max);
+    }
+    __syncthreads();
+    const int steps = tile_max_len;                        // LSTM steps any row of this tile still needs
+
+    // this lane's rows in the C layout and their sequence lengths
+    float len_r[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) len_r[rt][r] = act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + kPolXCol];
+
+    // ---- LSTM over the observed agents -------------------------------------------------------------------
+    f32x4 cell[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) cell[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // h = 0 (columns 0..63); columns 64..79 = [x_t(7), 0 x 9]
+    for (int e = tid; e < kPolRows * kPolHidden; e += 256) act[(e >> 6) * kPolStride + (e & 63)] = 0.0f;
+    const f32x4 *w_lstm = p.frags + kOffLstm;
+    for (int t = 0; t < steps; ++t) {
+        for (int e = tid; e < kPolRows * 16; e += 256) {
+            const int r = e >> 4, k = e & 15;
+            act[r * kPolStride + kPolHidden + k] =
+                k < kPolOther ? act[r * kPolStride + kPolXCol + 1 + kPolHost + kPolOther * t + k] : 0.0f;
+        }
+        __syncthreads();                                   // x_t and the previous step's h are in place
+        f32x4 acc[4][4];
+        policy_init_acc(p.bias + kBiasLstm, 4 * wave, lane, acc);
+        policy_gemm(act, w_lstm, t == 0 ? 4 : 0, kChLstm, 4 * wave, lane, acc);     // h == 0 at t == 0
+        __syncthreads();                                   // every wavefront has read h
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (len_r[rt][r] > (float)t) {             // dynamic_rnn: rows past their length keep (c, h)
+                    const float gi = acc[rt][0][r], gj = acc[rt][1][r], gf = acc[rt][2][r], go = acc[rt][3][r];
+                    const float c_new = fast_sigmoid(gf) * cell[rt][r] + fast_sigmoid(gi) * fast_tanh(gj);
+                    cell[rt][r] = c_new;
+                    act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * wave + (lane & 15)] = fast_sigmoid(go) * fast_tanh(c_new);
+                }
+            }
+    }
+    // ---- layer1 on [h | host] --------------------------------------------------------------------------------
+    for (int e = tid; e < kPolRows * 16; e += 256) {
+        const int r = e >> 4, k = e & 15;
+        act[r * kPolStride + kPolHidden + k] = k < kPolHost ? act[r * kPolStride + kPolXCol + 1 + k] : 0.0f;
+    }
+    __syncthreads();
+    {
+        f32x4 acc[4][4];
+        policy_init_acc(p.bias + kBiasL1, 4 * wave, lane, acc);
+        policy_gemm(act, p.frags + kOffL1, 0, kChL1, 4 * wave, lane, acc);
+        __syncthreads();
+        policy_store_relu(act, 4 * wave, lane, acc);
+    }
+    __syncthreads();
+    // ---- layer2, fullyconnected1 -----------------------------------------------------------------------------
+#pragma unroll 1
+    for (int l = 0; l < 2; ++l) {
+        f32x4 acc[4][4];
+        policy_init_acc(p.bias + (l == 0 ? kBiasL2 : kBiasFc1), 4 * wave, lane, acc);
+        policy_gemm(act, p.frags + (l == 0 ? kOffL2 : kOffFc1), 0, kChWide, 4 * wave, lane, acc);
+        __syncthreads();
+        policy_store_relu(act, 4 * wave, lane, acc);
+        __syncthreads();
+    }
+    // ---- heads: wavefront w does rows 16w..16w+15 x 16 columns (A logits, the value, padding) -----------------
+    {
+        f32x4 acc[4];
+        const float b = p.bias[kBiasHead + (lane & 15)];
+        acc[0] = f32x4{b, b, b, b};
+        acc[1] = acc[2] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *arow = act + (16 * wave + (lane & 15)) * kPolStride + 4 * (lane >> 4);
+        const f32x4 *brow = p.frags + kOffHead + lane;
+#pragma unroll 4
+        for (int ch = 0; ch < kChHead; ++ch) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 16 * ch);
+            const f32x4 bb = brow[64 * ch];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bb[s], acc[s], 0, 0, 0);
+        }
+        const f32x4 logit = acc[0] + acc[1] + acc[2] + acc[3];
+        const int col = lane & 15, A = p.num_actions;
+        const float scale = 1.0f / (1.0f + p.min_policy * (float)A);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = logit[r];
+            float m = col < A ? z : -INFINITY;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 16));
+            const float e = col < A ? expf(z - m) : 0.0f;
+            float sum = e;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);
+            const int64_t row = row0 + 16 * wave + 4 * (lane >> 4) + r;
+            const float pj = col < A ? (e / sum + p.min_policy) * scale : 0.0f;
+            if (row < p.rows) {
+                if (col < A) p.p_out[row * A + col] = pj;
+                else if (col == A) p.v_out[row] = z;
+            }
+            if (p.actions_out) {                           // wave-uniform
+                int action;
+                if (p.greedy) {                            // np.argmax: first index of the maximum
+                    float best = pj;
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) best = fmaxf(best, __shfl_xor(best, d, 16));
+                    int idx = (col < A && pj == best) ? col : 99;
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) { const int o = __shfl_xor(idx, d, 16); idx = o < idx ? o : idx; }
+                    action = idx;
+                } else {                                   // inverse CDF: #{c : cdf_c <= u * cdf_{A-1}}
+                    float cdf = pj;
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) { const float t = __shfl_up(cdf, d, 16); if (col >= d) cdf += t; }
+                    const float total = __shfl(cdf, A - 1, 16);
+                    const uint32_t bits = policy_philox_x((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)step, 0x504F4Cu,
+                                                          p.seed_lo, p.seed_hi);
+                    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+                    int below = (col < A && cdf <= u * total) ? 1 : 0;
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) below += __shfl_xor(below, d, 16);
+                    action = below < A - 1 ? below : A - 1;
+                }
+                if (row < p.rows && col == 0) p.actions_out[row] = action;
+            }
+        }
+    }
+    if (p.actions_out) {                                   // the last workgroup to finish advances the step counter
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            if (atomicAdd(p.blocks_done, 1u) == gridDim.x - 1u) {
+                *p.blocks_done = 0u;
+                *p.step_counter = step + 1;
+                __threadfence();
+            }
+        }
+    }
+}
+
+}  // namespace cavoid

@@ -1,0 +1,113 @@
+// cavoid_policy_capi.hip -- C ABI (include/cavoid.h, cavoid_policy_*) over the fused NetworkVP_rnn
+// inference kernel of cavoid_policy.hpp.
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "cavoid.h"
+#include "cavoid_host.hpp"
+#include "cavoid_policy.hpp"
+
+using namespace cavoid;
+
+struct cavoid_policy {
+    int device = 0;
+    int max_other = 0, num_actions = 0, in_size = 0;
+    bool loaded = false, normalize = false;
+    float min_policy = 0.0f;
+    uint64_t seed = 0;
+    void *slab = nullptr;
+    f32x4 *frags = nullptr;
+    float *bias = nullptr, *avg = nullptr, *std = nullptr;
+    int32_t *step_counter = nullptr;
+    uint32_t *blocks_done = nullptr;
+};
+
+extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int device, cavoid_policy **out) {
+    if (!out) return CAVOID_EINVAL;
+    *out = nullptr;
+    if (max_other < 1 || max_other > kPolMaxOthers || num_actions < 1 || num_actions > 15) return CAVOID_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CAVOID_ENODEVICE;
+    HIP_TRY(hipSetDevice(device));
+    cavoid_policy *h = new (std::nothrow) cavoid_policy();
+    if (!h) return CAVOID_ENOMEM;
+    h->device = device; h->max_other = max_other; h->num_actions = num_actions;
+    h->in_size = 1 + kPolHost + kPolOther * max_other;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_frag = carve((size_t)kPackFrags * sizeof(f32x4)), o_bias = carve(kBiasFloats * sizeof(float));
+    const size_t o_avg = carve(h->in_size * sizeof(float)), o_std = carve(h->in_size * sizeof(float));
+    const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t));
+    if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return CAVOID_ENOMEM; }
+    if (hipMemset(h->slab, 0, off) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP; }
+    unsigned char *b = static_cast<unsigned char *>(h->slab);
+    h->frags = reinterpret_cast<f32x4 *>(b + o_frag); h->bias = reinterpret_cast<float *>(b + o_bias);
+    h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
+    h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
+    // 66.5 KB of LDS per workgroup: above the 64 KB static limit, so it is dynamic and opted into here
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPolLdsBytes) != hipSuccess) {
+        g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP;
+    }
+    *out = h;
+    return CAVOID_OK;
+}
+
+extern "C" void cavoid_policy_destroy(cavoid_policy *h) {
+    if (!h) return;
+    if (h->slab) (void)hipFree(h->slab);
+    delete h;
+}
+
+extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights *w, void *stream) {
+    if (!h || !w || w->struct_size != (int32_t)sizeof(cavoid_policy_weights)) return CAVOID_EINVAL;
+    if (!w->lstm_kernel || !w->lstm_bias || !w->layer1_kernel || !w->layer1_bias || !w->layer2_kernel || !w->layer2_bias ||
+        !w->fc1_kernel || !w->fc1_bias || !w->p_kernel || !w->p_bias || !w->v_kernel || !w->v_bias)
+        return CAVOID_EINVAL;
+    if ((w->avg == nullptr) != (w->std == nullptr)) return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(h->device));
+    PolicyWeights k{};
+    k.lstm_kernel = w->lstm_kernel; k.lstm_bias = w->lstm_bias; k.layer1_kernel = w->layer1_kernel; k.layer1_bias = w->layer1_bias;
+    k.layer2_kernel = w->layer2_kernel; k.layer2_bias = w->layer2_bias; k.fc1_kernel = w->fc1_kernel; k.fc1_bias = w->fc1_bias;
+    k.p_kernel = w->p_kernel; k.p_bias = w->p_bias; k.v_kernel = w->v_kernel; k.v_bias = w->v_bias;
+    k.num_actions = h->num_actions; k.forget_bias = w->forget_bias;
+    const unsigned blocks = (unsigned)((kPackFrags + 255) / 256);
+    hipLaunchKernelGGL(policy_pack_kernel, dim3(blocks), dim3(256), 0, s, k, h->frags, h->bias);
+    HIP_TRY(hipGetLastError());
+    h->normalize = w->avg != nullptr;
+    if (h->normalize) {
+        HIP_TRY(hipMemcpyAsync(h->avg, w->avg, h->in_size * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->std, w->std, h->in_size * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    h->min_policy = w->min_policy;
+    h->loaded = true;
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_policy_seed(cavoid_policy *h, uint64_t seed, void *stream) {
+    if (!h) return CAVOID_EINVAL;
+    h->seed = seed;
+    HIP_TRY(hipMemsetAsync(h->step_counter, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_t row_stride, float *p_out, float *v_out,
+                                     int32_t *actions_out, int32_t greedy, void *stream) {
+    if (!h || !x || !p_out || !v_out || rows < 0 || row_stride < h->in_size || row_stride > 256) return CAVOID_EINVAL;
+    if (!h->loaded) return CAVOID_EINVAL;
+    if (rows == 0) return CAVOID_OK;
+    PolicyArgs a{};
+    a.x = x; a.rows = rows; a.stride = row_stride; a.max_other = h->max_other; a.num_actions = h->num_actions; a.in_size = h->in_size;
+    a.avg = h->normalize ? h->avg : nullptr; a.std = h->normalize ? h->std : nullptr;
+    a.frags = h->frags; a.bias = h->bias; a.min_policy = h->min_policy; a.p_out = p_out; a.v_out = v_out;
+    a.actions_out = actions_out; a.greedy = greedy ? 1 : 0;
+    a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
+    a.step_counter = h->step_counter; a.blocks_done = h->blocks_done;
+    const int64_t blocks = (rows + kPolRows - 1) / kPolRows;
+    if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
+    hipLaunchKernelGGL(policy_forward_kernel, dim3((unsigned)blocks), dim3(256), kPolLdsBytes, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}

@@ -121,6 +121,10 @@ class BatchedRollout(object):
     def act(self, obs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """predict + select_action for every agent row (ProcessAgent.py:89-103,128-144)."""
         W, N = self.env.num_worlds, self.env.max_agents
+        if getattr(self.policy, "accepts_strided_obs", False):
+            # fused kernel (ga3c/policy_kernel.py): reads the obs tensor in place and selects the action itself
+            actions, _, v = self.policy.act(obs.view(W * N, -1)[:, 1:], greedy=self.greedy)
+            return actions.reshape(W, N), v.reshape(W, N)
         p, v = self.policy(obs[..., 1:].reshape(W * N, -1))
         if self.greedy:
             actions = p.argmax(dim=-1)

@@ -1,0 +1,174 @@
+"""GPU parity of the fused policy kernel (HIP, through the C ABI: cavoid_policy_*) against the plain PyTorch
+float32 ``NetworkVP_rnn.forward`` of the same weights -- a floating-point kernel, so the torch fp32 graph
+is its reference (tolerances below); the action selection is integer work and is checked exactly."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle.cavoid_oracle import philox4x32
+
+pytestmark = pytest.mark.gpu
+
+P_TOL = 2e-5       # softmax probabilities (absolute; p <= 1): f32 MFMA vs rocBLAS f32, different summation order
+V_TOL = 2e-4       # value head (|v| = O(1)); absolute + relative
+
+
+def _net(M, seed=0, min_policy=0.0, normalize=True, A=11):
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.ga3c.network import NetworkVP_rnn
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = M + 1
+            EnvConfig.__init__(self)
+    cfg = Cfg()
+    cfg.MIN_POLICY = min_policy
+    cfg.NORMALIZE_INPUT = normalize
+    net = NetworkVP_rnn(cfg, num_actions=A, seed=seed).cuda()
+    g = torch.Generator().manual_seed(seed + 100)
+    with torch.no_grad():                      # non-zero biases so that every bias path is exercised
+        for name, prm in net.named_parameters():
+            if name.endswith("_bias"):
+                prm.copy_((torch.rand(prm.shape, generator=g) - 0.5).to(prm.device))
+    return net
+
+
+def _inputs(net, B, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    M = net.max_others
+    x = torch.randn((B, net.input_size), generator=g) * scale * net.std.cpu() + net.avg.cpu()
+    x[:, 0] = torch.randint(0, M + 1, (B,), generator=g).to(torch.float32)
+    return x.cuda()
+
+
+@pytest.mark.parametrize("M,B", [(3, 1), (3, 63), (3, 64), (3, 130), (3, 32768), (9, 1000), (19, 517), (1, 200)])
+def test_forward_matches_torch_fp32(M, B):
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(M, seed=M)
+    pol = FusedPolicy(net)
+    x = _inputs(net, B, seed=B)
+    p, v = pol(x)
+    with torch.no_grad():
+        _, p_ref, v_ref = net.forward(x)
+    assert p.shape == (B, 11) and v.shape == (B,)
+    assert torch.isfinite(p).all() and torch.isfinite(v).all()
+    assert (p - p_ref).abs().max().item() <= P_TOL
+    assert ((v - v_ref).abs() <= V_TOL + V_TOL * v_ref.abs()).all()
+    assert (p.sum(dim=1) - 1.0).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("min_policy,normalize", [(1e-3, True), (0.0, False)])
+def test_min_policy_and_unnormalised_input(min_policy, normalize):
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(3, seed=5, min_policy=min_policy, normalize=normalize)
+    pol = FusedPolicy(net)
+    x = _inputs(net, 777, seed=1, scale=0.3 if not normalize else 1.0)
+    p, v = pol(x)
+    with torch.no_grad():
+        _, p_ref, v_ref = net.forward(x)
+    assert (p - p_ref).abs().max().item() <= P_TOL
+    assert ((v - v_ref).abs() <= V_TOL + V_TOL * v_ref.abs()).all()
+
+
+def test_runs_on_the_env_observation_tensor_in_place():
+    """The kernel reads the env's obs tensor through a row stride (column 0 'is_learning' skipped): no slice copy."""
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    env = BatchedCollisionAvoidanceEnv(300, seed=3, gen_min_agents=2)
+    net = _net(3, seed=9)
+    pol = FusedPolicy(net)
+    obs = env.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        obs, _, _, _ = env.step_autoreset(torch.from_numpy(rng.integers(0, 11, size=(300, 4)).astype(np.int32)).cuda())
+    view = obs.view(300 * 4, -1)[:, 1:]
+    assert not view.is_contiguous()
+    p, v = pol(view)
+    with torch.no_grad():
+        _, p_ref, v_ref = net.forward(view.contiguous())
+    assert len(torch.unique(view[:, 0])) >= 2            # rows with different neighbour counts
+    assert (p - p_ref).abs().max().item() <= P_TOL
+    assert ((v - v_ref).abs() <= V_TOL + V_TOL * v_ref.abs()).all()
+
+
+def test_refresh_picks_up_new_weights():
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(3, seed=2)
+    pol = FusedPolicy(net)
+    x = _inputs(net, 256, seed=4)
+    p0, _ = pol(x)
+    with torch.no_grad():
+        for prm in net.parameters():
+            prm.mul_(0.5)
+    p_stale, _ = pol(x)
+    assert torch.equal(p_stale, p0)                         # the handle holds its own packed copy
+    pol.refresh()
+    p1, v1 = pol(x)
+    with torch.no_grad():
+        _, p_ref, v_ref = net.forward(x)
+    assert (p1 - p_ref).abs().max().item() <= P_TOL and not torch.allclose(p1, p0)
+
+
+def test_greedy_is_argmax_and_sampling_is_the_inverse_cdf():
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(3, seed=7)
+    SEED = 0x1234567890AB
+    pol = FusedPolicy(net, seed=SEED)
+    B = 5000
+    x = _inputs(net, B, seed=8)
+    a_g, p, _ = pol.act(x, greedy=True)
+    assert torch.equal(a_g.long(), p.argmax(dim=1))
+    draws = []
+    for _ in range(3):
+        a, p, _ = pol.act(x)
+        draws.append(a.cpu().numpy())
+    pn = p.cpu().numpy().astype(np.float64)
+    cdf = np.cumsum(pn, axis=1)
+    # every launch that selects actions advances the device-side counter: greedy was launch 0
+    for k, a in enumerate(draws):
+        step = 1 + k
+        bad = 0
+        for row in range(0, B, 7):
+            bits = philox4x32(row, 0, step, 0x504F4C, SEED & 0xFFFFFFFF, SEED >> 32)[0]
+            u = (bits >> 8) / 16777216.0
+            expect = min(int(np.sum(cdf[row] <= u * cdf[row, -1])), 10)
+            if expect != a[row]:
+                # only a draw within float32 rounding of a CDF boundary may land on the neighbour
+                assert np.min(np.abs(cdf[row] - u * cdf[row, -1])) < 1e-6, (row, step, expect, a[row])
+                bad += 1
+        assert bad <= 2
+    assert not np.array_equal(draws[0], draws[1])           # a fresh stream per launch
+    pol.seed(SEED)                                          # re-seeding rewinds the counter
+    pol.act(x, greedy=True)
+    again, _, _ = pol.act(x)
+    assert np.array_equal(again.cpu().numpy(), draws[0])
+
+
+def test_sampling_frequencies_follow_p():
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(3, seed=11)
+    pol = FusedPolicy(net, seed=99)
+    x = _inputs(net, 1, seed=3).repeat(200000, 1)
+    a, p, _ = pol.act(x)
+    freq = torch.bincount(a.long(), minlength=11).double() / a.numel()
+    assert (freq - p[0].double()).abs().max().item() < 5e-3
+
+
+def test_rollout_with_fused_policy_in_a_graph():
+    """BatchedRollout accepts the fused policy (strided obs, in-kernel action selection) and captures it."""
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    env = BatchedCollisionAvoidanceEnv(512, seed=5)
+    net = _net(3, seed=13)
+    roll = BatchedRollout(env, FusedPolicy(net, seed=1), reflush_done=False)
+    roll.reset()
+    roll.capture(steps_per_graph=4)
+    roll.replay(30)
+    batch = roll.drain(flush_all=True)
+    assert len(batch) > 20000 and batch.dropped == 0
+    assert int(batch.a_index.min()) >= 0 and int(batch.a_index.max()) <= 10
+    assert len(torch.unique(batch.a_index)) == 11
+    eps = roll.drain_episodes()
+    assert eps.shape[0] > 100
