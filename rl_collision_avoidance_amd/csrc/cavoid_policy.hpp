@@ -32,9 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPolRows = 64;           // rows per workgroup
 constexpr int kPolStride = 260;        // LDS row stride in floats (260 % 64 == 4)
 constexpr int kPolHidden = 64, kPolWidth = 256, kPolHost = 4, kPolOther = 7;
-constexpr int kPolMaxOthers = 24;      // x columns parked at LDS columns 80.. must fit: 80 + 5 + 7M <= 256
+constexpr int kPolMaxOthers = 19;      // the padded input row parked at LDS columns 80.. must fit: 80 + 16 + 8M + 8 <= 260
+constexpr int kPolCuSlots = 4096;      // (XCC id, SE, SH, CU) keys
 constexpr int kPolXCol = 80;           // first LDS column of the normalised input row
-constexpr size_t kPolLdsBytes = (size_t)(kPolRows * kPolStride + 4) * sizeof(float);
 
 // chunk counts (16 k each) and fragment offsets (in float4 = one lane's 4 k-values) of the packed weights
 constexpr int kChLstm = 5, kChL1 = 5, kChWide = 16, kChHead = 16;
@@ -47,6 +47,7 @@ constexpr int64_t kOffHead = kOffFc1 + kChWide * kFragPerChunk;  // one column t
 constexpr int64_t kPackFrags = kOffHead + kChHead * 64;
 // biases, in packed column order: lstm 256 (forget bias folded in), l1 256, l2 256, fc1 256, head 16
 constexpr int kBiasLstm = 0, kBiasL1 = 256, kBiasL2 = 512, kBiasFc1 = 768, kBiasHead = 1024, kBiasFloats = 1040;
+constexpr size_t kPolLdsBytes = (size_t)(kPolRows * kPolStride + kBiasFloats + 8) * sizeof(float);   // 70 752 B: 2 workgroups per CU
 
 struct PolicyWeights {                 // device pointers, TensorFlow layout ([in, out] kernels)
     const float *lstm_kernel, *lstm_bias;      // [7+64, 256] rows: 7 inputs then 64 hidden; gate order i, j, f, o
@@ -120,6 +121,18 @@ __global__ void __launch_bounds__(256) policy_pack_kernel(const PolicyWeights w,
     }
 }
 
+// Development aid (never in the product build): -DCAVOID_TRACE makes every workgroup record the constant-rate
+// wall clock at its phase boundaries and the CU it ran on into g_pol_trace[block*8 + k] (tools/trace_policy.py).
+#ifdef CAVOID_TRACE
+__device__ unsigned long long *g_pol_trace = nullptr;
+#define POLICY_STAMP(k)                                                                                      \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();     \
+    } while (0)
+#else
+#define POLICY_STAMP(k) do { } while (0)
+#endif
+
 // ---- forward ------------------------------------------------------------------------------------------
 struct PolicyArgs {
     const float *x;                    // first policy input of row 0 (the env's obs row + 1: 'is_learning' skipped)
@@ -137,6 +150,7 @@ struct PolicyArgs {
     uint32_t seed_lo, seed_hi;
     int32_t *step_counter;             // device-side: keys the random stream, advanced once per launch
     uint32_t *blocks_done;
+    uint32_t *cu_tickets;              // [kPolCuSlots] arrival counters, one per compute unit (see the kernel)
 };
 
 // Philox4x32-10, the same generator the scenario generator uses (cavoid_kernels.hpp)
@@ -152,17 +166,25 @@ __device__ __forceinline__ uint32_t policy_philox_x(uint32_t c0, uint32_t c1, ui
     return c0;
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each): |error| of the gates ~1e-7, far inside the 1e-5 the outputs are held to
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // One 16-wide K chunk of fragments: 4 row tiles of A (LDS) and 4 column tiles of B (packed weights, L2).
 struct PolicyFrag { f32x4 a[4], b[4]; };
 
-__device__ __forceinline__ void policy_load_frag(PolicyFrag &f, const float *arow, const f32x4 *brow, int ch) {
+// A fragments of chunk ch start at LDS column 16*ch, except that chunk 4 (the "input" chunk of the two 80-wide
+// layers) starts at `xcol`: the LSTM reads x_t and layer1 reads the host state where the prologue parked them.
+__device__ __forceinline__ void policy_load_a(PolicyFrag &f, const float *arow, int ch, int xcol) {
+    const int col = ch == 4 ? xcol : 16 * ch;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.a[t] = *reinterpret_cast<const f32x4 *>(arow + 16 * t * kPolStride + col);
+}
+
+__device__ __forceinline__ void policy_load_b(PolicyFrag &f, const f32x4 *layer, int ct0, int lane, int ch) {
+    const f32x4 *brow = layer + (int64_t)ct0 * 64 + lane;
 #pragma unroll
     for (int t = 0; t < 4; ++t) f.b[t] = brow[(int64_t)ch * kFragPerChunk + 64 * t];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) f.a[t] = *reinterpret_cast<const f32x4 *>(arow + 16 * t * kPolStride + 16 * ch);
 }
 
 __device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag &f, f32x4 (&acc)[4][4]) {
@@ -175,26 +197,47 @@ __device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag &f, f32x4 (&a
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[rt][s], f.b[ct][s], acc[rt][ct], 0, 0, 0);
 }
 
+// Issue order inside one chunk: the 4 weight loads and the 4 LDS reads of the NEXT chunk go out one at a time in the
+// shadow of the first 32 MFMAs (a wavefront can issue a few other instructions per 32-cycle MFMA slot; clustered at
+// the chunk boundary they cost ~350 cycles per 2048), the last 32 MFMAs cover their latency.
+#define POLICY_INTERLEAVE()                                          \
+    do {                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       \
+        }                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       \
+        }                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);          \
+    } while (0)
+
 // acc[rt][ct] += A(rows 16rt.., k chunks [c0, c1)) x B(column tiles ct0..ct0+3 of the packed layer).
+// f0.b must already hold chunk c0's weight fragments (policy_load_b, issued BEFORE the barrier that publishes
+// the activations: the weights do not depend on it, so their L2 latency hides behind the barrier).
 // Two fragment sets ping-pong: the loads of chunk n+1 are issued before the 64 MFMAs (2048 cycles) of chunk n
-// and are first needed after them, so neither the L2 nor the LDS latency is exposed.
-__device__ __forceinline__ void policy_gemm(const float *act, const f32x4 *layer, int c0, int c1, int ct0, int lane,
-                                            f32x4 (&acc)[4][4]) {
+// and are first needed after them, so neither the L2 nor the LDS latency is exposed.  The prefetches are
+// unconditional (the last one is a harmless re-read): a branch around them makes the compiler wait for them
+// at the join.
+__device__ __forceinline__ void policy_gemm(const float *act, const f32x4 *layer, int c0, int c1, int xcol, int ct0, int lane,
+                                            PolicyFrag &f0, f32x4 (&acc)[4][4]) {
     const float *arow = act + (lane & 15) * kPolStride + 4 * (lane >> 4);
-    const f32x4 *brow = layer + (int64_t)ct0 * 64 + lane;
-    PolicyFrag f0, f1;
-    policy_load_frag(f0, arow, brow, c0);
+    PolicyFrag f1;
+    policy_load_a(f0, arow, c0, xcol);
     int ch = c0;
     while (true) {
-        policy_load_frag(f1, arow, brow, ch + 1 < c1 ? ch + 1 : ch);      // unconditional (the last one is a harmless
-        __builtin_amdgcn_sched_barrier(0);                                  // re-read): a branch here would make the
+        const int n1 = ch + 1 < c1 ? ch + 1 : ch;
+        policy_load_b(f1, layer, ct0, lane, n1);
+        policy_load_a(f1, arow, n1, xcol);
         policy_mfma_chunk(f0, acc);
-        __builtin_amdgcn_sched_barrier(0);
+        POLICY_INTERLEAVE();
         if (ch + 1 >= c1) break;
-        policy_load_frag(f0, arow, brow, ch + 2 < c1 ? ch + 2 : ch);      // compiler wait for the prefetch at the join
-        __builtin_amdgcn_sched_barrier(0);
+        const int n2 = ch + 2 < c1 ? ch + 2 : ch;
+        policy_load_b(f0, layer, ct0, lane, n2);
+        policy_load_a(f0, arow, n2, xcol);
         policy_mfma_chunk(f1, acc);
-        __builtin_amdgcn_sched_barrier(0);
+        POLICY_INTERLEAVE();
         ch += 2;
         if (ch >= c1) break;
     }
@@ -220,42 +263,106 @@ __device__ __forceinline__ void policy_store_relu(float *act, int ct0, int lane,
                 act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * (ct0 + ct) + (lane & 15)] = fmaxf(acc[rt][ct][r], 0.0f);
 }
 
+// e / d for 0 <= e < 2^20 and 1 <= d <= 512 without the integer-division sequence
+__device__ __forceinline__ int policy_div(int e, int d, float inv_d) {
+    int q = (int)((float)e * inv_d);
+    q -= (q * d > e) ? 1 : 0;
+    q += ((q + 1) * d <= e) ? 1 : 0;
+    return q;
+}
+
 __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float act[];          // [kPolRows][kPolStride] + 1 int (66 564 B: dynamic)
-    int &tile_max_len = *reinterpret_cast<int *>(act + kPolRows * kPolStride);
+    // LDS: activations [kPolRows][kPolStride], then the packed biases, then one int.  While the LSTM runs, a row is
+    //   cols 0..63 h | 80 raw num_other | 84..87 host | 88+8t..94+8t x_t (t-th observed agent), zeros between
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    float *lds_bias = act + kPolRows * kPolStride;
+    int *wave_max = reinterpret_cast<int *>(lds_bias + kBiasFloats);
+    int &ticket = wave_max[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t row0 = (int64_t)blockIdx.x * kPolRows;
     const int rows_here = p.rows - row0 < kPolRows ? (int)(p.rows - row0) : kPolRows;
-    const int M = p.max_other, in_size = p.in_size;
+    const int M = p.max_other;
     const int step = p.actions_out ? *p.step_counter : 0;
+    POLICY_STAMP(0);
+#ifdef CAVOID_TRACE
+    const unsigned long long trace_c0 = clock64();
+    if (tid == 0 && g_pol_trace)
+        g_pol_trace[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                  ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+    const f32x4 *w_lstm = p.frags + kOffLstm;
+    PolicyFrag f0;
+    policy_load_b(f0, w_lstm, 4 * wave, lane, 4);          // first LSTM step: h == 0, only the input chunk contributes
 
-    // ---- input tile: normalise, park at columns kPolXCol.. (column kPolXCol holds the RAW num_other) ----
-    if (tid == 0) tile_max_len = 0;
-    __syncthreads();
+    // ---- input tile: gather + normalise into the padded layout above ------------------------------------------
+    // One trip to memory: every global load of the prologue (inputs, normalisation vectors, biases) is issued
+    // before the first of them is consumed.
     {
         const float *src = p.x + row0 * p.stride;
-        const int n = rows_here * (int)p.stride;
+        const int wpad = 16 + 8 * M + 8;                   // padded row: [num,0,0,0, host(4), M x (x_t(7),0), 16 zeros]
+        const float inv_wpad = 1.0f / (float)wpad;
+        const int total = kPolRows * wpad;
+        constexpr int U = 12;                              // M = 3: the whole tile in one pass
         int local_max = 0;
-        for (int e = tid; e < kPolRows * (int)p.stride; e += 256) {
-            const int r = e / (int)p.stride, cidx = e - r * (int)p.stride;
-            if (cidx >= in_size) continue;
-            float v = 0.0f;
-            if (e < n && r < rows_here) {
-                v = src[e];
-                if (cidx == 0) {
-                    int len = (int)v;
+        float bias_v[(kBiasFloats + 255) / 256];
+#pragma unroll
+        for (int u = 0; u < (kBiasFloats + 255) / 256; ++u) bias_v[u] = tid + 256 * u < kBiasFloats ? p.bias[tid + 256 * u] : 0.0f;
+        if (tid == 0) {
+            // Two workgroups share a CU (one wavefront of each per SIMD).  Arrival parity on the CU decides a static
+            // priority, so that the pair does not settle into lockstep (same phase at the same time, the matrix
+            // pipe idle while both do their pointwise / barrier phases): without it CU pairs finish anywhere between
+            // 85 and 131 us, with it every pair takes the same time.
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            const uint32_t key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);        // cu_id[11:8] sh_id[12] se_id[15:13]
+            ticket = (int)atomicAdd(p.cu_tickets + key, 1u);
+        }
+        for (int e0 = 0; e0 < total; e0 += 256 * U) {
+            float v[U], av[U], sd[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                  // all the loads of the pass first
+                const int e = e0 + u * 256 + tid;
+                const int r = policy_div(e, wpad, inv_wpad), c = e - r * wpad;
+                int sc = -1;                               // source column of this slot (-1: padding)
+                if (c == 0) sc = 0;
+                else if (c >= 4 && c < 8) sc = c - 3;
+                else if (c >= 8 && c < 8 + 8 * M && (c & 7) != 7) sc = 1 + kPolHost + kPolOther * ((c - 8) >> 3) + (c & 7);
+                const bool in = e < total && sc >= 0 && r < rows_here;
+                dst[u] = e < total ? r * kPolStride + kPolXCol + c : -1;
+                v[u] = in ? src[(int64_t)r * p.stride + sc] : 0.0f;
+                const bool norm = in && sc > 0 && p.avg != nullptr;
+                av[u] = norm ? p.avg[sc] : 0.0f;
+                sd[u] = norm ? p.std[sc] : 1.0f;
+                if (sc != 0) dst[u] |= dst[u] >= 0 ? 0x40000000 : 0;      // tag: not the length column
+            }
+            if (e0 == 0) {
+                for (int e = tid; e < kPolRows * kPolHidden; e += 256) act[(e >> 6) * kPolStride + (e & 63)] = 0.0f;   // h = 0
+#pragma unroll
+                for (int u = 0; u < (kBiasFloats + 255) / 256; ++u)
+                    if (tid + 256 * u < kBiasFloats) lds_bias[tid + 256 * u] = bias_v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (dst[u] < 0) continue;
+                if (!(dst[u] & 0x40000000)) {
+                    int len = (int)v[u];
                     len = len < 0 ? 0 : (len > M ? M : len);
                     local_max = local_max > len ? local_max : len;
-                } else if (p.avg) {
-                    v = (v - p.avg[cidx]) / p.std[cidx];
                 }
+                act[dst[u] & 0x3FFFFFFF] = (v[u] - av[u]) / sd[u];
             }
-            act[r * kPolStride + kPolXCol + cidx] = v;
         }
-        if (local_max > 0) atomicMax(&tile_max_len, local_max);
+        // tile-wide maximum without an initialising barrier: wavefront maxima into 4 LDS slots
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(local_max, d, 64); local_max = o > local_max ? o : local_max; }
+        if (lane == 0) wave_max[wave] = local_max;
     }
     __syncthreads();
+    const int m01 = wave_max[0] > wave_max[1] ? wave_max[0] : wave_max[1], m23 = wave_max[2] > wave_max[3] ? wave_max[2] : wave_max[3];
+    const int tile_max_len = m01 > m23 ? m01 : m23;
     const int steps = tile_max_len;                        // LSTM steps any row of this tile still needs
+    if (ticket & 1) __builtin_amdgcn_s_setprio(1);
+    POLICY_STAMP(5);
 
     // this lane's rows in the C layout and their sequence lengths
     float len_r[4][4];
@@ -265,74 +372,80 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
         for (int r = 0; r < 4; ++r) len_r[rt][r] = act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + kPolXCol];
 
     // ---- LSTM over the observed agents -------------------------------------------------------------------
-    f32x4 cell[4];
+    f32x4 cell[4], hid[4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) cell[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // h = 0 (columns 0..63); columns 64..79 = [x_t(7), 0 x 9]
-    for (int e = tid; e < kPolRows * kPolHidden; e += 256) act[(e >> 6) * kPolStride + (e & 63)] = 0.0f;
-    const f32x4 *w_lstm = p.frags + kOffLstm;
+    for (int rt = 0; rt < 4; ++rt) { cell[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; hid[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int t = 0; t < steps; ++t) {
-        for (int e = tid; e < kPolRows * 16; e += 256) {
-            const int r = e >> 4, k = e & 15;
-            act[r * kPolStride + kPolHidden + k] =
-                k < kPolOther ? act[r * kPolStride + kPolXCol + 1 + kPolHost + kPolOther * t + k] : 0.0f;
-        }
-        __syncthreads();                                   // x_t and the previous step's h are in place
         f32x4 acc[4][4];
-        policy_init_acc(p.bias + kBiasLstm, 4 * wave, lane, acc);
-        policy_gemm(act, w_lstm, t == 0 ? 4 : 0, kChLstm, 4 * wave, lane, acc);     // h == 0 at t == 0
+        policy_init_acc(lds_bias + kBiasLstm, 4 * wave, lane, acc);
+        policy_gemm(act, w_lstm, t == 0 ? 4 : 0, kChLstm, kPolXCol + 8 + 8 * t, 4 * wave, lane, f0, acc);
+        policy_load_b(f0, w_lstm, 4 * wave, lane, 0);      // the next step's first weight fragments
         __syncthreads();                                   // every wavefront has read h
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (len_r[rt][r] > (float)t) {             // dynamic_rnn: rows past their length keep (c, h)
-                    const float gi = acc[rt][0][r], gj = acc[rt][1][r], gf = acc[rt][2][r], go = acc[rt][3][r];
-                    const float c_new = fast_sigmoid(gf) * cell[rt][r] + fast_sigmoid(gi) * fast_tanh(gj);
-                    cell[rt][r] = c_new;
-                    act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * wave + (lane & 15)] = fast_sigmoid(go) * fast_tanh(c_new);
-                }
+                // dynamic_rnn: rows past their own length keep (c, h) -- selects, not branches
+                const bool live = len_r[rt][r] > (float)t;
+                const float gi = acc[rt][0][r], gj = acc[rt][1][r], gf = acc[rt][2][r], go = acc[rt][3][r];
+                const float c_new = fast_sigmoid(gf) * cell[rt][r] + fast_sigmoid(gi) * fast_tanh(gj);
+                const float h_new = fast_sigmoid(go) * fast_tanh(c_new);
+                cell[rt][r] = live ? c_new : cell[rt][r];
+                hid[rt][r] = live ? h_new : hid[rt][r];
+                act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * wave + (lane & 15)] = hid[rt][r];
             }
+        __syncthreads();                                   // the new h is in place
     }
+    POLICY_STAMP(1);
     // ---- layer1 on [h | host] --------------------------------------------------------------------------------
-    for (int e = tid; e < kPolRows * 16; e += 256) {
-        const int r = e >> 4, k = e & 15;
-        act[r * kPolStride + kPolHidden + k] = k < kPolHost ? act[r * kPolStride + kPolXCol + 1 + k] : 0.0f;
-    }
-    __syncthreads();
     {
         f32x4 acc[4][4];
-        policy_init_acc(p.bias + kBiasL1, 4 * wave, lane, acc);
-        policy_gemm(act, p.frags + kOffL1, 0, kChL1, 4 * wave, lane, acc);
+        policy_load_b(f0, p.frags + kOffL1, 4 * wave, lane, 0);
+        policy_init_acc(lds_bias + kBiasL1, 4 * wave, lane, acc);
+        policy_gemm(act, p.frags + kOffL1, 0, kChL1, kPolXCol + 4, 4 * wave, lane, f0, acc);
+        policy_load_b(f0, p.frags + kOffL2, 4 * wave, lane, 0);
         __syncthreads();
         policy_store_relu(act, 4 * wave, lane, acc);
+        __syncthreads();
     }
-    __syncthreads();
+    POLICY_STAMP(2);
     // ---- layer2, fullyconnected1 -----------------------------------------------------------------------------
-#pragma unroll 1
-    for (int l = 0; l < 2; ++l) {
+    {
         f32x4 acc[4][4];
-        policy_init_acc(p.bias + (l == 0 ? kBiasL2 : kBiasFc1), 4 * wave, lane, acc);
-        policy_gemm(act, p.frags + (l == 0 ? kOffL2 : kOffFc1), 0, kChWide, 4 * wave, lane, acc);
+        policy_init_acc(lds_bias + kBiasL2, 4 * wave, lane, acc);
+        policy_gemm(act, p.frags + kOffL2, 0, kChWide, 64, 4 * wave, lane, f0, acc);
+        policy_load_b(f0, p.frags + kOffFc1, 4 * wave, lane, 0);
         __syncthreads();
         policy_store_relu(act, 4 * wave, lane, acc);
         __syncthreads();
     }
+    f32x4 hb[kChHead];                                     // the heads' weight fragments: in flight across the last layer's
+    {                                                      // epilogue and barrier
+        f32x4 acc[4][4];
+        policy_init_acc(lds_bias + kBiasFc1, 4 * wave, lane, acc);
+        policy_gemm(act, p.frags + kOffFc1, 0, kChWide, 64, 4 * wave, lane, f0, acc);
+        const f32x4 *brow = p.frags + kOffHead + lane;
+#pragma unroll
+        for (int ch = 0; ch < kChHead; ++ch) hb[ch] = brow[64 * ch];
+        __syncthreads();
+        policy_store_relu(act, 4 * wave, lane, acc);
+        __syncthreads();
+    }
+    POLICY_STAMP(3);
     // ---- heads: wavefront w does rows 16w..16w+15 x 16 columns (A logits, the value, padding) -----------------
     {
         f32x4 acc[4];
-        const float b = p.bias[kBiasHead + (lane & 15)];
+        const float b = lds_bias[kBiasHead + (lane & 15)];
         acc[0] = f32x4{b, b, b, b};
         acc[1] = acc[2] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float *arow = act + (16 * wave + (lane & 15)) * kPolStride + 4 * (lane >> 4);
-        const f32x4 *brow = p.frags + kOffHead + lane;
-#pragma unroll 4
-        for (int ch = 0; ch < kChHead; ++ch) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 16 * ch);
-            const f32x4 bb = brow[64 * ch];
+        f32x4 ha[kChHead];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bb[s], acc[s], 0, 0, 0);
-        }
+        for (int ch = 0; ch < kChHead; ++ch) ha[ch] = *reinterpret_cast<const f32x4 *>(arow + 16 * ch);
+#pragma unroll
+        for (int ch = 0; ch < kChHead; ++ch)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ch][s], hb[ch][s], acc[s], 0, 0, 0);
         const f32x4 logit = acc[0] + acc[1] + acc[2] + acc[3];
         const int col = lane & 15, A = p.num_actions;
         const float scale = 1.0f / (1.0f + p.min_policy * (float)A);
@@ -379,6 +492,10 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
             }
         }
     }
+    POLICY_STAMP(4);
+#ifdef CAVOID_TRACE
+    if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 8 + 6] = clock64() - trace_c0;   // shader-clock cycles
+#endif
     if (p.actions_out) {                                   // the last workgroup to finish advances the step counter
         __syncthreads();
         if (tid == 0) {

@@ -20,7 +20,7 @@ struct cavoid_policy {
     f32x4 *frags = nullptr;
     float *bias = nullptr, *avg = nullptr, *std = nullptr;
     int32_t *step_counter = nullptr;
-    uint32_t *blocks_done = nullptr;
+    uint32_t *blocks_done = nullptr, *cu_tickets = nullptr;
 };
 
 extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int device, cavoid_policy **out) {
@@ -38,13 +38,14 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_frag = carve((size_t)kPackFrags * sizeof(f32x4)), o_bias = carve(kBiasFloats * sizeof(float));
     const size_t o_avg = carve(h->in_size * sizeof(float)), o_std = carve(h->in_size * sizeof(float));
-    const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t));
+    const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t)), o_tick = carve(kPolCuSlots * sizeof(uint32_t));
     if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return CAVOID_ENOMEM; }
     if (hipMemset(h->slab, 0, off) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP; }
     unsigned char *b = static_cast<unsigned char *>(h->slab);
     h->frags = reinterpret_cast<f32x4 *>(b + o_frag); h->bias = reinterpret_cast<float *>(b + o_bias);
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
+    h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
     // 66.5 KB of LDS per workgroup: above the 64 KB static limit, so it is dynamic and opted into here
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPolLdsBytes) != hipSuccess) {
@@ -104,10 +105,17 @@ extern "C" int cavoid_policy_forward(cavoid_policy *h, const float *x, int64_t r
     a.frags = h->frags; a.bias = h->bias; a.min_policy = h->min_policy; a.p_out = p_out; a.v_out = v_out;
     a.actions_out = actions_out; a.greedy = greedy ? 1 : 0;
     a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
-    a.step_counter = h->step_counter; a.blocks_done = h->blocks_done;
+    a.step_counter = h->step_counter; a.blocks_done = h->blocks_done; a.cu_tickets = h->cu_tickets;
     const int64_t blocks = (rows + kPolRows - 1) / kPolRows;
     if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
     hipLaunchKernelGGL(policy_forward_kernel, dim3((unsigned)blocks), dim3(256), kPolLdsBytes, static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }
+
+#ifdef CAVOID_TRACE
+extern "C" int cavoid_policy_debug_trace(unsigned long long *dev_ptr) {
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pol_trace), &dev_ptr, sizeof(dev_ptr)));
+    return CAVOID_OK;
+}
+#endif
