@@ -97,44 +97,89 @@ def python_baseline(N: int, budget_s: float):
             "sample": "oracle/cavoid_oracle.py, 1 world x %d agents, %d steps" % (N, steps)}
 
 
-def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int = 300, train_every: int = 5, max_rows: int = 4096):
-    """BASELINE configs[4]: everything on the device -- policy inference (PyTorch-ROCm NetworkVP_rnn), action
-    sampling, env.step, experience rings / n-step returns (HIP), and an Adam step on the drained rows every
-    `train_every` env steps (policy replica per GPU, no collective).  Reports the reference's PPS definition:
-    learning-agent steps per second (ProcessStats.py:54-56)."""
+def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int = 240, train_rows: int = 32768):
+    """BASELINE configs[4]: everything on the device -- policy inference + action selection (fused f32-MFMA kernel,
+    cavoid_policy_*), env.step, experience store / n-step returns (HIP), and Adam steps (PyTorch-ROCm autograd) on
+    EVERY drained row, in minibatches of `train_rows` (policy replica per GPU, no collective).  Reports the
+    reference's PPS definition: learning-agent steps per second (ProcessStats.py:54-56), for three regimes:
+    actors only (PLAY_MODE: no trainer), the full loop, and the full loop acting through the PyTorch graph."""
     import torch
     from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
-    env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
-    net = NetworkVP_rnn(cfg).to(device)
-    trainer = A3CTrainer(net)
-    train_every = 4                                          # env steps per hipGraph replay (even)
-    roll = BatchedRollout(env, net.predict_p_and_v, reflush_done=False)
-    roll.reset()
-    roll.capture(steps_per_graph=train_every)                # policy + sampling + env.step + bookkeeping as ONE graph
+    per_graph = 4                                            # env steps per hipGraph replay (even)
 
-    def run(n_replays):
-        for _ in range(n_replays):
-            roll.replay(1)
-            b = roll.drain()
-            if len(b) > 0:
-                trainer.train(b.x[:max_rows], b.r[:max_rows], b.a[:max_rows])
-        return n_replays * train_every * W * N               # all agents learn in this workload
-    run(8)
-    sync_all()
-    t0 = time.perf_counter()
-    frames = run(steps // train_every)
-    sync_all()
-    dt = time.perf_counter() - t0
-    steps = (steps // train_every) * train_every
-    out = {"learning_agent_steps_per_s_per_gpu": frames / dt, "env_steps": steps, "ms_per_env_step": dt * 1e3 / steps,
-           "training_steps": trainer.training_step, "train_rows_cap": max_rows, "steps_per_graph": train_every,
-           "policy_dtype": "f32",
-           "note": "policy+sampling+env+rollout (one hipGraph per %d steps) + Adam on one GPU; reference PPS datum: 563 "
-                   "(32 procs, laptop CPU)" % train_every}
-    roll.close()
-    env.close()
-    return out
+    def regime(fused: bool, train: bool):
+        env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
+        net = NetworkVP_rnn(cfg).to(device)
+        trainer = A3CTrainer(net)
+        pol = FusedPolicy(net, seed=rank) if fused else None
+        roll = BatchedRollout(env, pol if fused else net.predict_p_and_v, reflush_done=False)
+        roll.reset()
+        roll.capture(steps_per_graph=per_graph)              # policy + sampling + env.step + bookkeeping as ONE graph
+        rows = [0]
+
+        def run(n_replays):
+            for _ in range(n_replays):
+                roll.replay(1)
+                if not train:
+                    continue
+                b = roll.drain()
+                for lo in range(0, len(b), train_rows):
+                    trainer.train(b.x[lo:lo + train_rows], b.r[lo:lo + train_rows], b.a[lo:lo + train_rows])
+                rows[0] += len(b)
+                if pol is not None and len(b):
+                    pol.refresh()
+            return n_replays * per_graph * W * N             # all agents learn in this workload
+        run(8)
+        rows[0] = 0
+        sync_all()
+        t0 = time.perf_counter()
+        frames = run(steps // per_graph)
+        sync_all()
+        dt = time.perf_counter() - t0
+        n = (steps // per_graph) * per_graph
+        out = {"learning_agent_steps_per_s_per_gpu": frames / dt, "ms_per_env_step": dt * 1e3 / n, "env_steps": n,
+               "rows_trained": rows[0], "training_steps": trainer.training_step}
+        roll.close()
+        env.close()
+        return out
+    def policy_kernel():
+        """The fused inference kernel alone, on real observations: HIP events on the launch stream."""
+        env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
+        net = NetworkVP_rnn(cfg).to(device)
+        pol = FusedPolicy(net, seed=rank)
+        obs = env.reset().view(W * N, -1)[:, 1:]
+        M = net.max_others
+
+        def timed(fn, n=100):
+            for _ in range(10):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1) * 1e3 / n
+        fused_us = timed(lambda: pol.act(obs))
+        torch_us = timed(lambda: net.predict_p_and_v(obs.contiguous()), 30)
+        lens = obs[:, 0].clamp(0, M)
+        # issued MFMA work: 16-wide K chunks x 256 columns; LSTM step 0 needs the input chunk only; a 64-row tile runs as
+        # many LSTM steps as its longest row needs
+        steps = lens.view(-1, 64).max(dim=1).values.mean().item() if (W * N) % 64 == 0 else float(M)
+        chunks = (1 + 5 * max(steps - 1, 0)) + 5 + 16 + 16 + 1
+        flop = W * N * chunks * 16 * 256 * 2
+        env.close()
+        return {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us, "issued_TFLOPs": flop / fused_us * 1e-6,
+                "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3, "bound": "mfma", "dtype": "f32",
+                "kernel": "cavoid::policy_forward_kernel"}
+    res = {"policy_kernel": policy_kernel(), "actors_only_fused_policy": regime(True, False), "full_loop_fused_policy": regime(True, True),
+           "full_loop_torch_policy": regime(False, True),
+           "steps_per_graph": per_graph, "train_rows_per_adam_step": train_rows, "policy_dtype": "f32",
+           "note": "one hipGraph per %d env steps (policy + action selection + env + experience store); every drained row "
+                   "is trained on once; reference PPS datum: 563 (32 procs, laptop CPU)" % per_graph}
+    return res
 
 
 def main() -> None:

@@ -21,6 +21,7 @@ from ..batched_env import BatchedCollisionAvoidanceEnv
 from ..config import EnvConfig
 from ..sharding import shard_range
 from .network import A3CTrainer, NetworkVP_rnn
+from .policy_kernel import FusedPolicy
 from .rollout import BatchedRollout
 from .stats import EpisodeStats
 
@@ -32,7 +33,10 @@ def main(argv=None) -> None:
     ap.add_argument("--min-agents", type=int, default=2)
     ap.add_argument("--episodes", type=int, default=20000, help="stop after this many finished episodes (all ranks)")
     ap.add_argument("--steps-per-graph", type=int, default=4)
-    ap.add_argument("--train-rows", type=int, default=8192, help="rows per Adam step (cap)")
+    ap.add_argument("--train-rows", type=int, default=32768,
+                    help="rows per Adam step: every drained row is trained on exactly once, in minibatches of this size")
+    ap.add_argument("--torch-policy", action="store_true",
+                    help="act with the PyTorch-ROCm graph of the network instead of the fused MFMA kernel (rnn arch only)")
     ap.add_argument("--lr", type=float, default=2e-5)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--print-every", type=int, default=2000, help="stats line every n episodes (rank 0)")
@@ -60,7 +64,8 @@ def main(argv=None) -> None:
                                        gen_min_agents=min(args.min_agents, N))
     net = NetworkVP_rnn(cfg, seed=args.seed).to(device)
     trainer = A3CTrainer(net, learning_rate=args.lr)
-    roll = BatchedRollout(env, net.predict_p_and_v, reflush_done=args.faithful_reflush)
+    fused = None if (args.torch_policy or net.arch != "rnn") else FusedPolicy(net, seed=1000 * args.seed + rank)
+    roll = BatchedRollout(env, fused if fused is not None else net.predict_p_and_v, reflush_done=args.faithful_reflush)
     stats = EpisodeStats(print_every=args.print_every if rank == 0 else 0, agents=count)
     roll.reset()
     roll.capture(steps_per_graph=args.steps_per_graph)
@@ -69,10 +74,19 @@ def main(argv=None) -> None:
     while True:
         roll.replay(1)
         batch = roll.drain()
-        if len(batch) > 0 or size > 1:            # multi-GPU: every rank must enter the gradient all-reduce
-            n = min(len(batch), args.train_rows)
-            trainer.train(batch.x[:n], batch.r[:n], batch.a[:n])
+        # multi-GPU: every rank must enter the same number of gradient all-reduces
+        n_chunks = max(1, -(-len(batch) // args.train_rows)) if (len(batch) > 0 or size > 1) else 0
+        if size > 1:
+            done_flag[0] = float(n_chunks)
+            dist.all_reduce(done_flag, op=dist.ReduceOp.MAX)
+            n_chunks = int(done_flag.item())
+        for k in range(n_chunks):
+            lo, hi = k * args.train_rows, min((k + 1) * args.train_rows, len(batch))
+            lo = min(lo, hi)
+            trainer.train(batch.x[lo:hi], batch.r[lo:hi], batch.a[lo:hi])
             stats.add_training_steps(1)
+        if fused is not None and n_chunks:
+            fused.refresh()                       # the actors see the new weights from the next replay on
         stats.add_episodes(roll.drain_episodes().tolist())
         finished = stats.episode_count
         if size > 1:
