@@ -37,6 +37,41 @@ TF_VARIABLE_NAMES = {
 }
 
 
+class _SplitKLinear(torch.autograd.Function):
+    """``x @ w (+ b)`` whose weight gradient ``x^T @ g`` is computed split-K: the trainer's batches are tens of
+    thousands of rows against 256-wide layers, so the plain library GEMM for [in, B] x [B, out] launches
+    (in/32) x (out/64) = 32 workgroups on a 256-CU part and runs at ~12 % of it (140 us per layer at B = 32768).
+    Slicing B into S batched GEMMs fills the chip; the S partial [in, out] products are summed afterwards."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, w) if b is not None else x @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ w.t() if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            B, S = x.shape[0], 1
+            while S < 64 and B % (2 * S) == 0 and B // (2 * S) >= 256:
+                S *= 2
+            if S > 1 and x.is_cuda:
+                gw = torch.bmm(x.reshape(S, B // S, -1).transpose(1, 2), g.view(S, B // S, -1)).sum(dim=0)
+            else:
+                gw = x.t() @ g
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=0)
+        return gx, gw, gb
+
+
+def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _SplitKLinear.apply(x, w, b)
+
+
 def _glorot(shape, gen) -> torch.Tensor:
     limit = float(np.sqrt(6.0 / (shape[0] + shape[1])))
     return (torch.rand(shape, generator=gen) * 2.0 - 1.0) * limit
@@ -120,12 +155,17 @@ class NetworkVP_rnn(nn.Module):
         lengths = x[:, 0]
         host = xn[:, 1:1 + self.HOST]
         others = xn[:, 1 + self.HOST:].reshape(-1, self.max_others, self.OTHER)
-        h = self._lstm_final_h(others, lengths) if self.arch == "rnn" else self._weight_sharing_summary(others, lengths)
-        z = torch.relu(torch.addmm(self.layer1_bias, torch.cat([host, h], dim=1), self.layer1_kernel))
-        z = torch.relu(torch.addmm(self.layer2_bias, z, self.layer2_kernel))
-        z = torch.relu(torch.addmm(self.fc1_bias, z, self.fc1_kernel))
-        v = torch.addmm(self.v_bias, z, self.v_kernel).squeeze(1)
-        logits = torch.addmm(self.p_bias, z, self.p_kernel)
+        if self.arch != "rnn":
+            h = self._weight_sharing_summary(others, lengths)
+        elif x.is_cuda:          # same recurrence through ATen's fused (and differentiable) LSTM-cell kernel: the trainer's
+            h = self._lstm_final_h_fused(others, lengths)      # forward + backward drop ~25 pointwise launches per step
+        else:
+            h = self._lstm_final_h(others, lengths)
+        z = torch.relu(_linear(torch.cat([host, h], dim=1), self.layer1_kernel, self.layer1_bias))
+        z = torch.relu(_linear(z, self.layer2_kernel, self.layer2_bias))
+        z = torch.relu(_linear(z, self.fc1_kernel, self.fc1_bias))
+        v = _linear(z, self.v_kernel, self.v_bias).squeeze(1)
+        logits = _linear(z, self.p_kernel, self.p_bias)
         p = (torch.softmax(logits, dim=1) + self.min_policy) / (1.0 + self.min_policy * self.num_actions)
         return logits, p, v
 
@@ -138,12 +178,12 @@ class NetworkVP_rnn(nn.Module):
         w = self.lstm_kernel.index_select(1, perm)
         bias = self.lstm_bias.index_select(0, perm).clone()
         bias[H:2 * H] += 1.0                                   # tf.contrib.rnn.LSTMCell forget_bias
-        xproj = torch.addmm(bias, seq.reshape(B * M, self.OTHER), w[:self.OTHER]).view(B, M, 4 * H)
+        xproj = _linear(seq.reshape(B * M, self.OTHER), w[:self.OTHER], bias).view(B, M, 4 * H)
         wh = w[self.OTHER:]
         h = seq.new_zeros((B, H))
         c = seq.new_zeros((B, H))
         for t in range(M):
-            h_new, c_new, _ = torch.ops.aten._thnn_fused_lstm_cell(xproj[:, t].contiguous(), h @ wh, c)
+            h_new, c_new, _ = torch.ops.aten._thnn_fused_lstm_cell(xproj[:, t].contiguous(), _linear(h, wh), c)
             live = (lengths > t).unsqueeze(1)
             c = torch.where(live, c_new, c)
             h = torch.where(live, h_new, h)
@@ -204,7 +244,9 @@ class A3CTrainer(object):
     def __init__(self, model: NetworkVP_rnn, learning_rate: float = 2e-5, group=None, distributed: Optional[bool] = None):
         import torch.distributed as dist
         self.model = model
-        self.opt = torch.optim.Adam(model.parameters(), lr=learning_rate, eps=1e-8)     # tf.train.AdamOptimizer defaults
+        on_gpu = next(model.parameters()).is_cuda
+        self.opt = torch.optim.Adam(model.parameters(), lr=learning_rate, eps=1e-8,     # tf.train.AdamOptimizer defaults
+                                    fused=True if on_gpu else None)                     # one kernel for all 12 variables
         self.training_step = 0
         self.frame_counter = 0
         self.group = group

@@ -26,6 +26,26 @@ from .rollout import BatchedRollout
 from .stats import EpisodeStats
 
 
+def save_checkpoint(directory: str, episode: int, net: NetworkVP_rnn, trainer: A3CTrainer) -> str:
+    """``NetworkVPCore.save(episode)`` (:235-236): ``<dir>/network_%08d`` -- here a torch file with the variables under
+    their TensorFlow names' attributes, the Adam state and the episode count."""
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, "network_%08d.pt" % episode)
+    torch.save({"episode": int(episode), "model": net.state_dict(), "optimizer": trainer.opt.state_dict(),
+                "training_step": trainer.training_step}, path)
+    return path
+
+
+def load_checkpoint(path: str, net: NetworkVP_rnn, trainer: A3CTrainer, device) -> int:
+    """``NetworkVPCore.load`` (:238-262): returns the episode number the run resumes from."""
+    ck = torch.load(path, map_location=device)
+    net.load_state_dict(ck["model"])
+    if "optimizer" in ck:
+        trainer.opt.load_state_dict(ck["optimizer"])
+    trainer.training_step = int(ck.get("training_step", 0))
+    return int(ck.get("episode", 0))
+
+
 def main(argv=None) -> None:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--worlds", type=int, default=8192, help="total worlds over all GPUs")
@@ -37,7 +57,15 @@ def main(argv=None) -> None:
                     help="rows per Adam step: every drained row is trained on exactly once, in minibatches of this size")
     ap.add_argument("--torch-policy", action="store_true",
                     help="act with the PyTorch-ROCm graph of the network instead of the fused MFMA kernel (rnn arch only)")
-    ap.add_argument("--lr", type=float, default=2e-5)
+    ap.add_argument("--lr", type=float, default=2e-5, help="LEARNING_RATE_RL_START")
+    ap.add_argument("--lr-end", type=float, default=None, help="LEARNING_RATE_RL_END (default: no annealing)")
+    ap.add_argument("--beta", type=float, default=1e-4, help="BETA_START (entropy regularisation)")
+    ap.add_argument("--beta-end", type=float, default=None, help="BETA_END")
+    ap.add_argument("--annealing-episodes", type=int, default=None, help="ANNEALING_EPISODE_COUNT (default: --episodes)")
+    ap.add_argument("--play", action="store_true", help="PLAY_MODE: argmax actions, trainers disabled (Server.py:134-137)")
+    ap.add_argument("--checkpoint-dir", default=None, help="save network_%%08d.pt here (SAVE_MODELS)")
+    ap.add_argument("--save-every", type=int, default=50000, help="SAVE_FREQUENCY, in episodes")
+    ap.add_argument("--load", default=None, help="checkpoint file to start from (LOAD_CHECKPOINT)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--print-every", type=int, default=2000, help="stats line every n episodes (rank 0)")
     ap.add_argument("--faithful-reflush", action="store_true", help="keep the reference's post-done re-flush quirk")
@@ -64,18 +92,32 @@ def main(argv=None) -> None:
                                        gen_min_agents=min(args.min_agents, N))
     net = NetworkVP_rnn(cfg, seed=args.seed).to(device)
     trainer = A3CTrainer(net, learning_rate=args.lr)
+    episodes_before = 0
+    if args.load:
+        episodes_before = load_checkpoint(args.load, net, trainer, device)
+    steps_before = trainer.training_step
     fused = None if (args.torch_policy or net.arch != "rnn") else FusedPolicy(net, seed=1000 * args.seed + rank)
-    roll = BatchedRollout(env, fused if fused is not None else net.predict_p_and_v, reflush_done=args.faithful_reflush)
+    roll = BatchedRollout(env, fused if fused is not None else net.predict_p_and_v, reflush_done=args.faithful_reflush,
+                          greedy=args.play)
     stats = EpisodeStats(print_every=args.print_every if rank == 0 else 0, agents=count)
+    anneal_over = args.annealing_episodes or args.episodes
+    next_save = episodes_before + args.save_every
+    finished = 0
     roll.reset()
     roll.capture(steps_per_graph=args.steps_per_graph)
     done_flag = torch.zeros(1, device=device)
     t0 = time.time()
     while True:
+        # linear annealing of the learning rate and the entropy weight over the episode count (Server.py:139-147)
+        frac = min(finished, anneal_over - 1) / float(anneal_over)
+        trainer.opt.param_groups[0]["lr"] = args.lr + ((args.lr_end if args.lr_end is not None else args.lr) - args.lr) * frac
+        net.beta = args.beta + ((args.beta_end if args.beta_end is not None else args.beta) - args.beta) * frac
         roll.replay(1)
         batch = roll.drain()
         # multi-GPU: every rank must enter the same number of gradient all-reduces
         n_chunks = max(1, -(-len(batch) // args.train_rows)) if (len(batch) > 0 or size > 1) else 0
+        if args.play:
+            n_chunks = 0
         if size > 1:
             done_flag[0] = float(n_chunks)
             dist.all_reduce(done_flag, op=dist.ReduceOp.MAX)
@@ -93,12 +135,17 @@ def main(argv=None) -> None:
             done_flag[0] = float(finished)
             dist.all_reduce(done_flag)
             finished = int(done_flag.item())
+        if args.checkpoint_dir and rank == 0 and not args.play and episodes_before + finished >= next_save:
+            save_checkpoint(args.checkpoint_dir, episodes_before + finished, net, trainer)      # Server.save_model (:126-127)
+            next_save += args.save_every
         if finished >= args.episodes:
             break
+    if args.checkpoint_dir and rank == 0 and not args.play:
+        save_checkpoint(args.checkpoint_dir, episodes_before + finished, net, trainer)
     if rank == 0:
         dt = time.time() - t0
         print("finished %d episodes in %.1f s: %.0f learning-agent-steps/s per GPU, rolling reward %.4f, %d training steps"
-              % (finished, dt, stats.total_frame_count / dt, stats.roll_reward_log, trainer.training_step), flush=True)
+              % (finished, dt, stats.total_frame_count / dt, stats.roll_reward_log, trainer.training_step - steps_before), flush=True)
     roll.close()
     env.close()
     if size > 1:

@@ -172,3 +172,24 @@ def test_rollout_with_fused_policy_in_a_graph():
     assert len(torch.unique(batch.a_index)) == 11
     eps = roll.drain_episodes()
     assert eps.shape[0] > 100
+
+
+def test_train_cli_saves_resumes_and_plays(tmp_path, capsys):
+    """The training loop end to end on one GPU: trains (every drained row), writes network_%08d.pt, resumes from it and
+    runs PLAY_MODE (argmax, trainers off) on the loaded weights."""
+    import glob
+    from rl_collision_avoidance_amd.ga3c import train
+    ck = str(tmp_path / "ck")
+    train.main(["--worlds", "256", "--episodes", "600", "--print-every", "0", "--checkpoint-dir", ck, "--save-every", "300",
+                "--train-rows", "4096"])
+    out = capsys.readouterr().out
+    assert "finished" in out and "training steps" in out
+    files = sorted(glob.glob(ck + "/network_*.pt"))
+    assert len(files) >= 2
+    state = torch.load(files[-1], map_location="cpu")
+    assert state["episode"] >= 600 and state["training_step"] > 0 and "lstm_kernel" in state["model"]
+    train.main(["--worlds", "256", "--episodes", "200", "--print-every", "0", "--load", files[-1], "--lr-end", "1e-5"])
+    assert "finished" in capsys.readouterr().out
+    train.main(["--worlds", "256", "--episodes", "200", "--print-every", "0", "--load", files[-1], "--play"])
+    out = capsys.readouterr().out
+    assert "finished" in out and " 0 training steps" in out
