@@ -29,7 +29,6 @@ namespace cavoid {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kPolRows = 64;           // rows per workgroup
 constexpr int kPolStride = 260;        // LDS row stride in floats (260 % 64 == 4)
 constexpr int kPolHidden = 64, kPolWidth = 256, kPolHost = 4, kPolOther = 7;
 constexpr int kPolMaxOthers = 19;      // the padded input row parked at LDS columns 80.. must fit: 80 + 16 + 8M + 8 <= 260
@@ -47,7 +46,9 @@ constexpr int64_t kOffHead = kOffFc1 + kChWide * kFragPerChunk;  // one column t
 constexpr int64_t kPackFrags = kOffHead + kChHead * 64;
 // biases, in packed column order: lstm 256 (forget bias folded in), l1 256, l2 256, fc1 256, head 16
 constexpr int kBiasLstm = 0, kBiasL1 = 256, kBiasL2 = 512, kBiasFc1 = 768, kBiasHead = 1024, kBiasFloats = 1040;
-constexpr size_t kPolLdsBytes = (size_t)(kPolRows * kPolStride + kBiasFloats + 8) * sizeof(float);   // 70 752 B: 2 workgroups per CU
+constexpr size_t policy_lds_bytes(int row_tiles) {       // 64 rows: 70 752 B (2 workgroups per CU); 32 rows: 37 472 B (4 per CU)
+    return (size_t)(16 * row_tiles * kPolStride + kBiasFloats + 8) * sizeof(float);
+}
 
 struct PolicyWeights {                 // device pointers, TensorFlow layout ([in, out] kernels)
     const float *lstm_kernel, *lstm_bias;      // [7+64, 256] rows: 7 inputs then 64 hidden; gate order i, j, f, o
@@ -122,12 +123,12 @@ __global__ void __launch_bounds__(256) policy_pack_kernel(const PolicyWeights w,
 }
 
 // Development aid (never in the product build): -DCAVOID_TRACE makes every workgroup record the constant-rate
-// wall clock at its phase boundaries and the CU it ran on into g_pol_trace[block*8 + k] (tools/trace_policy.py).
+// wall clock at its phase boundaries and the CU it ran on into g_pol_trace[block*16 + k] (tools/trace_policy.py).
 #ifdef CAVOID_TRACE
 __device__ unsigned long long *g_pol_trace = nullptr;
 #define POLICY_STAMP(k)                                                                                      \
     do {                                                                                                     \
-        if (threadIdx.x == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();     \
+        if (threadIdx.x == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();     \
     } while (0)
 #else
 #define POLICY_STAMP(k) do { } while (0)
@@ -170,48 +171,55 @@ __device__ __forceinline__ uint32_t policy_philox_x(uint32_t c0, uint32_t c1, ui
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-// One 16-wide K chunk of fragments: 4 row tiles of A (LDS) and 4 column tiles of B (packed weights, L2).
-struct PolicyFrag { f32x4 a[4], b[4]; };
+// One 16-wide K chunk of fragments: RT row tiles of A (LDS) and 4 column tiles of B (packed weights, L2).
+// RT = row tiles per workgroup (16*RT rows): 4 -> 64 rows, 2 workgroups per CU; 2 -> 32 rows, 4 workgroups per CU.
+template <int RT>
+struct PolicyFrag { f32x4 a[RT], b[4]; };
 
 // A fragments of chunk ch start at LDS column 16*ch, except that chunk 4 (the "input" chunk of the two 80-wide
 // layers) starts at `xcol`: the LSTM reads x_t and layer1 reads the host state where the prologue parked them.
-__device__ __forceinline__ void policy_load_a(PolicyFrag &f, const float *arow, int ch, int xcol) {
+template <int RT>
+__device__ __forceinline__ void policy_load_a(PolicyFrag<RT> &f, const float *arow, int ch, int xcol) {
     const int col = ch == 4 ? xcol : 16 * ch;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) f.a[t] = *reinterpret_cast<const f32x4 *>(arow + 16 * t * kPolStride + col);
+    for (int t = 0; t < RT; ++t) f.a[t] = *reinterpret_cast<const f32x4 *>(arow + 16 * t * kPolStride + col);
 }
 
-__device__ __forceinline__ void policy_load_b(PolicyFrag &f, const f32x4 *layer, int ct0, int lane, int ch) {
+template <int RT>
+__device__ __forceinline__ void policy_load_b(PolicyFrag<RT> &f, const f32x4 *layer, int ct0, int lane, int ch) {
     const f32x4 *brow = layer + (int64_t)ct0 * 64 + lane;
 #pragma unroll
     for (int t = 0; t < 4; ++t) f.b[t] = brow[(int64_t)ch * kFragPerChunk + 64 * t];
 }
 
-__device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag &f, f32x4 (&acc)[4][4]) {
+template <int RT>
+__device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag<RT> &f, f32x4 (&acc)[RT][4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[rt][s], f.b[ct][s], acc[rt][ct], 0, 0, 0);
 }
 
-// Issue order inside one chunk: the 4 weight loads and the 4 LDS reads of the NEXT chunk go out one at a time in the
-// shadow of the first 32 MFMAs (a wavefront can issue a few other instructions per 32-cycle MFMA slot; clustered at
-// the chunk boundary they cost ~350 cycles per 2048), the last 32 MFMAs cover their latency.
-#define POLICY_INTERLEAVE()                                          \
-    do {                                                             \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {           \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       \
-        }                                                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {           \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       \
-        }                                                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);          \
-    } while (0)
+// Issue order inside one chunk (16*RT MFMAs): the 4 weight loads and the RT LDS reads of the NEXT chunk go out one
+// at a time, each after RT MFMAs (a wavefront can issue a few other instructions per 32-cycle MFMA slot; clustered at
+// the chunk boundary they cost ~350 cycles per chunk), the remaining MFMAs cover their latency.
+template <int RT>
+__device__ __forceinline__ void policy_interleave() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 * RT - RT * (4 + RT), 0);
+}
 
 // acc[rt][ct] += A(rows 16rt.., k chunks [c0, c1)) x B(column tiles ct0..ct0+3 of the packed layer).
 // f0.b must already hold chunk c0's weight fragments (policy_load_b, issued BEFORE the barrier that publishes
@@ -220,10 +228,11 @@ __device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag &f, f32x4 (&a
 // and are first needed after them, so neither the L2 nor the LDS latency is exposed.  The prefetches are
 // unconditional (the last one is a harmless re-read): a branch around them makes the compiler wait for them
 // at the join.
+template <int RT>
 __device__ __forceinline__ void policy_gemm(const float *act, const f32x4 *layer, int c0, int c1, int xcol, int ct0, int lane,
-                                            PolicyFrag &f0, f32x4 (&acc)[4][4]) {
+                                            PolicyFrag<RT> &f0, f32x4 (&acc)[RT][4]) {
     const float *arow = act + (lane & 15) * kPolStride + 4 * (lane >> 4);
-    PolicyFrag f1;
+    PolicyFrag<RT> f1;
     policy_load_a(f0, arow, c0, xcol);
     int ch = c0;
     while (true) {
@@ -231,31 +240,33 @@ __device__ __forceinline__ void policy_gemm(const float *act, const f32x4 *layer
         policy_load_b(f1, layer, ct0, lane, n1);
         policy_load_a(f1, arow, n1, xcol);
         policy_mfma_chunk(f0, acc);
-        POLICY_INTERLEAVE();
+        policy_interleave<RT>();
         if (ch + 1 >= c1) break;
         const int n2 = ch + 2 < c1 ? ch + 2 : ch;
         policy_load_b(f0, layer, ct0, lane, n2);
         policy_load_a(f0, arow, n2, xcol);
         policy_mfma_chunk(f1, acc);
-        POLICY_INTERLEAVE();
+        policy_interleave<RT>();
         ch += 2;
         if (ch >= c1) break;
     }
 }
 
-__device__ __forceinline__ void policy_init_acc(const float *bias, int ct0, int lane, f32x4 (&acc)[4][4]) {
+template <int RT>
+__device__ __forceinline__ void policy_init_acc(const float *bias, int ct0, int lane, f32x4 (&acc)[RT][4]) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const float b = bias[16 * (ct0 + ct) + (lane & 15)];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = f32x4{b, b, b, b};
+        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = f32x4{b, b, b, b};
     }
 }
 
 // relu(acc) -> act[row][col]: lane holds col = 16*(ct0+ct) + lane%16, rows 16rt + 4*(lane/16) + r
-__device__ __forceinline__ void policy_store_relu(float *act, int ct0, int lane, const f32x4 (&acc)[4][4]) {
+template <int RT>
+__device__ __forceinline__ void policy_store_relu(float *act, int ct0, int lane, const f32x4 (&acc)[RT][4]) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -271,28 +282,30 @@ __device__ __forceinline__ int policy_div(int e, int d, float inv_d) {
     return q;
 }
 
-__global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs p) {
-    // LDS: activations [kPolRows][kPolStride], then the packed biases, then one int.  While the LSTM runs, a row is
+template <int RT>
+__global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(const PolicyArgs p) {
+    constexpr int kRows = 16 * RT;
+    // LDS: activations [kRows][kPolStride], then the packed biases, then one int.  While the LSTM runs, a row is
     //   cols 0..63 h | 80 raw num_other | 84..87 host | 88+8t..94+8t x_t (t-th observed agent), zeros between
     extern __shared__ __attribute__((aligned(16))) float act[];
-    float *lds_bias = act + kPolRows * kPolStride;
+    float *lds_bias = act + kRows * kPolStride;
     int *wave_max = reinterpret_cast<int *>(lds_bias + kBiasFloats);
     int &ticket = wave_max[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t row0 = (int64_t)blockIdx.x * kPolRows;
-    const int rows_here = p.rows - row0 < kPolRows ? (int)(p.rows - row0) : kPolRows;
+    const int64_t row0 = (int64_t)blockIdx.x * kRows;
+    const int rows_here = p.rows - row0 < kRows ? (int)(p.rows - row0) : kRows;
     const int M = p.max_other;
     const int step = p.actions_out ? *p.step_counter : 0;
     POLICY_STAMP(0);
 #ifdef CAVOID_TRACE
     const unsigned long long trace_c0 = clock64();
     if (tid == 0 && g_pol_trace)
-        g_pol_trace[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+        g_pol_trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #endif
     const f32x4 *w_lstm = p.frags + kOffLstm;
-    PolicyFrag f0;
-    policy_load_b(f0, w_lstm, 4 * wave, lane, 4);          // first LSTM step: h == 0, only the input chunk contributes
+    PolicyFrag<RT> f0;
+    policy_load_b<RT>(f0, w_lstm, 4 * wave, lane, 4);          // first LSTM step: h == 0, only the input chunk contributes
 
     // ---- input tile: gather + normalise into the padded layout above ------------------------------------------
     // One trip to memory: every global load of the prologue (inputs, normalisation vectors, biases) is issued
@@ -301,8 +314,8 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
         const float *src = p.x + row0 * p.stride;
         const int wpad = 16 + 8 * M + 8;                   // padded row: [num,0,0,0, host(4), M x (x_t(7),0), 16 zeros]
         const float inv_wpad = 1.0f / (float)wpad;
-        const int total = kPolRows * wpad;
-        constexpr int U = 12;                              // M = 3: the whole tile in one pass
+        const int total = kRows * wpad;
+        constexpr int U = 3 * RT;                          // M = 3: the whole tile in one pass
         int local_max = 0;
         float bias_v[(kBiasFloats + 255) / 256];
 #pragma unroll
@@ -336,7 +349,7 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
                 if (sc != 0) dst[u] |= dst[u] >= 0 ? 0x40000000 : 0;      // tag: not the length column
             }
             if (e0 == 0) {
-                for (int e = tid; e < kPolRows * kPolHidden; e += 256) act[(e >> 6) * kPolStride + (e & 63)] = 0.0f;   // h = 0
+                for (int e = tid; e < kRows * kPolHidden; e += 256) act[(e >> 6) * kPolStride + (e & 63)] = 0.0f;   // h = 0
 #pragma unroll
                 for (int u = 0; u < (kBiasFloats + 255) / 256; ++u)
                     if (tid + 256 * u < kBiasFloats) lds_bias[tid + 256 * u] = bias_v[u];
@@ -365,24 +378,27 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
     POLICY_STAMP(5);
 
     // this lane's rows in the C layout and their sequence lengths
-    float len_r[4][4];
+    float len_r[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) len_r[rt][r] = act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + kPolXCol];
 
     // ---- LSTM over the observed agents -------------------------------------------------------------------
-    f32x4 cell[4], hid[4];
+    f32x4 cell[RT], hid[RT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) { cell[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; hid[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int rt = 0; rt < RT; ++rt) { cell[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; hid[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int t = 0; t < steps; ++t) {
-        f32x4 acc[4][4];
+        f32x4 acc[RT][4];
         policy_init_acc(lds_bias + kBiasLstm, 4 * wave, lane, acc);
+        if (t == 1) POLICY_STAMP(8);
         policy_gemm(act, w_lstm, t == 0 ? 4 : 0, kChLstm, kPolXCol + 8 + 8 * t, 4 * wave, lane, f0, acc);
-        policy_load_b(f0, w_lstm, 4 * wave, lane, 0);      // the next step's first weight fragments
+        if (t == 1) POLICY_STAMP(9);
+        policy_load_b<RT>(f0, w_lstm, 4 * wave, lane, 0);      // the next step's first weight fragments
         __syncthreads();                                   // every wavefront has read h
+        if (t == 1) POLICY_STAMP(10);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // dynamic_rnn: rows past their own length keep (c, h) -- selects, not branches
@@ -394,16 +410,18 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
                 hid[rt][r] = live ? h_new : hid[rt][r];
                 act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * wave + (lane & 15)] = hid[rt][r];
             }
+        if (t == 1) POLICY_STAMP(11);
         __syncthreads();                                   // the new h is in place
+        if (t == 1) POLICY_STAMP(12);
     }
     POLICY_STAMP(1);
     // ---- layer1 on [h | host] --------------------------------------------------------------------------------
     {
-        f32x4 acc[4][4];
-        policy_load_b(f0, p.frags + kOffL1, 4 * wave, lane, 0);
+        f32x4 acc[RT][4];
+        policy_load_b<RT>(f0, p.frags + kOffL1, 4 * wave, lane, 0);
         policy_init_acc(lds_bias + kBiasL1, 4 * wave, lane, acc);
         policy_gemm(act, p.frags + kOffL1, 0, kChL1, kPolXCol + 4, 4 * wave, lane, f0, acc);
-        policy_load_b(f0, p.frags + kOffL2, 4 * wave, lane, 0);
+        policy_load_b<RT>(f0, p.frags + kOffL2, 4 * wave, lane, 0);
         __syncthreads();
         policy_store_relu(act, 4 * wave, lane, acc);
         __syncthreads();
@@ -411,41 +429,54 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
     POLICY_STAMP(2);
     // ---- layer2, fullyconnected1 -----------------------------------------------------------------------------
     {
-        f32x4 acc[4][4];
+        f32x4 acc[RT][4];
         policy_init_acc(lds_bias + kBiasL2, 4 * wave, lane, acc);
         policy_gemm(act, p.frags + kOffL2, 0, kChWide, 64, 4 * wave, lane, f0, acc);
-        policy_load_b(f0, p.frags + kOffFc1, 4 * wave, lane, 0);
+        policy_load_b<RT>(f0, p.frags + kOffFc1, 4 * wave, lane, 0);
         __syncthreads();
         policy_store_relu(act, 4 * wave, lane, acc);
         __syncthreads();
     }
     f32x4 hb[kChHead];                                     // the heads' weight fragments: in flight across the last layer's
     {                                                      // epilogue and barrier
-        f32x4 acc[4][4];
+        f32x4 acc[RT][4];
         policy_init_acc(lds_bias + kBiasFc1, 4 * wave, lane, acc);
         policy_gemm(act, p.frags + kOffFc1, 0, kChWide, 64, 4 * wave, lane, f0, acc);
         const f32x4 *brow = p.frags + kOffHead + lane;
+        if (RT == 4) {                                     // 2 wavefronts per SIMD: the registers are there
 #pragma unroll
-        for (int ch = 0; ch < kChHead; ++ch) hb[ch] = brow[64 * ch];
+            for (int ch = 0; ch < kChHead; ++ch) hb[ch] = brow[64 * ch];
+        }
         __syncthreads();
         policy_store_relu(act, 4 * wave, lane, acc);
         __syncthreads();
+        if (RT != 4) {                                     // 4 wavefronts per SIMD, 128 registers: half now, half below
+#pragma unroll
+            for (int ch = 0; ch < kChHead / 2; ++ch) hb[ch] = brow[64 * ch];
+        }
     }
     POLICY_STAMP(3);
-    // ---- heads: wavefront w does rows 16w..16w+15 x 16 columns (A logits, the value, padding) -----------------
-    {
+    // ---- heads: wavefront w < RT does rows 16w..16w+15 x 16 columns (A logits, the value, padding) ------------
+    if (wave < RT) {
         f32x4 acc[4];
         const float b = lds_bias[kBiasHead + (lane & 15)];
         acc[0] = f32x4{b, b, b, b};
         acc[1] = acc[2] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float *arow = act + (16 * wave + (lane & 15)) * kPolStride + 4 * (lane >> 4);
-        f32x4 ha[kChHead];
 #pragma unroll
-        for (int ch = 0; ch < kChHead; ++ch) ha[ch] = *reinterpret_cast<const f32x4 *>(arow + 16 * ch);
+        for (int g = 0; g < kChHead; g += 4) {
+            if (RT != 4 && g == 0) {
 #pragma unroll
-        for (int ch = 0; ch < kChHead; ++ch)
+                for (int ch = kChHead / 2; ch < kChHead; ++ch) hb[ch] = p.frags[kOffHead + lane + 64 * ch];
+            }
+            f32x4 ha[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ch][s], hb[ch][s], acc[s], 0, 0, 0);
+            for (int ch = 0; ch < 4; ++ch) ha[ch] = *reinterpret_cast<const f32x4 *>(arow + 16 * (g + ch));
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ch][s], hb[g + ch][s], acc[s], 0, 0, 0);
+        }
         const f32x4 logit = acc[0] + acc[1] + acc[2] + acc[3];
         const int col = lane & 15, A = p.num_actions;
         const float scale = 1.0f / (1.0f + p.min_policy * (float)A);
@@ -494,7 +525,7 @@ __global__ void __launch_bounds__(256, 2) policy_forward_kernel(const PolicyArgs
     }
     POLICY_STAMP(4);
 #ifdef CAVOID_TRACE
-    if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 8 + 6] = clock64() - trace_c0;   // shader-clock cycles
+    if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
 #endif
     if (p.actions_out) {                                   // the last workgroup to finish advances the step counter
         __syncthreads();

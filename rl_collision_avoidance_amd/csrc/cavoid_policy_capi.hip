@@ -21,6 +21,8 @@ struct cavoid_policy {
     float *bias = nullptr, *avg = nullptr, *std = nullptr;
     int32_t *step_counter = nullptr;
     uint32_t *blocks_done = nullptr, *cu_tickets = nullptr;
+    int row_tiles = 4;               // 16-row tiles per workgroup (64 rows, 2 workgroups per CU); the 32-row / 4-per-CU
+                                     // instantiation was measured and dropped: 175 vs 132 us
 };
 
 extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int device, cavoid_policy **out) {
@@ -46,9 +48,9 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
     h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
-    // 66.5 KB of LDS per workgroup: above the 64 KB static limit, so it is dynamic and opted into here
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kPolLdsBytes) != hipSuccess) {
+    // 70 KB of LDS per 64-row workgroup: above the 64 KB static limit, so it is dynamic and opted into here
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_lds_bytes(4)) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP;
     }
     *out = h;
@@ -106,9 +108,10 @@ extern "C" int cavoid_policy_forward(cavoid_policy *h, const float *x, int64_t r
     a.actions_out = actions_out; a.greedy = greedy ? 1 : 0;
     a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
     a.step_counter = h->step_counter; a.blocks_done = h->blocks_done; a.cu_tickets = h->cu_tickets;
-    const int64_t blocks = (rows + kPolRows - 1) / kPolRows;
+    const int tile = 16 * h->row_tiles;
+    const int64_t blocks = (rows + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
-    hipLaunchKernelGGL(policy_forward_kernel, dim3((unsigned)blocks), dim3(256), kPolLdsBytes, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(policy_forward_kernel<4>, dim3((unsigned)blocks), dim3(256), policy_lds_bytes(4), static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }

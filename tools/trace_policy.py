@@ -21,7 +21,7 @@ def main():
     x = torch.randn((B, net.input_size)).cuda() * net.std + net.avg
     x[:, 0] = 3.0
     nb = (B + 63) // 64
-    buf = torch.zeros((nb, 8), dtype=torch.int64, device="cuda")
+    buf = torch.zeros((nb, 16), dtype=torch.int64, device="cuda")
     lib = _lib.lib()
     lib.cavoid_policy_debug_trace.argtypes = [C.c_void_p]
     for _ in range(3):
@@ -57,6 +57,9 @@ def main():
         for q in range(0, len(pairs), max(1, len(pairs) // 8)):
             print("   pair", np.round(pairs[q], 1).tolist())
     late = us[:, 0] > 20
+    if (t[:, 12] > 0).all():
+        seg = np.diff(t[:, 8:13], axis=1) / 100.0
+        print("LSTM step 1 (gemm 5 chunks, barrier, cell update, barrier) us p50:", np.round(np.median(seg, axis=0), 2).tolist())
     print("prologue us p50 %.1f; shader clock p50 %.0f MHz (s_memtime cycles / wall-clock time)" % (
         np.median((t[:, 5] - t[:, 0]) / 100.0), np.median(t[:, 6] / dur)))
     for xc in range(8):
