@@ -271,29 +271,39 @@ __device__ __forceinline__ int other_index(int i, int o, int n) {
 }
 
 // E6: centre distances to the other agents of the lane's world (from the LDS-staged positions), the
-// collision test and the nearest gap.  All 64 lanes call this together.
+// collision test and the nearest gap.  All 64 lanes call this together.  What E9 needs later is kept
+// in its cheapest form -- the gap as the float32 that goes into the observation, its centimetre bucket
+// as an int32 sort key, and one "within the sensing horizon" bit -- not the float64 distance (the
+// register budget decides how many wavefronts a SIMD holds, and with it how much memory latency hides).
 template <int N>
 __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, bool present, int i, int base,
                                           const double *lds_px, const double *lds_py, const float *lds_r,
-                                          double (&dist)[Others<N>::K], uint32_t &others, bool &hit, double &min_gap) {
+                                          int (&gr)[Others<N>::K], float (&gapf)[Others<N>::K], uint32_t &others, uint32_t &near,
+                                          bool &hit, double &min_gap) {
     const double ri = (double)a.radius;
     others = 0u;
+    near = 0u;
     hit = false;
     min_gap = INFINITY;
-    dist[0] = 0.0;
+    gr[0] = 0; gapf[0] = 0.0f;
 #pragma unroll
     for (int o = 0; o < N - 1; ++o) {
         const int j = base + other_index(i, o, N);
         const float rjf = lds_r[j];
         const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
         const double d = sqrt(rx * rx + ry * ry);
-        dist[o] = d;
         const bool other = present && (rjf >= 0.0f);
         // unordered-pair gap d - (r_lo + r_hi): the sum is commutative, both ends agree bitwise
         const double gap_c = d - (ri + (double)rjf);
         min_gap = other ? fmin(min_gap, gap_c) : min_gap;
         hit = hit || (other && gap_c <= c.collision_dist);
         others |= other ? (1u << o) : 0u;
+        near |= !(d > c.horizon) ? (1u << o) : 0u;
+        // the observation's gap, host-side association (d - r_host) - r_other; rint(gap*100) is
+        // order-isomorphic to round(gap, 2) and integer-valued: exact in int32 (|gap| < 2e7 m)
+        const double gap_o = d - ri - (double)rjf;
+        gr[o] = (int)rint(gap_o * 100.0);
+        gapf[o] = (float)gap_o;
     }
 }
 
@@ -327,31 +337,37 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
 template <int N>
 __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
-                                             const double *lds_vy, const float *lds_r, const double (&dist)[Others<N>::K],
-                                             uint32_t others, float *tile, float *obs_dst, int rows_active) {
+                                             const double *lds_vy, const float *lds_r, const int (&gr)[Others<N>::K],
+                                             const float (&gapf)[Others<N>::K], uint32_t others, uint32_t near, float *tile,
+                                             float *obs_dst, int rows_active) {
     constexpr int K = Others<N>::K, NO = N - 1;
     const int M = c.max_other, width = c.width;
     const bool present = active && (a.flags & CAVOID_F_PRESENT);
     const double ri = (double)a.radius;
-    // sort criteria: gap rounded to centimetres (rint(gap*100) is order-isomorphic to round(gap,2)),
-    // then the lateral offset; its sign-preserving un-normalised form ry*tx - rx*ty orders the same;
-    // full ties fall back to the agent index (what a stable sort does)
-    int gr[K];                                                   // integer-valued: exact in int32 (|gap| < 2e7 m)
-    double lat[K];
-    uint32_t valid = 0u;
-    gr[0] = 0; lat[0] = 0.0;
+    // sort criteria: gap rounded to centimetres (gr, from the pair pass), then the lateral offset; its
+    // sign-preserving un-normalised form ry*tx - rx*ty orders the same; full ties fall back to the agent
+    // index (what a stable sort does).  The lateral key matters only between two neighbours in the same
+    // centimetre bucket, so it is computed on demand (wave-uniform branch) instead of living in 2*(N-1)
+    // registers.
+    const uint32_t valid = others & near;
     // index tie-break without an index array: others run in ring order j = (i+1+o) mod N, so for p < q
     // j_p < j_q unless the wrap (at o = N-1-i) falls between them
     const int wrap_o = N - 1 - i;
-#pragma unroll
-    for (int o = 0; o < NO; ++o) {
+    auto lateral = [&](int o) -> double {
         const int j = base + other_index(i, o, N);
-        const double rj = (double)lds_r[j];
         const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
-        gr[o] = (int)rint((dist[o] - ri - rj) * 100.0);
-        lat[o] = ry * e.tx - rx * e.ty;
-        valid |= (((others >> o) & 1u) && !(dist[o] > c.horizon)) ? (1u << o) : 0u;
-    }
+        return ry * e.tx - rx * e.ty;
+    };
+    // p, q in the same bucket: does p come first (smaller lateral offset, then smaller agent index)?
+    auto tie_first = [&](int p, int q, bool tied) -> bool {
+        bool first = false;
+        if (__ballot(tied) != 0ull) {
+            const double lp = lateral(p), lq = lateral(q);
+            const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
+            first = (lp < lq) || (lp == lq && idx_lt);
+        }
+        return first;
+    };
     const int m = __popc(valid);
     const int first = m > M ? m - M : 0;
     const int kept = m - first;
@@ -370,9 +386,8 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         for (int p = 0; p < NO; ++p)           // far -> near: larger time first, then larger gap, then smaller lateral
 #pragma unroll
             for (int q = p + 1; q < NO; ++q) {
-                const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
-                const bool p_first = (tti[p] > tti[q]) ||
-                                     (tti[p] == tti[q] && (gr[p] > gr[q] || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && idx_lt)))));
+                const bool tied = tti[p] == tti[q] && gr[p] == gr[q] && ((valid >> p) & (valid >> q) & 1u);
+                const bool p_first = (tti[p] > tti[q]) || (tti[p] == tti[q] && gr[p] > gr[q]) || (tied && tie_first(p, q, tied));
                 pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
                 pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
             }
@@ -381,8 +396,8 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         for (int p = 0; p < NO; ++p)           // far -> near: larger gap first, then smaller lateral, then index
 #pragma unroll
             for (int q = p + 1; q < NO; ++q) {
-                const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
-                const bool p_first = (gr[p] > gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && idx_lt)));
+                const bool tied = gr[p] == gr[q] && ((valid >> p) & (valid >> q) & 1u);
+                const bool p_first = (gr[p] > gr[q]) || (tied && tie_first(p, q, tied));
                 pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
                 pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
             }
@@ -400,8 +415,8 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         for (int p = 0; p < NO; ++p)
 #pragma unroll
             for (int q = p + 1; q < NO; ++q) {
-                const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
-                const bool p_first = (gr[p] < gr[q]) || (gr[p] == gr[q] && (lat[p] < lat[q] || (lat[p] == lat[q] && idx_lt)));
+                const bool tied = gr[p] == gr[q] && ((keep >> p) & (keep >> q) & 1u);
+                const bool p_first = (gr[p] < gr[q]) || (tied && tie_first(p, q, tied));
                 pos[q] += (p_first && ((keep >> p) & 1u)) ? 1 : 0;
                 pos[p] += (!p_first && ((keep >> q) & 1u)) ? 1 : 0;
             }
@@ -431,7 +446,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
             f[3] = (float)(ovy * e.prll_x - ovx * e.prll_y);
             f[4] = (float)rj;
             f[5] = (float)(ri + rj);
-            f[6] = (float)(dist[o] - ri - rj);
+            f[6] = gapf[o];
         }
         for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;   // unfilled slots
     }
@@ -488,10 +503,13 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, 
 
 enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESET = 3 };
 
+#ifndef CAVOID_OCC4_MAX_N
+#define CAVOID_OCC4_MAX_N 4
+#endif
 template <int N, int MODE>
 // (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
 //  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
-__global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
+__global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     using G = Geometry<N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -650,11 +668,12 @@ __global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c
     lds_r[lane] = present ? a.radius : -1.0f;              // radius < 0 marks an absent row
     wave_lds_sync();
     Ego e = ego_frame_obs(a);
-    double dist[Others<N>::K];
-    uint32_t others;
+    int gr[Others<N>::K];
+    float gapf[Others<N>::K];
+    uint32_t others, near;
     bool hit;
     double min_gap;
-    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, dist, others, hit, min_gap);
+    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, gr, gapf, others, near, hit, min_gap);
 
     CAVOID_STAMP(4);                                        // ego frame + pair pass done
     bool restart = false;
@@ -698,7 +717,7 @@ __global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c
                     e = ego_frame_obs(a);
                     bool hit2;
                     double gap2;
-                    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, dist, others, hit2, gap2);
+                    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, gr, gapf, others, near, hit2, gap2);
                 }
             }
         }
@@ -711,7 +730,7 @@ __global__ void __launch_bounds__(256, (N <= 4 ? 4 : 1)) env_kernel(const KCfg c
         if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
         if (worlds_here < 0) worlds_here = 0;
         CAVOID_STAMP(6);
-        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, dist, others, tile,
+        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, gr, gapf, others, near, tile,
                         io.obs + w0 * N * width, (int)worlds_here * N);
     }
 
