@@ -205,7 +205,7 @@ typedef struct cavoid_policy_weights {
     int32_t struct_size;             /* sizeof(cavoid_policy_weights) */
     float min_policy;                /* Config.MIN_POLICY */
     float forget_bias;               /* tf.contrib.rnn.LSTMCell default: 1.0 */
-    int32_t reserved;
+    int32_t with_backward;           /* != 0: also pack the transposed copies cavoid_policy_train_* needs */
     const float *avg, *std;          /* [5 + 7*max_other] or both NULL */
     const float *lstm_kernel, *lstm_bias;       /* rnn/lstm_cell/kernel [71,256], bias [256] */
     const float *layer1_kernel, *layer1_bias;   /* layer1 [68,256], [256] */
@@ -220,6 +220,33 @@ int cavoid_policy_load(cavoid_policy *p, const cavoid_policy_weights *w, void *s
 int cavoid_policy_seed(cavoid_policy *p, uint64_t seed, void *stream);
 int cavoid_policy_forward(cavoid_policy *p, const float *x, int64_t rows, int64_t row_stride, float *p_out, float *v_out,
                           int32_t *actions_out, int32_t greedy, void *stream);
+
+/* ---- fused trainer pass (Server.train_model -> NetworkVPCore.train, ga3c/GA3C/Server.py:114-124, NetworkVPCore.py:71-100,178-187)
+ * Forward + loss + the row-local part of the backward pass of the same network, for a batch of training rows
+ * (x [rows, row_stride], y_r [rows] n-step returns, a_idx int32 [rows] actions taken), in two launches on the matrix
+ * cores.  Needs cavoid_policy_load(with_backward = 1).  It leaves, in caller-owned buffers, the operand pair of every
+ * weight-gradient GEMM (the layer's input rows and the gradient at its output rows); the caller forms X^T G with its GEMM
+ * library, sums the bias gradients and takes the optimiser step:
+ *   d fullyconnected1 = z2^T g3,  d layer2 = z1^T g2,  d layer1 (rows in packed order: 64 hidden, 4 host) = l1_in^T g1,
+ *   d [logits_p | logits_v] = z3^T gh,  d lstm (rows: 64 hidden then 7 inputs; gate columns in packed order
+ *   64w + 16 gate + u for unit 16w + u) = sum_t h_in[t]^T gl[t];   bias gradients = column sums of g3, g2, g1, gh, gl.
+ * All per-row buffers have `capacity_rows` rows (a multiple of 64, >= rows rounded up to 64); rows past `rows` carry
+ * zero gradients.  loss[0] = cost_p, loss[1] = cost_v (sums over rows, NetworkVPCore.py:71-100). */
+typedef struct cavoid_policy_train_buffers {
+    int32_t struct_size;             /* sizeof(cavoid_policy_train_buffers) */
+    int32_t reserved;
+    int64_t capacity_rows;
+    float *z1, *z2, *z3;             /* [capacity_rows, 256] */
+    float *l1_in;                    /* [capacity_rows, 72] */
+    float *h_in;                     /* [max_other, capacity_rows, 72] */
+    float *save;                     /* [capacity_rows / 64, max_other, 16, 256, 8] */
+    float *gh;                       /* [capacity_rows, 16] */
+    float *loss;                     /* [2] */
+    float *g1, *g2, *g3;             /* [capacity_rows, 256] */
+    float *gl;                       /* [max_other, capacity_rows, 256] */
+} cavoid_policy_train_buffers;
+int cavoid_policy_train(cavoid_policy *p, const float *x, int64_t rows, int64_t row_stride, const float *y_r, const int32_t *a_idx,
+                        float beta, float log_epsilon, const cavoid_policy_train_buffers *buffers, void *stream);
 
 /* kernel timing helper: HIP events recorded on `stream` around the launches of the calls made
  * between begin and end; end synchronises and returns elapsed milliseconds */

@@ -43,9 +43,15 @@ class CavoidCfg(C.Structure):
 
 class CavoidPolicyWeights(C.Structure):
     """Mirror of ``struct cavoid_policy_weights`` (include/cavoid.h)."""
-    _fields_ = [("struct_size", C.c_int32), ("min_policy", C.c_float), ("forget_bias", C.c_float), ("reserved", C.c_int32)] + [
+    _fields_ = [("struct_size", C.c_int32), ("min_policy", C.c_float), ("forget_bias", C.c_float), ("with_backward", C.c_int32)] + [
         (n, C.c_void_p) for n in ("avg", "std", "lstm_kernel", "lstm_bias", "layer1_kernel", "layer1_bias", "layer2_kernel",
                                   "layer2_bias", "fc1_kernel", "fc1_bias", "p_kernel", "p_bias", "v_kernel", "v_bias")]
+
+
+class CavoidPolicyTrainBuffers(C.Structure):
+    """Mirror of ``struct cavoid_policy_train_buffers`` (include/cavoid.h)."""
+    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("capacity_rows", C.c_int64)] + [
+        (n, C.c_void_p) for n in ("z1", "z2", "z3", "l1_in", "h_in", "save", "gh", "loss", "g1", "g2", "g3", "gl")]
 
 
 class CavoidError(RuntimeError):
@@ -89,6 +95,7 @@ SYMBOLS = [
     ("cavoid_policy_load", C.c_int, [_P, C.POINTER(CavoidPolicyWeights), _P]),
     ("cavoid_policy_seed", C.c_int, [_P, C.c_uint64, _P]),
     ("cavoid_policy_forward", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32, _P]),
+    ("cavoid_policy_train", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, C.c_float, C.c_float, C.POINTER(CavoidPolicyTrainBuffers), _P]),
     ("cavoid_timer_begin", C.c_int, [_P, _P]),
     ("cavoid_timer_end", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
 ]

@@ -44,6 +44,15 @@ constexpr int64_t kOffL2 = kOffL1 + kChL1 * kFragPerChunk;
 constexpr int64_t kOffFc1 = kOffL2 + kChWide * kFragPerChunk;
 constexpr int64_t kOffHead = kOffFc1 + kChWide * kFragPerChunk;  // one column tile only: 64 frags per chunk
 constexpr int64_t kPackFrags = kOffHead + kChHead * 64;
+// transposed copies for the trainer's backward pass (dX = dY x W^T: K = the layer's output width, N = its input width);
+// N = 64 layers (inputs that are the LSTM state) have 4 column tiles per chunk instead of 16
+constexpr int64_t kFragPerChunkNarrow = 4 * 64;
+constexpr int64_t kOffTHead = kPackFrags;                                   // K = 16 (A logits, value, pad), N = 256
+constexpr int64_t kOffTFc1 = kOffTHead + 1 * kFragPerChunk;                 // K = 256, N = 256
+constexpr int64_t kOffTL2 = kOffTFc1 + kChWide * kFragPerChunk;
+constexpr int64_t kOffTL1 = kOffTL2 + kChWide * kFragPerChunk;              // K = 256, N = 64 (the hidden-state inputs of layer1)
+constexpr int64_t kOffTLstm = kOffTL1 + kChWide * kFragPerChunkNarrow;      // K = 256 gate columns (packed order), N = 64
+constexpr int64_t kPackFragsTrain = kOffTLstm + kChWide * kFragPerChunkNarrow;
 // biases, in packed column order: lstm 256 (forget bias folded in), l1 256, l2 256, fc1 256, head 16
 constexpr int kBiasLstm = 0, kBiasL1 = 256, kBiasL2 = 512, kBiasFc1 = 768, kBiasHead = 1024, kBiasFloats = 1040;
 constexpr size_t policy_lds_bytes(int row_tiles) {       // 64 rows: 70 752 B (2 workgroups per CU); 32 rows: 37 472 B (4 per CU)
@@ -79,18 +88,38 @@ __device__ __forceinline__ float policy_weight(const PolicyWeights &w, int layer
         return 0.0f;
     case 2: return w.layer2_kernel[(int64_t)k * 256 + col];
     case 3: return w.fc1_kernel[(int64_t)k * 256 + col];
-    default:                                                // heads: columns 0..A-1 logits_p, column A logits_v
+    case 4:                                                 // heads: columns 0..A-1 logits_p, column A logits_v
         if (col < w.num_actions) return w.p_kernel[(int64_t)k * w.num_actions + col];
         if (col == w.num_actions) return w.v_kernel[k];
         return 0.0f;
+    // ---- transposed (backward) layers: element [k][col] = W[col][k] --------------------------------------------
+    case 5:                                                 // heads^T: k = logit / value index, col = fullyconnected1 unit
+        if (k < w.num_actions) return w.p_kernel[(int64_t)col * w.num_actions + k];
+        if (k == w.num_actions) return w.v_kernel[col];
+        return 0.0f;
+    case 6: return w.fc1_kernel[(int64_t)col * 256 + k];
+    case 7: return w.layer2_kernel[(int64_t)col * 256 + k];
+    case 8: return w.layer1_kernel[(int64_t)(kPolHost + col) * 256 + k];           // col < 64: the hidden-state inputs
+    default: {                                              // LSTM^T: k = gate column in packed order, col = hidden unit
+        const int wave = k >> 6, gate = (k >> 4) & 3, u = k & 15;
+        return w.lstm_kernel[(int64_t)(kPolOther + col) * 256 + gate * kPolHidden + 16 * wave + u];
+    }
     }
 }
 
-__global__ void __launch_bounds__(256) policy_pack_kernel(const PolicyWeights w, f32x4 *frags, float *bias) {
+__global__ void __launch_bounds__(256) policy_pack_kernel(const PolicyWeights w, f32x4 *frags, float *bias, int with_backward) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < kPackFrags) {
+    if (f < (with_backward ? kPackFragsTrain : kPackFrags)) {
         int layer, chunk, ct, lane;
-        if (f >= kOffHead) {
+        if (f >= kOffTL1) {                                 // narrow transposed layers: 4 column tiles per chunk
+            layer = f >= kOffTLstm ? 9 : 8;
+            const int64_t r = f - (f >= kOffTLstm ? kOffTLstm : kOffTL1);
+            chunk = (int)(r / kFragPerChunkNarrow); ct = (int)((r >> 6) & 3); lane = (int)(r & 63);
+        } else if (f >= kOffTHead) {
+            layer = f >= kOffTL2 ? 7 : f >= kOffTFc1 ? 6 : 5;
+            const int64_t r = f - (f >= kOffTL2 ? kOffTL2 : f >= kOffTFc1 ? kOffTFc1 : kOffTHead);
+            chunk = (int)(r / kFragPerChunk); ct = (int)((r >> 6) & 15); lane = (int)(r & 63);
+        } else if (f >= kOffHead) {
             const int64_t r = f - kOffHead;
             layer = 4; chunk = (int)(r >> 6); ct = 0; lane = (int)(r & 63);
         } else {
@@ -152,6 +181,18 @@ struct PolicyArgs {
     int32_t *step_counter;             // device-side: keys the random stream, advanced once per launch
     uint32_t *blocks_done;
     uint32_t *cu_tickets;              // [kPolCuSlots] arrival counters, one per compute unit (see the kernel)
+    // TRAIN instantiation only (the trainer's forward pass): targets, the activations the backward pass and the
+    // weight-gradient GEMMs need, and the gradient at the heads.  rows64 = rows rounded up to the 64-row tile.
+    const float *y_r;                  // [rows] n-step returns
+    const int32_t *a_idx;              // [rows] action taken
+    float beta, log_eps;               // entropy weight, LOG_EPSILON
+    int64_t rows64;
+    float *z1, *z2, *z3;               // [rows64, 256] relu outputs of layer1, layer2, fullyconnected1
+    float *l1_in;                      // [rows64, 72]  layer1's input in packed K order [h(64) | host(4) | 0]
+    float *h_in;                       // [M, rows64, 72] LSTM step input [h_{t-1}(64) | x_t(7) | 0]
+    float *save;                       // [tiles, M, 16, 256, 8] per lane and cell: i, j, f, o, c_{t-1}, tanh(c_t), 0, 0
+    float *gh;                         // [rows64, 16] d cost / d (logits_p, logits_v)
+    float *loss;                       // [2] cost_p, cost_v (summed over rows)
 };
 
 // Philox4x32-10, the same generator the scenario generator uses (cavoid_kernels.hpp)
@@ -173,41 +214,44 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __bui
 
 // One 16-wide K chunk of fragments: RT row tiles of A (LDS) and 4 column tiles of B (packed weights, L2).
 // RT = row tiles per workgroup (16*RT rows): 4 -> 64 rows, 2 workgroups per CU; 2 -> 32 rows, 4 workgroups per CU.
-template <int RT>
-struct PolicyFrag { f32x4 a[RT], b[4]; };
+// CT = column tiles per wavefront: 4 for the 256-wide layers, 1 for the backward GEMMs whose output is the 64-wide LSTM state.
+template <int RT, int CT = 4>
+struct PolicyFrag { f32x4 a[RT], b[CT]; };
 
 // A fragments of chunk ch start at LDS column 16*ch, except that chunk 4 (the "input" chunk of the two 80-wide
 // layers) starts at `xcol`: the LSTM reads x_t and layer1 reads the host state where the prologue parked them.
-template <int RT>
-__device__ __forceinline__ void policy_load_a(PolicyFrag<RT> &f, const float *arow, int ch, int xcol) {
+template <int RT, int CT>
+__device__ __forceinline__ void policy_load_a(PolicyFrag<RT, CT> &f, const float *arow, int ch, int xcol) {
     const int col = ch == 4 ? xcol : 16 * ch;
 #pragma unroll
     for (int t = 0; t < RT; ++t) f.a[t] = *reinterpret_cast<const f32x4 *>(arow + 16 * t * kPolStride + col);
 }
 
-template <int RT>
-__device__ __forceinline__ void policy_load_b(PolicyFrag<RT> &f, const f32x4 *layer, int ct0, int lane, int ch) {
+template <int RT, int CT>
+__device__ __forceinline__ void policy_load_b(PolicyFrag<RT, CT> &f, const f32x4 *layer, int ct0, int lane, int ch) {
     const f32x4 *brow = layer + (int64_t)ct0 * 64 + lane;
+    constexpr int64_t stride = CT == 4 ? kFragPerChunk : kFragPerChunkNarrow;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) f.b[t] = brow[(int64_t)ch * kFragPerChunk + 64 * t];
+    for (int t = 0; t < CT; ++t) f.b[t] = brow[(int64_t)ch * stride + 64 * t];
 }
 
-template <int RT>
-__device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag<RT> &f, f32x4 (&acc)[RT][4]) {
+template <int RT, int CT>
+__device__ __forceinline__ void policy_mfma_chunk(const PolicyFrag<RT, CT> &f, f32x4 (&acc)[RT][CT]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[rt][s], f.b[ct][s], acc[rt][ct], 0, 0, 0);
 }
 
 // Issue order inside one chunk (16*RT MFMAs): the 4 weight loads and the RT LDS reads of the NEXT chunk go out one
 // at a time, each after RT MFMAs (a wavefront can issue a few other instructions per 32-cycle MFMA slot; clustered at
 // the chunk boundary they cost ~350 cycles per chunk), the remaining MFMAs cover their latency.
-template <int RT>
+template <int RT, int CT>
 __device__ __forceinline__ void policy_interleave() {
+    if (CT != 4) return;                                   // the narrow GEMMs (16 MFMAs per chunk) are left to the compiler
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);
@@ -228,11 +272,11 @@ __device__ __forceinline__ void policy_interleave() {
 // and are first needed after them, so neither the L2 nor the LDS latency is exposed.  The prefetches are
 // unconditional (the last one is a harmless re-read): a branch around them makes the compiler wait for them
 // at the join.
-template <int RT>
+template <int RT, int CT>
 __device__ __forceinline__ void policy_gemm(const float *act, const f32x4 *layer, int c0, int c1, int xcol, int ct0, int lane,
-                                            PolicyFrag<RT> &f0, f32x4 (&acc)[RT][4]) {
+                                            PolicyFrag<RT, CT> &f0, f32x4 (&acc)[RT][CT]) {
     const float *arow = act + (lane & 15) * kPolStride + 4 * (lane >> 4);
-    PolicyFrag<RT> f1;
+    PolicyFrag<RT, CT> f1;
     policy_load_a(f0, arow, c0, xcol);
     int ch = c0;
     while (true) {
@@ -240,13 +284,13 @@ __device__ __forceinline__ void policy_gemm(const float *act, const f32x4 *layer
         policy_load_b(f1, layer, ct0, lane, n1);
         policy_load_a(f1, arow, n1, xcol);
         policy_mfma_chunk(f0, acc);
-        policy_interleave<RT>();
+        policy_interleave<RT, CT>();
         if (ch + 1 >= c1) break;
         const int n2 = ch + 2 < c1 ? ch + 2 : ch;
         policy_load_b(f0, layer, ct0, lane, n2);
         policy_load_a(f0, arow, n2, xcol);
         policy_mfma_chunk(f1, acc);
-        policy_interleave<RT>();
+        policy_interleave<RT, CT>();
         ch += 2;
         if (ch >= c1) break;
     }
@@ -262,16 +306,22 @@ __device__ __forceinline__ void policy_init_acc(const float *bias, int ct0, int 
     }
 }
 
-// relu(acc) -> act[row][col]: lane holds col = 16*(ct0+ct) + lane%16, rows 16rt + 4*(lane/16) + r
+// relu(acc) -> act[row][col]: lane holds col = 16*(ct0+ct) + lane%16, rows 16rt + 4*(lane/16) + r.
+// zg (trainer only): the same values to global memory [rows64, 256], first row of the tile = zg.
 template <int RT>
-__device__ __forceinline__ void policy_store_relu(float *act, int ct0, int lane, const f32x4 (&acc)[RT][4]) {
+__device__ __forceinline__ void policy_store_relu(float *act, int ct0, int lane, const f32x4 (&acc)[RT][4], float *zg = nullptr) {
+    float *arow = act + (4 * (lane >> 4)) * kPolStride + 16 * ct0 + (lane & 15);
+    float *grow = zg ? zg + (4 * (lane >> 4)) * kPolWidth + 16 * ct0 + (lane & 15) : nullptr;   // one base, constant offsets
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * (ct0 + ct) + (lane & 15)] = fmaxf(acc[rt][ct][r], 0.0f);
+            for (int r = 0; r < 4; ++r) {
+                const float z = fmaxf(acc[rt][ct][r], 0.0f);
+                arow[(16 * rt + r) * kPolStride + 16 * ct] = z;
+                if (zg) grow[(16 * rt + r) * kPolWidth + 16 * ct] = z;
+            }
 }
 
 // e / d for 0 <= e < 2^20 and 1 <= d <= 512 without the integer-division sequence
@@ -282,8 +332,8 @@ __device__ __forceinline__ int policy_div(int e, int d, float inv_d) {
     return q;
 }
 
-template <int RT>
-__global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(const PolicyArgs p) {
+template <int RT, bool TRAIN>
+__global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_forward_kernel(const PolicyArgs p) {
     constexpr int kRows = 16 * RT;
     // LDS: activations [kRows][kPolStride], then the packed biases, then one int.  While the LSTM runs, a row is
     //   cols 0..63 h | 80 raw num_other | 84..87 host | 88+8t..94+8t x_t (t-th observed agent), zeros between
@@ -295,7 +345,7 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
     const int64_t row0 = (int64_t)blockIdx.x * kRows;
     const int rows_here = p.rows - row0 < kRows ? (int)(p.rows - row0) : kRows;
     const int M = p.max_other;
-    const int step = p.actions_out ? *p.step_counter : 0;
+    const int step = (!TRAIN && p.actions_out) ? *p.step_counter : 0;
     POLICY_STAMP(0);
 #ifdef CAVOID_TRACE
     const unsigned long long trace_c0 = clock64();
@@ -304,8 +354,8 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #endif
     const f32x4 *w_lstm = p.frags + kOffLstm;
-    PolicyFrag<RT> f0;
-    policy_load_b<RT>(f0, w_lstm, 4 * wave, lane, 4);          // first LSTM step: h == 0, only the input chunk contributes
+    PolicyFrag<RT, 4> f0;
+    policy_load_b(f0, w_lstm, 4 * wave, lane, 4);          // first LSTM step: h == 0, only the input chunk contributes
 
     // ---- input tile: gather + normalise into the padded layout above ------------------------------------------
     // One trip to memory: every global load of the prologue (inputs, normalisation vectors, biases) is issued
@@ -389,12 +439,20 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { cell[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; hid[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int t = 0; t < steps; ++t) {
+        if (TRAIN) {                                       // the step's input rows, for the LSTM weight gradient
+            float *dst = p.h_in + ((int64_t)t * p.rows64 + row0) * 72;
+            for (int e = tid; e < kRows * 72; e += 256) {
+                const int r = e / 72, k = e - r * 72;
+                dst[e] = k < kPolHidden ? act[r * kPolStride + k]
+                                        : (k < kPolHidden + kPolOther ? act[r * kPolStride + kPolXCol + 8 + 8 * t + (k - kPolHidden)] : 0.0f);
+            }
+        }
         f32x4 acc[RT][4];
         policy_init_acc(lds_bias + kBiasLstm, 4 * wave, lane, acc);
         if (t == 1) POLICY_STAMP(8);
         policy_gemm(act, w_lstm, t == 0 ? 4 : 0, kChLstm, kPolXCol + 8 + 8 * t, 4 * wave, lane, f0, acc);
         if (t == 1) POLICY_STAMP(9);
-        policy_load_b<RT>(f0, w_lstm, 4 * wave, lane, 0);      // the next step's first weight fragments
+        policy_load_b(f0, w_lstm, 4 * wave, lane, 0);      // the next step's first weight fragments
         __syncthreads();                                   // every wavefront has read h
         if (t == 1) POLICY_STAMP(10);
 #pragma unroll
@@ -403,9 +461,16 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
             for (int r = 0; r < 4; ++r) {
                 // dynamic_rnn: rows past their own length keep (c, h) -- selects, not branches
                 const bool live = len_r[rt][r] > (float)t;
-                const float gi = acc[rt][0][r], gj = acc[rt][1][r], gf = acc[rt][2][r], go = acc[rt][3][r];
-                const float c_new = fast_sigmoid(gf) * cell[rt][r] + fast_sigmoid(gi) * fast_tanh(gj);
-                const float h_new = fast_sigmoid(go) * fast_tanh(c_new);
+                const float gi = fast_sigmoid(acc[rt][0][r]), gj = fast_tanh(acc[rt][1][r]);
+                const float gf = fast_sigmoid(acc[rt][2][r]), go = fast_sigmoid(acc[rt][3][r]);
+                const float c_new = gf * cell[rt][r] + gi * gj;
+                const float tc = fast_tanh(c_new);
+                const float h_new = go * tc;
+                if (TRAIN) {                               // lane-private 32-byte records: the backward pass reads them back as is
+                    f32x4 *sv = reinterpret_cast<f32x4 *>(p.save) + ((((int64_t)blockIdx.x * M + t) * 16 + (rt * 4 + r)) * 256 + tid) * 2;
+                    sv[0] = f32x4{gi, gj, gf, go};
+                    sv[1] = f32x4{cell[rt][r], tc, 0.0f, 0.0f};
+                }
                 cell[rt][r] = live ? c_new : cell[rt][r];
                 hid[rt][r] = live ? h_new : hid[rt][r];
                 act[(16 * rt + 4 * (lane >> 4) + r) * kPolStride + 16 * wave + (lane & 15)] = hid[rt][r];
@@ -417,13 +482,21 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
     POLICY_STAMP(1);
     // ---- layer1 on [h | host] --------------------------------------------------------------------------------
     {
+        if (TRAIN) {                                       // layer1's input rows [h | host | 0], for its weight gradient
+            float *dst = p.l1_in + row0 * 72;
+            for (int e = tid; e < kRows * 72; e += 256) {
+                const int r = e / 72, k = e - r * 72;
+                dst[e] = k < kPolHidden ? act[r * kPolStride + k]
+                                        : (k < kPolHidden + kPolHost ? act[r * kPolStride + kPolXCol + 4 + (k - kPolHidden)] : 0.0f);
+            }
+        }
         f32x4 acc[RT][4];
-        policy_load_b<RT>(f0, p.frags + kOffL1, 4 * wave, lane, 0);
+        policy_load_b(f0, p.frags + kOffL1, 4 * wave, lane, 0);
         policy_init_acc(lds_bias + kBiasL1, 4 * wave, lane, acc);
         policy_gemm(act, p.frags + kOffL1, 0, kChL1, kPolXCol + 4, 4 * wave, lane, f0, acc);
-        policy_load_b<RT>(f0, p.frags + kOffL2, 4 * wave, lane, 0);
+        policy_load_b(f0, p.frags + kOffL2, 4 * wave, lane, 0);
         __syncthreads();
-        policy_store_relu(act, 4 * wave, lane, acc);
+        policy_store_relu(act, 4 * wave, lane, acc, TRAIN ? p.z1 + row0 * kPolWidth : nullptr);
         __syncthreads();
     }
     POLICY_STAMP(2);
@@ -432,9 +505,9 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
         f32x4 acc[RT][4];
         policy_init_acc(lds_bias + kBiasL2, 4 * wave, lane, acc);
         policy_gemm(act, p.frags + kOffL2, 0, kChWide, 64, 4 * wave, lane, f0, acc);
-        policy_load_b<RT>(f0, p.frags + kOffFc1, 4 * wave, lane, 0);
+        policy_load_b(f0, p.frags + kOffFc1, 4 * wave, lane, 0);
         __syncthreads();
-        policy_store_relu(act, 4 * wave, lane, acc);
+        policy_store_relu(act, 4 * wave, lane, acc, TRAIN ? p.z2 + row0 * kPolWidth : nullptr);
         __syncthreads();
     }
     f32x4 hb[kChHead];                                     // the heads' weight fragments: in flight across the last layer's
@@ -443,14 +516,14 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
         policy_init_acc(lds_bias + kBiasFc1, 4 * wave, lane, acc);
         policy_gemm(act, p.frags + kOffFc1, 0, kChWide, 64, 4 * wave, lane, f0, acc);
         const f32x4 *brow = p.frags + kOffHead + lane;
-        if (RT == 4) {                                     // 2 wavefronts per SIMD: the registers are there
+        if (RT == 4 && !TRAIN) {                           // 2 wavefronts per SIMD: the registers are there
 #pragma unroll
             for (int ch = 0; ch < kChHead; ++ch) hb[ch] = brow[64 * ch];
         }
         __syncthreads();
-        policy_store_relu(act, 4 * wave, lane, acc);
+        policy_store_relu(act, 4 * wave, lane, acc, TRAIN ? p.z3 + row0 * kPolWidth : nullptr);
         __syncthreads();
-        if (RT != 4) {                                     // 4 wavefronts per SIMD, 128 registers: half now, half below
+        if (RT != 4 || TRAIN) {                            // tighter register budget: half now, half below
 #pragma unroll
             for (int ch = 0; ch < kChHead / 2; ++ch) hb[ch] = brow[64 * ch];
         }
@@ -465,7 +538,7 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
         const float *arow = act + (16 * wave + (lane & 15)) * kPolStride + 4 * (lane >> 4);
 #pragma unroll
         for (int g = 0; g < kChHead; g += 4) {
-            if (RT != 4 && g == 0) {
+            if ((RT != 4 || TRAIN) && g == 0) {
 #pragma unroll
                 for (int ch = kChHead / 2; ch < kChHead; ++ch) hb[ch] = p.frags[kOffHead + lane + 64 * ch];
             }
@@ -480,6 +553,7 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
         const f32x4 logit = acc[0] + acc[1] + acc[2] + acc[3];
         const int col = lane & 15, A = p.num_actions;
         const float scale = 1.0f / (1.0f + p.min_policy * (float)A);
+        float cost_p = 0.0f, cost_v = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float z = logit[r];
@@ -491,12 +565,40 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);
             const int64_t row = row0 + 16 * wave + 4 * (lane >> 4) + r;
-            const float pj = col < A ? (e / sum + p.min_policy) * scale : 0.0f;
-            if (row < p.rows) {
+            const float sm = e / sum;                      // softmax
+            const float pj = col < A ? (sm + p.min_policy) * scale : 0.0f;
+            if (!TRAIN && row < p.rows) {
                 if (col < A) p.p_out[row * A + col] = pj;
                 else if (col == A) p.v_out[row] = z;
             }
-            if (p.actions_out) {                           // wave-uniform
+            if (TRAIN) {
+                // A3C loss of NetworkVPCore.py:71-100 (sums over rows) and its gradient at the logits:
+                //   cost_v = 0.5 (y - v)^2;  cost_p = -[ log(max(p_a, eps)) (y - v_detached) - beta sum_k log(max(p_k, eps)) p_k ]
+                const bool valid = row < p.rows;
+                const float y = valid ? p.y_r[row] : 0.0f;
+                const int a = valid ? p.a_idx[row] : 0;
+                const float v = __shfl(z, A, 16);
+                const float sel = __shfl(pj, a, 16);
+                const float lp = __logf(fmaxf(pj, p.log_eps));
+                // d cost_p / d p'_k, then through p' = (softmax + MIN_POLICY) * scale and the softmax
+                float dp = p.beta * (pj > p.log_eps ? lp + 1.0f : lp);
+                if (col == a && sel > p.log_eps) dp -= (y - v) / sel;
+                dp = col < A ? dp * scale : 0.0f;
+                float dot = sm * dp;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) dot += __shfl_xor(dot, d, 16);
+                float g = col < A ? sm * (dp - dot) : (col == A ? v - y : 0.0f);
+                if (!valid) g = 0.0f;
+                p.gh[(row0 + 16 * wave + 4 * (lane >> 4) + r) * 16 + col] = g;
+                float ent = col < A ? lp * pj : 0.0f;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) ent += __shfl_xor(ent, d, 16);
+                if (valid && col == 0) {
+                    cost_p -= __logf(fmaxf(sel, p.log_eps)) * (y - v) - p.beta * ent;
+                    cost_v += 0.5f * (y - v) * (y - v);
+                }
+            }
+            if (!TRAIN && p.actions_out) {                 // wave-uniform
                 int action;
                 if (p.greedy) {                            // np.argmax: first index of the maximum
                     float best = pj;
@@ -522,12 +624,17 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
                 if (row < p.rows && col == 0) p.actions_out[row] = action;
             }
         }
+        if (TRAIN) {                                       // one atomic pair per wavefront
+            cost_p += __shfl_xor(cost_p, 16, 64); cost_p += __shfl_xor(cost_p, 32, 64);
+            cost_v += __shfl_xor(cost_v, 16, 64); cost_v += __shfl_xor(cost_v, 32, 64);
+            if (lane == 0) { atomicAdd(p.loss, cost_p); atomicAdd(p.loss + 1, cost_v); }
+        }
     }
     POLICY_STAMP(4);
 #ifdef CAVOID_TRACE
     if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
 #endif
-    if (p.actions_out) {                                   // the last workgroup to finish advances the step counter
+    if (!TRAIN && p.actions_out) {                         // the last workgroup to finish advances the step counter
         __syncthreads();
         if (tid == 0) {
             __threadfence();
@@ -537,6 +644,176 @@ __global__ void __launch_bounds__(256, RT == 4 ? 2 : 4) policy_forward_kernel(co
                 __threadfence();
             }
         }
+    }
+}
+
+// ---- backward (trainer) ---------------------------------------------------------------------------------
+// Everything of the backward pass that is row-local: the gradient at the heads (from the TRAIN forward) is pushed back
+// through fullyconnected1, layer2, layer1 and the LSTM, 64 rows per workgroup, same LDS / fragment machinery as the
+// forward (dX = dY x W^T with the transposed packs).  What it leaves in memory -- the masked gradient at every layer's
+// output (g3, g2, g1, the per-step gate gradients gl) next to the forward's saved layer inputs -- is exactly the operand
+// pair of each weight-gradient GEMM (X^T x G over all rows), which is a plain large GEMM and stays a library call.
+struct PolicyBackArgs {
+    const float *x;                    // [rows, stride]: column 0 = num_other_agents (the LSTM length)
+    int64_t rows, stride, rows64;
+    int max_other;
+    const f32x4 *frags;
+    const float *z1, *z2, *z3, *save, *gh;
+    float *g1, *g2, *g3;               // [rows64, 256]
+    float *gl;                         // [M, rows64, 256], gate columns in packed order (64w + 16 gate + u)
+};
+
+// g = acc where the layer's relu was active, else 0 -> LDS (the next GEMM's A operand) and global memory
+template <int RT>
+__device__ __forceinline__ void policy_store_masked(float *act, int ct0, int lane, const f32x4 (&acc)[RT][4], const float *zg, float *gg) {
+    const int lane_off = (4 * (lane >> 4)) * kPolWidth + 16 * ct0 + (lane & 15);
+    const float *zrow = zg + lane_off;
+    float *grow = gg + lane_off;
+    float *arow = act + (4 * (lane >> 4)) * kPolStride + 16 * ct0 + (lane & 15);
+    float z[RT][4][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[rt][ct][r] = zrow[(16 * rt + r) * kPolWidth + 16 * ct];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = z[rt][ct][r] > 0.0f ? acc[rt][ct][r] : 0.0f;
+                arow[(16 * rt + r) * kPolStride + 16 * ct] = g;
+                grow[(16 * rt + r) * kPolWidth + 16 * ct] = g;
+            }
+}
+
+template <int RT>
+__device__ __forceinline__ void policy_zero_acc(f32x4 (&acc)[RT][4]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int RT>
+__global__ void __launch_bounds__(256, 2) policy_backward_kernel(const PolicyBackArgs p) {
+    constexpr int kRows = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    int *wave_max = reinterpret_cast<int *>(act + kRows * kPolStride);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t row0 = (int64_t)blockIdx.x * kRows;
+    const int M = p.max_other;
+
+    PolicyFrag<RT, 4> f0;
+    policy_load_b(f0, p.frags + kOffTHead, 4 * wave, lane, 0);
+    // sequence lengths of this lane's rows (C layout), the tile's step count, and the head gradient into LDS
+    float len_r[RT][4];
+    int local_max = 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * rt + 4 * (lane >> 4) + r;
+            const float len = row < p.rows ? p.x[row * p.stride] : 0.0f;
+            len_r[rt][r] = len;
+            int li = (int)len;
+            li = li < 0 ? 0 : (li > M ? M : li);
+            local_max = local_max > li ? local_max : li;
+        }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(local_max, d, 64); local_max = o > local_max ? o : local_max; }
+    if (lane == 0) wave_max[wave] = local_max;
+    for (int e = tid; e < kRows * 16; e += 256) act[(e >> 4) * kPolStride + (e & 15)] = p.gh[row0 * 16 + e];
+    __syncthreads();
+    const int m01 = wave_max[0] > wave_max[1] ? wave_max[0] : wave_max[1], m23 = wave_max[2] > wave_max[3] ? wave_max[2] : wave_max[3];
+    const int steps = m01 > m23 ? m01 : m23;
+
+    // ---- heads^T, fullyconnected1^T, layer2^T: 256-wide outputs, masked by the forward's relu ---------------------
+    {
+        f32x4 acc[RT][4];
+        policy_zero_acc(acc);
+        policy_gemm(act, p.frags + kOffTHead, 0, 1, 64, 4 * wave, lane, f0, acc);
+        policy_load_b(f0, p.frags + kOffTFc1, 4 * wave, lane, 0);
+        __syncthreads();
+        policy_store_masked(act, 4 * wave, lane, acc, p.z3 + row0 * kPolWidth, p.g3 + row0 * kPolWidth);
+        __syncthreads();
+    }
+    {
+        f32x4 acc[RT][4];
+        policy_zero_acc(acc);
+        policy_gemm(act, p.frags + kOffTFc1, 0, kChWide, 64, 4 * wave, lane, f0, acc);
+        policy_load_b(f0, p.frags + kOffTL2, 4 * wave, lane, 0);
+        __syncthreads();
+        policy_store_masked(act, 4 * wave, lane, acc, p.z2 + row0 * kPolWidth, p.g2 + row0 * kPolWidth);
+        __syncthreads();
+    }
+    {
+        f32x4 acc[RT][4];
+        policy_zero_acc(acc);
+        policy_gemm(act, p.frags + kOffTL2, 0, kChWide, 64, 4 * wave, lane, f0, acc);
+        __syncthreads();
+        policy_store_masked(act, 4 * wave, lane, acc, p.z1 + row0 * kPolWidth, p.g1 + row0 * kPolWidth);
+        __syncthreads();
+    }
+    // ---- layer1^T, hidden-state inputs only: d cost / d h_final, one column tile per wavefront = its 16 hidden units --
+    PolicyFrag<RT, 1> n0;
+    f32x4 dh[RT], dc[RT];
+    {
+        f32x4 acc1[RT][1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc1[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        policy_load_b(n0, p.frags + kOffTL1, wave, lane, 0);
+        policy_gemm(act, p.frags + kOffTL1, 0, kChWide, 64, wave, lane, n0, acc1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { dh[rt] = acc1[rt][0]; dc[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    __syncthreads();                                       // g1 has been read by every wavefront
+    // ---- LSTM, backwards through the observed agents ------------------------------------------------------------
+    for (int t = M - 1; t >= 0; --t) {
+        float *glt = p.gl + ((int64_t)t * p.rows64 + row0) * kPolWidth;
+        if (t >= steps) {                                  // no row of this tile took step t
+            for (int e = tid; e < kRows * kPolWidth; e += 256) glt[e] = 0.0f;
+            continue;
+        }
+        policy_load_b(n0, p.frags + kOffTLstm, wave, lane, 0);
+        f32x4 dc_new[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 *sv = reinterpret_cast<const f32x4 *>(p.save) + ((((int64_t)blockIdx.x * M + t) * 16 + (rt * 4 + r)) * 256 + tid) * 2;
+                const f32x4 s0 = sv[0], s1 = sv[1];
+                const float gi = s0[0], gj = s0[1], gf = s0[2], go = s0[3], cprev = s1[0], tc = s1[1];
+                const bool live = len_r[rt][r] > (float)t;
+                const float dhv = dh[rt][r];
+                const float dct = dc[rt][r] + dhv * go * (1.0f - tc * tc);
+                const float d_o = live ? dhv * tc * go * (1.0f - go) : 0.0f;
+                const float d_i = live ? dct * gj * gi * (1.0f - gi) : 0.0f;
+                const float d_j = live ? dct * gi * (1.0f - gj * gj) : 0.0f;
+                const float d_f = live ? dct * cprev * gf * (1.0f - gf) : 0.0f;
+                dc_new[rt][r] = live ? dct * gf : dc[rt][r];
+                const int row = 16 * rt + 4 * (lane >> 4) + r, col = 64 * wave + (lane & 15);
+                float *a = act + row * kPolStride + col;
+                float *g = glt + (int64_t)row * kPolWidth + col;
+                a[0] = d_i; a[16] = d_j; a[32] = d_f; a[48] = d_o;
+                g[0] = d_i; g[16] = d_j; g[32] = d_f; g[48] = d_o;
+            }
+        __syncthreads();
+        f32x4 acc1[RT][1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc1[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        policy_gemm(act, p.frags + kOffTLstm, 0, kChWide, 64, wave, lane, n0, acc1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool live = len_r[rt][r] > (float)t;
+                dh[rt][r] = live ? acc1[rt][0][r] : dh[rt][r];     // rows past their length: the step was the identity
+                dc[rt][r] = dc_new[rt][r];
+            }
+        __syncthreads();
     }
 }
 

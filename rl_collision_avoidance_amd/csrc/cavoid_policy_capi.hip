@@ -13,7 +13,7 @@ using namespace cavoid;
 struct cavoid_policy {
     int device = 0;
     int max_other = 0, num_actions = 0, in_size = 0;
-    bool loaded = false, normalize = false;
+    bool loaded = false, normalize = false, backward_loaded = false;
     float min_policy = 0.0f;
     uint64_t seed = 0;
     void *slab = nullptr;
@@ -38,7 +38,7 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     h->in_size = 1 + kPolHost + kPolOther * max_other;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_frag = carve((size_t)kPackFrags * sizeof(f32x4)), o_bias = carve(kBiasFloats * sizeof(float));
+    const size_t o_frag = carve((size_t)kPackFragsTrain * sizeof(f32x4)), o_bias = carve(kBiasFloats * sizeof(float));
     const size_t o_avg = carve(h->in_size * sizeof(float)), o_std = carve(h->in_size * sizeof(float));
     const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t)), o_tick = carve(kPolCuSlots * sizeof(uint32_t));
     if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return CAVOID_ENOMEM; }
@@ -49,7 +49,11 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
     h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
     // 70 KB of LDS per 64-row workgroup: above the 64 KB static limit, so it is dynamic and opted into here
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_lds_bytes(4)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_lds_bytes(4)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_backward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_lds_bytes(4)) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP;
     }
@@ -76,8 +80,10 @@ extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights 
     k.layer2_kernel = w->layer2_kernel; k.layer2_bias = w->layer2_bias; k.fc1_kernel = w->fc1_kernel; k.fc1_bias = w->fc1_bias;
     k.p_kernel = w->p_kernel; k.p_bias = w->p_bias; k.v_kernel = w->v_kernel; k.v_bias = w->v_bias;
     k.num_actions = h->num_actions; k.forget_bias = w->forget_bias;
-    const unsigned blocks = (unsigned)((kPackFrags + 255) / 256);
-    hipLaunchKernelGGL(policy_pack_kernel, dim3(blocks), dim3(256), 0, s, k, h->frags, h->bias);
+    const int with_backward = w->with_backward ? 1 : 0;
+    const unsigned blocks = (unsigned)(((with_backward ? kPackFragsTrain : kPackFrags) + 255) / 256);
+    hipLaunchKernelGGL(policy_pack_kernel, dim3(blocks), dim3(256), 0, s, k, h->frags, h->bias, with_backward);
+    h->backward_loaded = with_backward != 0;
     HIP_TRY(hipGetLastError());
     h->normalize = w->avg != nullptr;
     if (h->normalize) {
@@ -111,7 +117,37 @@ extern "C" int cavoid_policy_forward(cavoid_policy *h, const float *x, int64_t r
     const int tile = 16 * h->row_tiles;
     const int64_t blocks = (rows + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
-    hipLaunchKernelGGL(policy_forward_kernel<4>, dim3((unsigned)blocks), dim3(256), policy_lds_bytes(4), static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL((policy_forward_kernel<4, false>), dim3((unsigned)blocks), dim3(256), policy_lds_bytes(4), static_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_policy_train(cavoid_policy *h, const float *x, int64_t rows, int64_t row_stride, const float *y_r,
+                                   const int32_t *a_idx, float beta, float log_epsilon, const cavoid_policy_train_buffers *b,
+                                   void *stream) {
+    if (!h || !x || !y_r || !a_idx || !b || b->struct_size != (int32_t)sizeof(cavoid_policy_train_buffers)) return CAVOID_EINVAL;
+    if (!h->loaded || !h->backward_loaded || rows < 0 || row_stride < h->in_size) return CAVOID_EINVAL;
+    const int64_t rows64 = (rows + 63) / 64 * 64;
+    if (b->capacity_rows < rows64 || !b->z1 || !b->z2 || !b->z3 || !b->l1_in || !b->h_in || !b->save || !b->gh || !b->loss ||
+        !b->g1 || !b->g2 || !b->g3 || !b->gl)
+        return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(b->loss, 0, 2 * sizeof(float), s));
+    if (rows == 0) return CAVOID_OK;
+    const int64_t cap = b->capacity_rows;                  // leading dimension (in rows) of the per-step buffers
+    PolicyArgs a{};
+    a.x = x; a.rows = rows; a.stride = row_stride; a.max_other = h->max_other; a.num_actions = h->num_actions; a.in_size = h->in_size;
+    a.avg = h->normalize ? h->avg : nullptr; a.std = h->normalize ? h->std : nullptr;
+    a.frags = h->frags; a.bias = h->bias; a.min_policy = h->min_policy; a.cu_tickets = h->cu_tickets;
+    a.y_r = y_r; a.a_idx = a_idx; a.beta = beta; a.log_eps = log_epsilon; a.rows64 = cap;
+    a.z1 = b->z1; a.z2 = b->z2; a.z3 = b->z3; a.l1_in = b->l1_in; a.h_in = b->h_in; a.save = b->save; a.gh = b->gh; a.loss = b->loss;
+    const unsigned blocks = (unsigned)(rows64 / 64);
+    hipLaunchKernelGGL((policy_forward_kernel<4, true>), dim3(blocks), dim3(256), policy_lds_bytes(4), s, a);
+    HIP_TRY(hipGetLastError());
+    PolicyBackArgs k{};
+    k.x = x; k.rows = rows; k.stride = row_stride; k.rows64 = cap; k.max_other = h->max_other; k.frags = h->frags;
+    k.z1 = b->z1; k.z2 = b->z2; k.z3 = b->z3; k.save = b->save; k.gh = b->gh; k.g1 = b->g1; k.g2 = b->g2; k.g3 = b->g3; k.gl = b->gl;
+    hipLaunchKernelGGL((policy_backward_kernel<4>), dim3(blocks), dim3(256), policy_lds_bytes(4), s, k);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }

@@ -53,12 +53,14 @@ class FusedPolicy(object):
     def seed(self, seed: int) -> None:
         _lib.check(self._lib.cavoid_policy_seed(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1)), self._stream()), "cavoid_policy_seed")
 
-    def refresh(self) -> None:
-        """Re-pack the module's current parameters (after a trainer step / checkpoint load)."""
+    def refresh(self, with_backward: bool = False) -> None:
+        """Re-pack the module's current parameters (after a trainer step / checkpoint load).  ``with_backward`` also
+        packs the transposed copies the fused trainer pass needs."""
         n = self.net
         w = _lib.CavoidPolicyWeights()
         w.struct_size = C.sizeof(_lib.CavoidPolicyWeights)
         w.min_policy, w.forget_bias = float(n.min_policy), self.forget_bias
+        w.with_backward = 1 if with_backward else 0
         ptr = lambda t: C.c_void_p(self._f32(t).data_ptr())
         self._keep = []                  # tensors that had to be made contiguous stay alive until the next refresh
         if n.normalize:
@@ -102,3 +104,96 @@ class FusedPolicy(object):
         """predict + select_action (ProcessAgent.py:89-103,128-144): (actions int32 [B], p, v)."""
         p, v, a = self.forward(x, sample=True, greedy=greedy)
         return a, p, v
+
+
+class FusedA3CTrainer(object):
+    """``Server.train_model`` (/root/reference/ga3c/GA3C/Server.py:114-124) with the network's forward pass, the A3C loss
+    (NetworkVPCore.py:71-100) and the row-local half of the backward pass as two MFMA kernel launches
+    (``cavoid_policy_train``); the weight gradients are the library GEMMs ``X^T G`` over all rows (split-K batched), the
+    optimiser is the same fused Adam as ``A3CTrainer``.  Gradients equal PyTorch autograd's on ``NetworkVP_rnn.loss`` to
+    float32 rounding (tests/test_gpu_policy.py)."""
+
+    def __init__(self, net: NetworkVP_rnn, policy: Optional[FusedPolicy] = None, learning_rate: float = 2e-5, group=None,
+                 distributed: Optional[bool] = None):
+        from .network import A3CTrainer
+        self.net = net
+        self.policy = policy if policy is not None else FusedPolicy(net)
+        self._base = A3CTrainer(net, learning_rate=learning_rate, group=group, distributed=distributed)
+        self.opt = self._base.opt
+        self.device = self.policy.device
+        self._buffers = {}
+        H, A = net.HIDDEN, net.num_actions
+        # packed gate column k = 64w + 16 gate + u  <->  checkpoint column c = 64 gate + 16w + u
+        c = torch.arange(4 * H, device=self.device)
+        gate, w, u = c // H, (c % H) // 16, c % 16
+        self._k_of_c = 64 * w + 16 * gate + u
+        self.policy.refresh(with_backward=True)
+
+    training_step = property(lambda self: self._base.training_step,
+                             lambda self, v: setattr(self._base, "training_step", v))
+    frame_counter = property(lambda self: self._base.frame_counter)
+
+    def _scratch(self, rows64: int):
+        b = self._buffers.get(rows64)
+        if b is None:
+            M, dev = self.net.max_others, self.device
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            t = {"z1": f(rows64, 256), "z2": f(rows64, 256), "z3": f(rows64, 256), "l1_in": f(rows64, 72), "h_in": f(M, rows64, 72),
+                 "save": f(rows64 // 64, M, 16, 256, 8), "gh": f(rows64, 16), "loss": f(2), "g1": f(rows64, 256), "g2": f(rows64, 256),
+                 "g3": f(rows64, 256), "gl": f(M, rows64, 256)}
+            c = _lib.CavoidPolicyTrainBuffers()
+            c.struct_size, c.capacity_rows = C.sizeof(_lib.CavoidPolicyTrainBuffers), rows64
+            for k, v in t.items():
+                setattr(c, k, C.c_void_p(v.data_ptr()))
+            b = self._buffers[rows64] = (t, c)
+            if len(self._buffers) > 4:                     # keep the cache small: minibatch size + a remainder or two
+                self._buffers.pop(next(iter(self._buffers)))
+        return b
+
+    @staticmethod
+    def _xtg(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        """x^T g over all rows, split-K (see network._SplitKLinear)."""
+        R, S = x.shape[0], 1
+        while S < 64 and R % (2 * S) == 0 and R // (2 * S) >= 256:
+            S *= 2
+        if S == 1:
+            return x.t() @ g
+        return torch.bmm(x.view(S, R // S, -1).transpose(1, 2), g.view(S, R // S, -1)).sum(dim=0)
+
+    def train(self, x: torch.Tensor, y_r: torch.Tensor, a: torch.Tensor) -> float:
+        """One optimiser step on the batch.  ``a``: action indices [n] or the reference's one-hot float [n, A]."""
+        net, pol = self.net, self.policy
+        n = int(x.shape[0])
+        if n == 0:
+            return self._base.train(x, y_r, a if a.dim() == 2 else torch.nn.functional.one_hot(a.long(), net.num_actions).float())
+        x = x.to(torch.float32).contiguous()
+        y_r = y_r.to(torch.float32).contiguous()
+        a_idx = (a.argmax(dim=1) if a.dim() == 2 else a).to(torch.int32).contiguous()
+        rows64 = (n + 63) // 64 * 64
+        t, cbuf = self._scratch(rows64)
+        ptr = lambda v: C.c_void_p(v.data_ptr())
+        _lib.check(pol._lib.cavoid_policy_train(pol._h, ptr(x), n, x.stride(0), ptr(y_r), ptr(a_idx), float(net.beta),
+                                                float(net.log_epsilon), C.byref(cbuf), pol._stream()), "cavoid_policy_train")
+        A, H, M = net.num_actions, net.HIDDEN, net.max_others
+        xtg = self._xtg
+        d_head = xtg(t["z3"], t["gh"])
+        net.p_kernel.grad, net.v_kernel.grad = d_head[:, :A].contiguous(), d_head[:, A:A + 1].contiguous()
+        b_head = t["gh"].sum(dim=0)
+        net.p_bias.grad, net.v_bias.grad = b_head[:A].contiguous(), b_head[A:A + 1].contiguous()
+        net.fc1_kernel.grad, net.fc1_bias.grad = xtg(t["z2"], t["g3"]), t["g3"].sum(dim=0)
+        net.layer2_kernel.grad, net.layer2_bias.grad = xtg(t["z1"], t["g2"]), t["g2"].sum(dim=0)
+        d_l1 = xtg(t["l1_in"], t["g1"])                                     # rows: 64 hidden, 4 host, 4 padding
+        net.layer1_kernel.grad = torch.cat([d_l1[H:H + net.HOST], d_l1[:H]], dim=0)
+        net.layer1_bias.grad = t["g1"].sum(dim=0)
+        gl = t["gl"].view(M * rows64, 4 * H)
+        d_lstm = xtg(t["h_in"].view(M * rows64, 72), gl)                   # rows: 64 hidden, 7 inputs, 1 padding; packed gate columns
+        d_lstm = torch.cat([d_lstm[H:H + net.OTHER], d_lstm[:H]], dim=0)
+        net.lstm_kernel.grad = d_lstm.index_select(1, self._k_of_c)
+        net.lstm_bias.grad = gl.sum(dim=0).index_select(0, self._k_of_c)
+        if self._base.distributed:
+            self._base._allreduce_grads()
+        self.opt.step()
+        self._base.training_step += 1
+        self._base.frame_counter += n
+        pol.refresh(with_backward=True)                    # actors and the next training pass see the new weights
+        return float(t["loss"].sum())
