@@ -101,19 +101,20 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     """BASELINE configs[4]: everything on the device -- policy inference + action selection (fused f32-MFMA kernel,
     cavoid_policy_*), env.step, experience store / n-step returns (HIP), and Adam steps (PyTorch-ROCm autograd) on
     EVERY drained row, in minibatches of `train_rows` (policy replica per GPU, no collective).  Reports the
-    reference's PPS definition: learning-agent steps per second (ProcessStats.py:54-56), for three regimes:
-    actors only (PLAY_MODE: no trainer), the full loop, and the full loop acting through the PyTorch graph."""
+    reference's PPS definition: learning-agent steps per second (ProcessStats.py:54-56), for four regimes:
+    actors only (PLAY_MODE: no trainer); the full loop with the fused trainer pass (cavoid_policy_train + library
+    weight-gradient GEMMs); with the PyTorch autograd trainer; and all-PyTorch (policy and trainer)."""
     import torch
     from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
-    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedA3CTrainer, FusedPolicy
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
     per_graph = 4                                            # env steps per hipGraph replay (even)
 
-    def regime(fused: bool, train: bool):
+    def regime(fused: bool, train: bool, fused_trainer: bool = False):
         env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
         net = NetworkVP_rnn(cfg).to(device)
-        trainer = A3CTrainer(net)
         pol = FusedPolicy(net, seed=rank) if fused else None
+        trainer = FusedA3CTrainer(net, pol) if fused_trainer else A3CTrainer(net)
         roll = BatchedRollout(env, pol if fused else net.predict_p_and_v, reflush_done=False)
         roll.reset()
         roll.capture(steps_per_graph=per_graph)              # policy + sampling + env.step + bookkeeping as ONE graph
@@ -126,9 +127,10 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
                     continue
                 b = roll.drain()
                 for lo in range(0, len(b), train_rows):
-                    trainer.train(b.x[lo:lo + train_rows], b.r[lo:lo + train_rows], b.a[lo:lo + train_rows])
+                    trainer.train(b.x[lo:lo + train_rows], b.r[lo:lo + train_rows],
+                                  b.a_index[lo:lo + train_rows] if fused_trainer else b.a[lo:lo + train_rows])
                 rows[0] += len(b)
-                if pol is not None and len(b):
+                if pol is not None and len(b) and not fused_trainer:
                     pol.refresh()
             return n_replays * per_graph * W * N             # all agents learn in this workload
         run(8)
@@ -174,8 +176,9 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         return {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us, "issued_TFLOPs": flop / fused_us * 1e-6,
                 "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3, "bound": "mfma", "dtype": "f32",
                 "kernel": "cavoid::policy_forward_kernel"}
-    res = {"policy_kernel": policy_kernel(), "actors_only_fused_policy": regime(True, False), "full_loop_fused_policy": regime(True, True),
-           "full_loop_torch_policy": regime(False, True),
+    res = {"policy_kernel": policy_kernel(), "actors_only_fused_policy": regime(True, False), "full_loop_fused_policy_fused_trainer": regime(True, True, True),
+           "full_loop_fused_policy_autograd_trainer": regime(True, True),
+           "full_loop_torch_policy_autograd_trainer": regime(False, True),
            "steps_per_graph": per_graph, "train_rows_per_adam_step": train_rows, "policy_dtype": "f32",
            "note": "one hipGraph per %d env steps (policy + action selection + env + experience store); every drained row "
                    "is trained on once; reference PPS datum: 563 (32 procs, laptop CPU)" % per_graph}

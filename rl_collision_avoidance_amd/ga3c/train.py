@@ -21,7 +21,7 @@ from ..batched_env import BatchedCollisionAvoidanceEnv
 from ..config import EnvConfig
 from ..sharding import shard_range
 from .network import A3CTrainer, NetworkVP_rnn
-from .policy_kernel import FusedPolicy
+from .policy_kernel import FusedA3CTrainer, FusedPolicy
 from .rollout import BatchedRollout
 from .stats import EpisodeStats
 
@@ -57,6 +57,8 @@ def main(argv=None) -> None:
                     help="rows per Adam step: every drained row is trained on exactly once, in minibatches of this size")
     ap.add_argument("--torch-policy", action="store_true",
                     help="act with the PyTorch-ROCm graph of the network instead of the fused MFMA kernel (rnn arch only)")
+    ap.add_argument("--autograd-trainer", action="store_true",
+                    help="train through PyTorch autograd instead of the fused forward/backward kernels (rnn arch only)")
     ap.add_argument("--lr", type=float, default=2e-5, help="LEARNING_RATE_RL_START")
     ap.add_argument("--lr-end", type=float, default=None, help="LEARNING_RATE_RL_END (default: no annealing)")
     ap.add_argument("--beta", type=float, default=1e-4, help="BETA_START (entropy regularisation)")
@@ -91,12 +93,17 @@ def main(argv=None) -> None:
     env = BatchedCollisionAvoidanceEnv(count, cfg, device=device, world_offset=offset, seed=1000 * args.seed,
                                        gen_min_agents=min(args.min_agents, N))
     net = NetworkVP_rnn(cfg, seed=args.seed).to(device)
-    trainer = A3CTrainer(net, learning_rate=args.lr)
+    fused = None if (args.torch_policy or net.arch != "rnn") else FusedPolicy(net, seed=1000 * args.seed + rank)
+    if args.autograd_trainer or net.arch != "rnn":
+        trainer = A3CTrainer(net, learning_rate=args.lr)
+    else:
+        trainer = FusedA3CTrainer(net, fused, learning_rate=args.lr)       # shares (or creates) the packed-weight handle
     episodes_before = 0
     if args.load:
         episodes_before = load_checkpoint(args.load, net, trainer, device)
     steps_before = trainer.training_step
-    fused = None if (args.torch_policy or net.arch != "rnn") else FusedPolicy(net, seed=1000 * args.seed + rank)
+    if fused is not None:
+        fused.refresh(with_backward=isinstance(trainer, FusedA3CTrainer))      # weights may have come from a checkpoint
     roll = BatchedRollout(env, fused if fused is not None else net.predict_p_and_v, reflush_done=args.faithful_reflush,
                           greedy=args.play)
     stats = EpisodeStats(print_every=args.print_every if rank == 0 else 0, agents=count)
@@ -125,10 +132,11 @@ def main(argv=None) -> None:
         for k in range(n_chunks):
             lo, hi = k * args.train_rows, min((k + 1) * args.train_rows, len(batch))
             lo = min(lo, hi)
-            trainer.train(batch.x[lo:hi], batch.r[lo:hi], batch.a[lo:hi])
+            trainer.train(batch.x[lo:hi], batch.r[lo:hi], batch.a_index[lo:hi] if isinstance(trainer, FusedA3CTrainer) else batch.a[lo:hi])
             stats.add_training_steps(1)
-        if fused is not None and n_chunks:
+        if fused is not None and n_chunks and not isinstance(trainer, FusedA3CTrainer):
             fused.refresh()                       # the actors see the new weights from the next replay on
+            # (the fused trainer re-packs after every optimiser step itself)
         stats.add_episodes(roll.drain_episodes().tolist())
         finished = stats.episode_count
         if size > 1:
