@@ -229,9 +229,9 @@ int cavoid_policy_forward(cavoid_policy *p, const float *x, int64_t rows, int64_
  * library, sums the bias gradients and takes the optimiser step:
  *   d fullyconnected1 = z2^T g3,  d layer2 = z1^T g2,  d layer1 (rows in packed order: 64 hidden, 4 host) = l1_in^T g1,
  *   d [logits_p | logits_v] = z3^T gh,  d lstm (rows: 64 hidden then 7 inputs; gate columns in packed order
- *   64w + 16 gate + u for unit 16w + u) = sum_t h_in[t]^T gl[t];   bias gradients = column sums of g3, g2, g1, gh, gl.
- * All per-row buffers have `capacity_rows` rows (a multiple of 64, >= rows rounded up to 64); rows past `rows` carry
- * zero gradients.  loss[0] = cost_p, loss[1] = cost_v (sums over rows, NetworkVPCore.py:71-100). */
+ *   64w + 16 gate + u for unit 16w + u) = sum_t h_in[t]^T gl[t];   bias gradients (column sums of g3, g2, g1, gh, gl) come back in `db`.
+ * All per-row buffers have `capacity_rows` rows (a multiple of 64, >= rows rounded up to 64); every one of them is
+ * written by each call, rows past `rows` with zero gradients -- the GEMMs may run over all capacity_rows.  loss[0] = cost_p, loss[1] = cost_v (sums over rows, NetworkVPCore.py:71-100). */
 typedef struct cavoid_policy_train_buffers {
     int32_t struct_size;             /* sizeof(cavoid_policy_train_buffers) */
     int32_t reserved;
@@ -244,6 +244,8 @@ typedef struct cavoid_policy_train_buffers {
     float *loss;                     /* [2] */
     float *g1, *g2, *g3;             /* [capacity_rows, 256] */
     float *gl;                       /* [max_other, capacity_rows, 256] */
+    float *db;                       /* [1040] bias gradients: lstm 256 (packed gate order), layer1, layer2, fullyconnected1 256 each,
+                                        heads 16 (A logits, value, padding) */
 } cavoid_policy_train_buffers;
 int cavoid_policy_train(cavoid_policy *p, const float *x, int64_t rows, int64_t row_stride, const float *y_r, const int32_t *a_idx,
                         float beta, float log_epsilon, const cavoid_policy_train_buffers *buffers, void *stream);

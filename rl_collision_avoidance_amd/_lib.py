@@ -51,7 +51,7 @@ class CavoidPolicyWeights(C.Structure):
 class CavoidPolicyTrainBuffers(C.Structure):
     """Mirror of ``struct cavoid_policy_train_buffers`` (include/cavoid.h)."""
     _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("capacity_rows", C.c_int64)] + [
-        (n, C.c_void_p) for n in ("z1", "z2", "z3", "l1_in", "h_in", "save", "gh", "loss", "g1", "g2", "g3", "gl")]
+        (n, C.c_void_p) for n in ("z1", "z2", "z3", "l1_in", "h_in", "save", "gh", "loss", "g1", "g2", "g3", "gl", "db")]
 
 
 class CavoidError(RuntimeError):

@@ -193,6 +193,7 @@ struct PolicyArgs {
     float *save;                       // [tiles, M, 16, 256, 8] per lane and cell: i, j, f, o, c_{t-1}, tanh(c_t), 0, 0
     float *gh;                         // [rows64, 16] d cost / d (logits_p, logits_v)
     float *loss;                       // [2] cost_p, cost_v (summed over rows)
+    float *db;                         // [kBiasFloats] bias gradients (column sums), same order as the packed biases
 };
 
 // Philox4x32-10, the same generator the scenario generator uses (cavoid_kernels.hpp)
@@ -553,7 +554,7 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
         const f32x4 logit = acc[0] + acc[1] + acc[2] + acc[3];
         const int col = lane & 15, A = p.num_actions;
         const float scale = 1.0f / (1.0f + p.min_policy * (float)A);
-        float cost_p = 0.0f, cost_v = 0.0f;
+        float cost_p = 0.0f, cost_v = 0.0f, gsum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float z = logit[r];
@@ -590,6 +591,7 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
                 float g = col < A ? sm * (dp - dot) : (col == A ? v - y : 0.0f);
                 if (!valid) g = 0.0f;
                 p.gh[(row0 + 16 * wave + 4 * (lane >> 4) + r) * 16 + col] = g;
+                gsum += g;
                 float ent = col < A ? lp * pj : 0.0f;
 #pragma unroll
                 for (int d = 1; d < 16; d <<= 1) ent += __shfl_xor(ent, d, 16);
@@ -628,6 +630,8 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
             cost_p += __shfl_xor(cost_p, 16, 64); cost_p += __shfl_xor(cost_p, 32, 64);
             cost_v += __shfl_xor(cost_v, 16, 64); cost_v += __shfl_xor(cost_v, 32, 64);
             if (lane == 0) { atomicAdd(p.loss, cost_p); atomicAdd(p.loss + 1, cost_v); }
+            gsum += __shfl_xor(gsum, 16, 64); gsum += __shfl_xor(gsum, 32, 64);
+            if (lane < 16) atomicAdd(p.db + kBiasHead + lane, gsum);
         }
     }
     POLICY_STAMP(4);
@@ -661,11 +665,13 @@ struct PolicyBackArgs {
     const float *z1, *z2, *z3, *save, *gh;
     float *g1, *g2, *g3;               // [rows64, 256]
     float *gl;                         // [M, rows64, 256], gate columns in packed order (64w + 16 gate + u)
+    float *db;                         // [kBiasFloats] bias gradients, accumulated with atomics (packed bias order)
 };
 
 // g = acc where the layer's relu was active, else 0 -> LDS (the next GEMM's A operand) and global memory
 template <int RT>
-__device__ __forceinline__ void policy_store_masked(float *act, int ct0, int lane, const f32x4 (&acc)[RT][4], const float *zg, float *gg) {
+__device__ __forceinline__ void policy_store_masked(float *act, int ct0, int lane, const f32x4 (&acc)[RT][4], const float *zg, float *gg,
+                                                    float *db) {
     const int lane_off = (4 * (lane >> 4)) * kPolWidth + 16 * ct0 + (lane & 15);
     const float *zrow = zg + lane_off;
     float *grow = gg + lane_off;
@@ -686,7 +692,20 @@ __device__ __forceinline__ void policy_store_masked(float *act, int ct0, int lan
                 const float g = z[rt][ct][r] > 0.0f ? acc[rt][ct][r] : 0.0f;
                 arow[(16 * rt + r) * kPolStride + 16 * ct] = g;
                 grow[(16 * rt + r) * kPolWidth + 16 * ct] = g;
+                z[rt][ct][r] = g;
             }
+    // bias gradient = column sums: 16 rows per lane, then the 4 lane groups, one atomic per column and wavefront
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += z[rt][ct][r];
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (lane < 16) atomicAdd(db + 16 * (ct0 + ct) + lane, sum);
+    }
 }
 
 template <int RT>
@@ -737,7 +756,7 @@ __global__ void __launch_bounds__(256, 2) policy_backward_kernel(const PolicyBac
         policy_gemm(act, p.frags + kOffTHead, 0, 1, 64, 4 * wave, lane, f0, acc);
         policy_load_b(f0, p.frags + kOffTFc1, 4 * wave, lane, 0);
         __syncthreads();
-        policy_store_masked(act, 4 * wave, lane, acc, p.z3 + row0 * kPolWidth, p.g3 + row0 * kPolWidth);
+        policy_store_masked(act, 4 * wave, lane, acc, p.z3 + row0 * kPolWidth, p.g3 + row0 * kPolWidth, p.db + kBiasFc1);
         __syncthreads();
     }
     {
@@ -746,7 +765,7 @@ __global__ void __launch_bounds__(256, 2) policy_backward_kernel(const PolicyBac
         policy_gemm(act, p.frags + kOffTFc1, 0, kChWide, 64, 4 * wave, lane, f0, acc);
         policy_load_b(f0, p.frags + kOffTL2, 4 * wave, lane, 0);
         __syncthreads();
-        policy_store_masked(act, 4 * wave, lane, acc, p.z2 + row0 * kPolWidth, p.g2 + row0 * kPolWidth);
+        policy_store_masked(act, 4 * wave, lane, acc, p.z2 + row0 * kPolWidth, p.g2 + row0 * kPolWidth, p.db + kBiasL2);
         __syncthreads();
     }
     {
@@ -754,7 +773,7 @@ __global__ void __launch_bounds__(256, 2) policy_backward_kernel(const PolicyBac
         policy_zero_acc(acc);
         policy_gemm(act, p.frags + kOffTL2, 0, kChWide, 64, 4 * wave, lane, f0, acc);
         __syncthreads();
-        policy_store_masked(act, 4 * wave, lane, acc, p.z1 + row0 * kPolWidth, p.g1 + row0 * kPolWidth);
+        policy_store_masked(act, 4 * wave, lane, acc, p.z1 + row0 * kPolWidth, p.g1 + row0 * kPolWidth, p.db + kBiasL1);
         __syncthreads();
     }
     // ---- layer1^T, hidden-state inputs only: d cost / d h_final, one column tile per wavefront = its 16 hidden units --
@@ -779,6 +798,7 @@ __global__ void __launch_bounds__(256, 2) policy_backward_kernel(const PolicyBac
         }
         policy_load_b(n0, p.frags + kOffTLstm, wave, lane, 0);
         f32x4 dc_new[RT];
+        float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};          // gate-bias gradient: column sums of this lane's 16 cells
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -799,7 +819,15 @@ __global__ void __launch_bounds__(256, 2) policy_backward_kernel(const PolicyBac
                 float *g = glt + (int64_t)row * kPolWidth + col;
                 a[0] = d_i; a[16] = d_j; a[32] = d_f; a[48] = d_o;
                 g[0] = d_i; g[16] = d_j; g[32] = d_f; g[48] = d_o;
+                bsum[0] += d_i; bsum[1] += d_j; bsum[2] += d_f; bsum[3] += d_o;
             }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sum = bsum[q];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (lane < 16) atomicAdd(p.db + kBiasLstm + 64 * wave + 16 * q + lane, sum);
+        }
         __syncthreads();
         f32x4 acc1[RT][1];
 #pragma unroll

@@ -128,11 +128,12 @@ extern "C" int cavoid_policy_train(cavoid_policy *h, const float *x, int64_t row
     if (!h || !x || !y_r || !a_idx || !b || b->struct_size != (int32_t)sizeof(cavoid_policy_train_buffers)) return CAVOID_EINVAL;
     if (!h->loaded || !h->backward_loaded || rows < 0 || row_stride < h->in_size) return CAVOID_EINVAL;
     const int64_t rows64 = (rows + 63) / 64 * 64;
-    if (b->capacity_rows < rows64 || !b->z1 || !b->z2 || !b->z3 || !b->l1_in || !b->h_in || !b->save || !b->gh || !b->loss ||
-        !b->g1 || !b->g2 || !b->g3 || !b->gl)
+    if (b->capacity_rows < rows64 || b->capacity_rows % 64 != 0 || !b->z1 || !b->z2 || !b->z3 || !b->l1_in || !b->h_in || !b->save || !b->gh || !b->loss ||
+        !b->g1 || !b->g2 || !b->g3 || !b->gl || !b->db)
         return CAVOID_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(b->loss, 0, 2 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(b->db, 0, kBiasFloats * sizeof(float), s));
     if (rows == 0) return CAVOID_OK;
     const int64_t cap = b->capacity_rows;                  // leading dimension (in rows) of the per-step buffers
     PolicyArgs a{};
@@ -140,13 +141,15 @@ extern "C" int cavoid_policy_train(cavoid_policy *h, const float *x, int64_t row
     a.avg = h->normalize ? h->avg : nullptr; a.std = h->normalize ? h->std : nullptr;
     a.frags = h->frags; a.bias = h->bias; a.min_policy = h->min_policy; a.cu_tickets = h->cu_tickets;
     a.y_r = y_r; a.a_idx = a_idx; a.beta = beta; a.log_eps = log_epsilon; a.rows64 = cap;
-    a.z1 = b->z1; a.z2 = b->z2; a.z3 = b->z3; a.l1_in = b->l1_in; a.h_in = b->h_in; a.save = b->save; a.gh = b->gh; a.loss = b->loss;
-    const unsigned blocks = (unsigned)(rows64 / 64);
+    a.z1 = b->z1; a.z2 = b->z2; a.z3 = b->z3; a.l1_in = b->l1_in; a.h_in = b->h_in; a.save = b->save; a.gh = b->gh; a.loss = b->loss; a.db = b->db;
+    // every tile of the buffers is processed (tiles past `rows` carry zero gradients), so that the caller can run its
+    // weight-gradient GEMMs over a convenient row count without ever reading stale rows
+    const unsigned blocks = (unsigned)(cap / 64);
     hipLaunchKernelGGL((policy_forward_kernel<4, true>), dim3(blocks), dim3(256), policy_lds_bytes(4), s, a);
     HIP_TRY(hipGetLastError());
     PolicyBackArgs k{};
     k.x = x; k.rows = rows; k.stride = row_stride; k.rows64 = cap; k.max_other = h->max_other; k.frags = h->frags;
-    k.z1 = b->z1; k.z2 = b->z2; k.z3 = b->z3; k.save = b->save; k.gh = b->gh; k.g1 = b->g1; k.g2 = b->g2; k.g3 = b->g3; k.gl = b->gl;
+    k.z1 = b->z1; k.z2 = b->z2; k.z3 = b->z3; k.save = b->save; k.gh = b->gh; k.g1 = b->g1; k.g2 = b->g2; k.g3 = b->g3; k.gl = b->gl; k.db = b->db;
     hipLaunchKernelGGL((policy_backward_kernel<4>), dim3(blocks), dim3(256), policy_lds_bytes(4), s, k);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;

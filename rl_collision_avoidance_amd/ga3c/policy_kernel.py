@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from .. import _lib
-from .network import NetworkVP_rnn
+from .network import NetworkVP_rnn, split_k_factor
 
 
 class FusedPolicy(object):
@@ -127,6 +127,10 @@ class FusedA3CTrainer(object):
         c = torch.arange(4 * H, device=self.device)
         gate, w, u = c // H, (c % H) // 16, c % 16
         self._k_of_c = 64 * w + 16 * gate + u
+        # packed LSTM gradient [72 rows: 64 hidden, 7 inputs, pad] x [256 packed columns] -> checkpoint layout [7 + 64, 256]
+        rows = torch.cat([torch.arange(H, H + net.OTHER), torch.arange(0, H)]).to(self.device)
+        self._lstm_flat = (rows.unsqueeze(1) * (4 * H) + self._k_of_c.unsqueeze(0)).reshape(-1)
+        self._l1_rows = torch.cat([torch.arange(H, H + net.HOST), torch.arange(0, H)]).to(self.device)
         self.policy.refresh(with_backward=True)
 
     training_step = property(lambda self: self._base.training_step,
@@ -140,7 +144,7 @@ class FusedA3CTrainer(object):
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             t = {"z1": f(rows64, 256), "z2": f(rows64, 256), "z3": f(rows64, 256), "l1_in": f(rows64, 72), "h_in": f(M, rows64, 72),
                  "save": f(rows64 // 64, M, 16, 256, 8), "gh": f(rows64, 16), "loss": f(2), "g1": f(rows64, 256), "g2": f(rows64, 256),
-                 "g3": f(rows64, 256), "gl": f(M, rows64, 256)}
+                 "g3": f(rows64, 256), "gl": f(M, rows64, 256), "db": f(1040)}
             c = _lib.CavoidPolicyTrainBuffers()
             c.struct_size, c.capacity_rows = C.sizeof(_lib.CavoidPolicyTrainBuffers), rows64
             for k, v in t.items():
@@ -153,23 +157,26 @@ class FusedA3CTrainer(object):
     @staticmethod
     def _xtg(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
         """x^T g over all rows, split-K (see network._SplitKLinear)."""
-        R, S = x.shape[0], 1
-        while S < 64 and R % (2 * S) == 0 and R // (2 * S) >= 256:
-            S *= 2
+        R = x.shape[0]
+        S = split_k_factor(R)
         if S == 1:
             return x.t() @ g
         return torch.bmm(x.view(S, R // S, -1).transpose(1, 2), g.view(S, R // S, -1)).sum(dim=0)
 
-    def train(self, x: torch.Tensor, y_r: torch.Tensor, a: torch.Tensor) -> float:
-        """One optimiser step on the batch.  ``a``: action indices [n] or the reference's one-hot float [n, A]."""
+    def train(self, x: torch.Tensor, y_r: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+        """One optimiser step on the batch.  ``a``: action indices [n] or the reference's one-hot float [n, A].
+        Returns the loss (cost_p + cost_v) as a 0-d device tensor: nothing here waits for the GPU."""
         net, pol = self.net, self.policy
         n = int(x.shape[0])
         if n == 0:
-            return self._base.train(x, y_r, a if a.dim() == 2 else torch.nn.functional.one_hot(a.long(), net.num_actions).float())
+            return torch.as_tensor(self._base.train(x, y_r, a if a.dim() == 2 else
+                                                    torch.nn.functional.one_hot(a.long(), net.num_actions).float()), device=self.device)
         x = x.to(torch.float32).contiguous()
         y_r = y_r.to(torch.float32).contiguous()
         a_idx = (a.argmax(dim=1) if a.dim() == 2 else a).to(torch.int32).contiguous()
-        rows64 = (n + 63) // 64 * 64
+        # buffer rows: a multiple of 2048 (the split-K slice of the weight-gradient GEMMs) once the batch is that large;
+        # the kernels write every buffer row, rows past n with zero gradients
+        rows64 = (n + 2047) // 2048 * 2048 if n >= 2048 else (n + 63) // 64 * 64
         t, cbuf = self._scratch(rows64)
         ptr = lambda v: C.c_void_p(v.data_ptr())
         _lib.check(pol._lib.cavoid_policy_train(pol._h, ptr(x), n, x.stride(0), ptr(y_r), ptr(a_idx), float(net.beta),
@@ -178,22 +185,22 @@ class FusedA3CTrainer(object):
         xtg = self._xtg
         d_head = xtg(t["z3"], t["gh"])
         net.p_kernel.grad, net.v_kernel.grad = d_head[:, :A].contiguous(), d_head[:, A:A + 1].contiguous()
-        b_head = t["gh"].sum(dim=0)
-        net.p_bias.grad, net.v_bias.grad = b_head[:A].contiguous(), b_head[A:A + 1].contiguous()
-        net.fc1_kernel.grad, net.fc1_bias.grad = xtg(t["z2"], t["g3"]), t["g3"].sum(dim=0)
-        net.layer2_kernel.grad, net.layer2_bias.grad = xtg(t["z1"], t["g2"]), t["g2"].sum(dim=0)
+        db = t["db"]                                       # packed bias order: lstm 256 | layer1 | layer2 | fc1 | heads 16
+        loss = t["loss"].sum()
+        net.p_bias.grad, net.v_bias.grad = db[1024:1024 + A], db[1024 + A:1025 + A]
+        net.fc1_kernel.grad, net.fc1_bias.grad = xtg(t["z2"], t["g3"]), db[768:1024]
+        net.layer2_kernel.grad, net.layer2_bias.grad = xtg(t["z1"], t["g2"]), db[512:768]
         d_l1 = xtg(t["l1_in"], t["g1"])                                     # rows: 64 hidden, 4 host, 4 padding
-        net.layer1_kernel.grad = torch.cat([d_l1[H:H + net.HOST], d_l1[:H]], dim=0)
-        net.layer1_bias.grad = t["g1"].sum(dim=0)
+        net.layer1_kernel.grad = d_l1.index_select(0, self._l1_rows)
+        net.layer1_bias.grad = db[256:512]
         gl = t["gl"].view(M * rows64, 4 * H)
         d_lstm = xtg(t["h_in"].view(M * rows64, 72), gl)                   # rows: 64 hidden, 7 inputs, 1 padding; packed gate columns
-        d_lstm = torch.cat([d_lstm[H:H + net.OTHER], d_lstm[:H]], dim=0)
-        net.lstm_kernel.grad = d_lstm.index_select(1, self._k_of_c)
-        net.lstm_bias.grad = gl.sum(dim=0).index_select(0, self._k_of_c)
+        net.lstm_kernel.grad = d_lstm.reshape(-1).index_select(0, self._lstm_flat).view(H + net.OTHER, 4 * H)
+        net.lstm_bias.grad = db[:256].index_select(0, self._k_of_c)
         if self._base.distributed:
             self._base._allreduce_grads()
         self.opt.step()
         self._base.training_step += 1
         self._base.frame_counter += n
         pol.refresh(with_backward=True)                    # actors and the next training pass see the new weights
-        return float(t["loss"].sum())
+        return loss

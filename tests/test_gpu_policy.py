@@ -214,7 +214,7 @@ def test_fused_trainer_gradients_match_autograd(M, B, min_policy):
     net.loss(x, y, onehot)[0].backward()
     torch32 = {k: v.grad.clone() for k, v in net.named_parameters()}
     tr = FusedA3CTrainer(net, learning_rate=0.0)             # lr 0: the optimiser step leaves the weights alone
-    loss = tr.train(x, y, a)
+    loss = float(tr.train(x, y, a))
     assert abs(loss - float(total.detach())) <= 2e-4 * max(1.0, abs(float(total.detach())))
     for k, v in net.named_parameters():
         ref = want[k]
@@ -246,7 +246,7 @@ def test_fused_trainer_learns_like_the_autograd_trainer():
         y = torch.randn(4096, generator=g).cuda()
         a = torch.randint(0, 11, (4096,), generator=g).cuda()
         la = ta.train(x, y, torch.nn.functional.one_hot(a, 11).float())
-        lb = tb.train(x, y, a)
+        lb = float(tb.train(x, y, a))
         assert abs(la - lb) <= 1e-3 * max(1.0, abs(la))
     for (k, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
         assert (pa - pb).abs().max().item() <= 2e-5, k
