@@ -1,4 +1,6 @@
-// cavoid_policy.hpp -- NetworkVP_rnn inference (the actors' predict_p_and_v) as ONE gfx950 kernel.
+// cavoid_policy.hpp -- NetworkVP_rnn on the gfx950 matrix cores: the actors' predict_p_and_v + select_action as ONE
+// kernel (policy_forward_kernel<RT, false>), and the trainer's pass over a batch as two (policy_forward_kernel<RT, true>:
+// forward + A3C loss + gradient at the heads; policy_backward_kernel: everything row-local of the backward pass).
 //
 // What it computes (citations: /root/reference/ga3c/GA3C):
 //   x [rows, 5+7M] -> (x - avg) / std                                        NetworkVP_rnn.py:50-53
@@ -21,6 +23,8 @@
 //     lane feeds 4 MFMAs, 1 KB contiguous per wave instruction, L2-resident (688 KB in all);
 //   * a K chunk is 16 wide: lane group g = lane/16 supplies k = 16*chunk + 4g + s in MFMA s = 0..3
 //     (any fixed bijection of k works as long as A and B agree).
+// The backward pass is the same machinery on transposed fragment packs (dX = dY x W^T); the weight gradients X^T G
+// are large plain GEMMs over all rows and are left to the GEMM library (see policy_backward_kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
