@@ -123,29 +123,33 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         def run(n_replays):
             for _ in range(n_replays):
                 roll.replay(1)
+                b = roll.drain(provenance=False)             # hand-over of the rows that became training rows (the PPS numerator)
+                rows[0] += len(b)
                 if not train:
                     continue
-                b = roll.drain()
                 for lo in range(0, len(b), train_rows):
                     trainer.train(b.x[lo:lo + train_rows], b.r[lo:lo + train_rows],
                                   b.a_index[lo:lo + train_rows] if fused_trainer else b.a[lo:lo + train_rows])
-                rows[0] += len(b)
                 if pol is not None and len(b) and not fused_trainer:
                     pol.refresh()
-            return n_replays * per_graph * W * N             # all agents learn in this workload
+            return n_replays * per_graph * W * N
         run(8)
         rows[0] = 0
         sync_all()
         t0 = time.perf_counter()
-        frames = run(steps // per_graph)
+        policy_rows = run(steps // per_graph)
         sync_all()
         dt = time.perf_counter() - t0
         n = (steps // per_graph) * per_graph
-        out = {"learning_agent_steps_per_s_per_gpu": frames / dt, "ms_per_env_step": dt * 1e3 / n, "env_steps": n,
-               "rows_trained": rows[0], "training_steps": trainer.training_step}
+        # PPS as the reference counts it (ProcessStats.py:54-56; ProcessAgent.py:237): experiences handed to the trainer.
+        # Agents that are done and wait for their world to end still occupy a policy row but yield nothing.
+        out = {"learning_agent_steps_per_s_per_gpu": rows[0] / dt, "policy_rows_per_s_per_gpu": policy_rows / dt,
+               "ms_per_env_step": dt * 1e3 / n, "env_steps": n, "rows_handed_over": rows[0],
+               "training_steps": trainer.training_step if train else 0}
         roll.close()
         env.close()
         return out
+
     def policy_kernel():
         """The fused inference kernel alone, on real observations: HIP events on the launch stream."""
         env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)

@@ -184,6 +184,15 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
                         float *dup_x, float *dup_r, int32_t *dup_a, int32_t *dup_src, int32_t *dup_count, int64_t dup_capacity,
                         float *ep_out, int32_t *ep_count, int64_t ep_capacity, void *stream);
 
+/* hand-over to the trainer (`training_q.put((x_, r_, a_))`, ProcessAgent.py:238): append the training rows (emit_t >= 0) of
+ * the step blocks [step_lo, step_hi) to one batch -- out_x float [capacity, D], out_r float [capacity] (n-step returns),
+ * out_a int32 [capacity], out_src int32 [capacity, 4] (world, agent, recorded-at, emitted-at; may be NULL),
+ * out_count int32 [2] = (rows appended, rows dropped for lack of capacity), zeroed by the call.  Row order is unspecified.
+ * mark_taken != 0 stamps the rows emit_t = -2 (they are not handed out again). */
+int cavoid_rollout_compact(cavoid_rollout *r, int32_t step_lo, int32_t step_hi, int32_t mark_taken, const float *x, const float *ret,
+                           const uint8_t *act, int32_t *emit_t, float *out_x, float *out_r, int32_t *out_a, int32_t *out_src,
+                           int32_t *out_count, int64_t capacity, void *stream);
+
 /* ---- fused policy inference (the actors' predict + select_action) ------------------------------------
  * Stands in for `NetworkVPCore.predict_p_and_v(x)` (ga3c/GA3C/NetworkVPCore.py:175-176) on the graph
  * `NetworkVP_rnn._create_graph` builds for MULTI_AGENT_ARCH 'RNN' (ga3c/GA3C/NetworkVP_rnn.py:50-67,103-105;

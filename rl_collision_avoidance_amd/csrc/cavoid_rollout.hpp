@@ -263,4 +263,53 @@ __global__ void __launch_bounds__(256) rollout_episode_kernel(const RolloutCfg c
     s.ep_length[w] = 0;
 }
 
+// ---- hand-over: compact the emitted rows of the step blocks [step_lo, step_hi) into one batch -----------------
+struct CompactArgs {
+    int32_t step_lo, step_hi;
+    int32_t mark_taken;      // 1: stamp the rows emit_t = -2 so that they are not handed out twice (flush_all)
+    const float *x;          // [ring_len][slots][D]
+    const float *ret;        // [ring_len][slots]
+    const uint8_t *act;      // [ring_len][slots]
+    int32_t *emit_t;         // [ring_len][slots]
+    float *out_x;            // [capacity][D]
+    float *out_r;            // [capacity]
+    int32_t *out_a;          // [capacity]
+    int32_t *out_src;        // [capacity][4] (world, agent, recorded-at step, emitted-at step) or nullptr
+    int32_t *out_count;      // [2] rows appended, rows dropped for lack of capacity
+    int64_t capacity;
+};
+
+// One lane per (step block, slot); a wavefront appends its emitted rows with one atomic (ballot + prefix count).
+// Row order inside the batch is unspecified (the A3C loss is a sum over rows).
+__global__ void __launch_bounds__(256) rollout_compact_kernel(const RolloutCfg c, const CompactArgs a) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int step = a.step_lo + (int)blockIdx.y;
+    const int lane = threadIdx.x & 63, D = c.obs_width - 1;
+    const int64_t row = (int64_t)(step % c.ring_len) * c.num_slots + slot;
+    int32_t emitted = -1;
+    if (slot < c.num_slots) emitted = a.emit_t[row];
+    const bool take = emitted >= 0;
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0ull) return;
+    const int count = __popcll(mask), rank = __popcll(mask & ((1ull << lane) - 1ull));
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(a.out_count, count);
+    base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+    if (!take) return;
+    const int64_t dst = (int64_t)base + rank;
+    if (dst >= a.capacity) { atomicAdd(a.out_count + 1, 1); return; }
+    const float *src = a.x + row * D;
+    float *out = a.out_x + dst * D;
+    for (int k = 0; k < D; ++k) out[k] = src[k];
+    a.out_r[dst] = a.ret[row];
+    a.out_a[dst] = (int32_t)a.act[row];
+    if (a.out_src) {
+        a.out_src[4 * dst + 0] = (int32_t)(slot / c.max_agents);
+        a.out_src[4 * dst + 1] = (int32_t)(slot % c.max_agents);
+        a.out_src[4 * dst + 2] = step;
+        a.out_src[4 * dst + 3] = emitted;
+    }
+    if (a.mark_taken) a.emit_t[row] = -2;
+}
+
 }  // namespace cavoid

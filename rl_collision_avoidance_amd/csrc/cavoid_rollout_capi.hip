@@ -86,3 +86,21 @@ extern "C" int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, con
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }
+
+extern "C" int cavoid_rollout_compact(cavoid_rollout *r, int32_t step_lo, int32_t step_hi, int32_t mark_taken, const float *x,
+                                      const float *ret, const uint8_t *act, int32_t *emit_t, float *out_x, float *out_r,
+                                      int32_t *out_a, int32_t *out_src, int32_t *out_count, int64_t capacity, void *stream) {
+    if (!r || !x || !ret || !act || !emit_t || !out_x || !out_r || !out_a || !out_count || capacity < 0 || step_lo < 0 ||
+        step_hi < step_lo || step_hi - step_lo > 65535)
+        return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(out_count, 0, 2 * sizeof(int32_t), s));
+    if (step_hi == step_lo) return CAVOID_OK;
+    CompactArgs a{};
+    a.step_lo = step_lo; a.step_hi = step_hi; a.mark_taken = mark_taken ? 1 : 0; a.x = x; a.ret = ret; a.act = act; a.emit_t = emit_t;
+    a.out_x = out_x; a.out_r = out_r; a.out_a = out_a; a.out_src = out_src; a.out_count = out_count; a.capacity = capacity;
+    const dim3 grid((unsigned)((r->c.num_slots + 255) / 256), (unsigned)(step_hi - step_lo));
+    hipLaunchKernelGGL(rollout_compact_kernel, grid, dim3(256), 0, s, r->c, a);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}

@@ -195,42 +195,44 @@ class BatchedRollout(object):
             lo = oldest_alive
         return lo, hi
 
-    def drain(self, flush_all: bool = False) -> TrainingBatch:
+    def drain(self, flush_all: bool = False, provenance: bool = True) -> TrainingBatch:
         """Hand the final rows to the trainer (``training_q.put((x_, r_, a_))``, :238).  ``flush_all``
-        also takes the not-yet-final blocks' emitted rows (end of a run / tests).  One device-side
-        compaction (boolean-mask gather); synchronises."""
+        also takes the not-yet-final blocks' emitted rows (end of a run / tests).  One compaction launch
+        (``cavoid_rollout_compact``) and one read-back of the row count; ``provenance=False`` skips the
+        per-row (world, agent, recorded-at, emitted-at) record that only tests look at."""
         lo, hi = self.pending_final_steps()
         if flush_all:
             hi = self.step_index
-        W, N = self.env.num_worlds, self.env.max_agents
-        xs, rs, as_, srcs = [], [], [], []
-        if hi > lo:
-            steps = torch.arange(lo, hi, device=self.env.device)
-            blocks = steps % self.ring_len
-            valid = self.emit_t[blocks] >= 0                                 # [k, slots]: emitted rows
-            idx = valid.nonzero(as_tuple=False)                              # [n, 2] (block position, slot)
-            b, sl = blocks[idx[:, 0]], idx[:, 1]
-            xs.append(self.x[b, sl])
-            rs.append(self.ret[b, sl])
-            as_.append(self.act_ring[b, sl].to(torch.int32))
-            srcs.append(torch.stack([(sl // N).to(torch.int32), (sl % N).to(torch.int32), steps[idx[:, 0]].to(torch.int32),
-                                     self.emit_t[b, sl]], dim=1))
-            if flush_all:
-                self.emit_t[b, sl] = -2                                      # do not hand these out twice
-            self.drained_until = hi if not flush_all else self.drained_until
-            if not flush_all:
-                self.drained_until = hi
-        n_dup, dropped = [int(v) for v in self.dup_count.tolist()]
+        S, D, dev = self.slots, self.env.obs_width - 1, self.env.device
+        cap = max(hi - lo, 0) * S
+        out_x = torch.empty((cap, D), dtype=torch.float32, device=dev)
+        out_r = torch.empty((cap,), dtype=torch.float32, device=dev)
+        out_a = torch.empty((cap,), dtype=torch.int32, device=dev)
+        out_src = torch.empty((cap, 4), dtype=torch.int32, device=dev) if provenance else None
+        counts = torch.empty((2,), dtype=torch.int32, device=dev)
+        p = BatchedCollisionAvoidanceEnv._ptr
+        n = 0
+        for s0 in range(lo, max(hi, lo), 65535):                            # (one launch unless a test flushes > 65535 steps)
+            s1 = min(hi, s0 + 65535)
+            _lib.check(self._lib.cavoid_rollout_compact(
+                self._h, s0, s1, 1 if flush_all else 0, p(self.x), p(self.ret), p(self.act_ring), p(self.emit_t),
+                C.c_void_p(out_x[n:].data_ptr()), C.c_void_p(out_r[n:].data_ptr()), C.c_void_p(out_a[n:].data_ptr()),
+                C.c_void_p(out_src[n:].data_ptr()) if provenance else None, p(counts), cap - n, self.env._stream()),
+                "cavoid_rollout_compact")
+            if s1 < hi:
+                n += int(counts[0].item())
+        got, _, n_dup, dropped = torch.cat([counts, self.dup_count]).tolist() if hi > lo else [0, 0] + self.dup_count.tolist()
+        n += int(got)                                                       # (the one read-back of a normal drain)
+        if not flush_all:
+            self.drained_until = max(hi, lo)
+        xs, rs, as_, srcs = [out_x[:n]], [out_r[:n]], [out_a[:n]], [out_src[:n] if provenance else None]
         n_dup = min(n_dup, self.dup_capacity)
         if n_dup:
             xs.append(self.dup_x[:n_dup].clone()); rs.append(self.dup_r[:n_dup].clone())
-            as_.append(self.dup_a[:n_dup].clone()); srcs.append(self.dup_src[:n_dup].clone())
-        self.dup_count.zero_()
-        D = self.env.obs_width - 1
-        dev = self.env.device
-        cat = lambda parts, shape, dt: torch.cat(parts) if parts else torch.empty(shape, dtype=dt, device=dev)
-        batch = TrainingBatch(cat(xs, (0, D), torch.float32), cat(rs, (0,), torch.float32), cat(as_, (0,), torch.int32),
-                              cat(srcs, (0, 4), torch.int32), self.env.num_actions, dropped + 0)
+            as_.append(self.dup_a[:n_dup].clone()); srcs.append(self.dup_src[:n_dup].clone() if provenance else None)
+            self.dup_count.zero_()
+        cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts)
+        batch = TrainingBatch(cat(xs), cat(rs), cat(as_), cat(srcs) if provenance else None, self.env.num_actions, dropped + 0)
         self.frames += len(batch)
         return batch
 

@@ -120,7 +120,7 @@ def main(argv=None) -> None:
         trainer.opt.param_groups[0]["lr"] = args.lr + ((args.lr_end if args.lr_end is not None else args.lr) - args.lr) * frac
         net.beta = args.beta + ((args.beta_end if args.beta_end is not None else args.beta) - args.beta) * frac
         roll.replay(1)
-        batch = roll.drain()
+        batch = roll.drain(provenance=False)
         # multi-GPU: every rank must enter the same number of gradient all-reduces
         n_chunks = max(1, -(-len(batch) // args.train_rows)) if (len(batch) > 0 or size > 1) else 0
         if args.play:
