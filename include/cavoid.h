@@ -193,6 +193,14 @@ int cavoid_rollout_compact(cavoid_rollout *r, int32_t step_lo, int32_t step_hi, 
                            const uint8_t *act, int32_t *emit_t, float *out_x, float *out_r, int32_t *out_a, int32_t *out_src,
                            int32_t *out_count, int64_t capacity, void *stream);
 
+/* the (world, agent) slots that still need a policy output: learning agents that have not finished (an agent that is done
+ * waits for its world's last learning agent; the env ignores its action -- ProcessAgent.py:149-211).  obs = the observation
+ * the policy is about to act on [W,N,1+D]; done / game_over = the outputs of the step that produced it (after a reset:
+ * game_over = 1 everywhere).  row_index int32 [W*N] receives the slot ids in unspecified order, row_count int32 [1] their
+ * number; both stay on the device (cavoid_policy_forward_rows reads them there). */
+int cavoid_rollout_active_rows(cavoid_rollout *r, const float *obs, const uint8_t *done, const uint8_t *game_over,
+                               int32_t *row_index, int32_t *row_count, void *stream);
+
 /* ---- fused policy inference (the actors' predict + select_action) ------------------------------------
  * Stands in for `NetworkVPCore.predict_p_and_v(x)` (ga3c/GA3C/NetworkVPCore.py:175-176) on the graph
  * `NetworkVP_rnn._create_graph` builds for MULTI_AGENT_ARCH 'RNN' (ga3c/GA3C/NetworkVP_rnn.py:50-67,103-105;
@@ -229,6 +237,11 @@ int cavoid_policy_load(cavoid_policy *p, const cavoid_policy_weights *w, void *s
 int cavoid_policy_seed(cavoid_policy *p, uint64_t seed, void *stream);
 int cavoid_policy_forward(cavoid_policy *p, const float *x, int64_t rows, int64_t row_stride, float *p_out, float *v_out,
                           int32_t *actions_out, int32_t greedy, void *stream);
+/* as cavoid_policy_forward, for the rows row_index[0 .. *row_count) only (device-side list and count: the launch geometry
+ * does not depend on them, so the call can sit in a hipGraph); outputs of the other rows are left untouched */
+int cavoid_policy_forward_rows(cavoid_policy *p, const float *x, int64_t rows, int64_t row_stride, const int32_t *row_index,
+                               const int32_t *row_count, float *p_out, float *v_out, int32_t *actions_out, int32_t greedy,
+                               void *stream);
 
 /* ---- fused trainer pass (Server.train_model -> NetworkVPCore.train, ga3c/GA3C/Server.py:114-124, NetworkVPCore.py:71-100,178-187)
  * Forward + loss + the row-local part of the backward pass of the same network, for a batch of training rows

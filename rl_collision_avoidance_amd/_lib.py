@@ -91,6 +91,8 @@ SYMBOLS = [
     ("cavoid_rollout_reset", C.c_int, [_P, _P]),
     ("cavoid_rollout_push", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32] + [_P] * 10 + [C.c_int64, _P, _P, C.c_int64, _P]),
     ("cavoid_rollout_compact", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32] + [_P] * 9 + [C.c_int64, _P]),
+    ("cavoid_rollout_active_rows", C.c_int, [_P] * 7),
+    ("cavoid_policy_forward_rows", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
     ("cavoid_policy_create", C.c_int, [C.c_int32, C.c_int32, C.c_int, C.POINTER(_P)]),
     ("cavoid_policy_destroy", None, [_P]),
     ("cavoid_policy_load", C.c_int, [_P, C.POINTER(CavoidPolicyWeights), _P]),

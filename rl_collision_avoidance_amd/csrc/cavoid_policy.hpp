@@ -59,8 +59,8 @@ constexpr int64_t kOffTLstm = kOffTL1 + kChWide * kFragPerChunkNarrow;      // K
 constexpr int64_t kPackFragsTrain = kOffTLstm + kChWide * kFragPerChunkNarrow;
 // biases, in packed column order: lstm 256 (forget bias folded in), l1 256, l2 256, fc1 256, head 16
 constexpr int kBiasLstm = 0, kBiasL1 = 256, kBiasL2 = 512, kBiasFc1 = 768, kBiasHead = 1024, kBiasFloats = 1040;
-constexpr size_t policy_lds_bytes(int row_tiles) {       // 64 rows: 70 752 B (2 workgroups per CU); 32 rows: 37 472 B (4 per CU)
-    return (size_t)(16 * row_tiles * kPolStride + kBiasFloats + 8) * sizeof(float);
+constexpr size_t policy_lds_bytes(int row_tiles) {       // 64 rows: 71 008 B (2 workgroups per CU)
+    return (size_t)(16 * row_tiles * kPolStride + kBiasFloats + 8 + 16 * row_tiles) * sizeof(float);
 }
 
 struct PolicyWeights {                 // device pointers, TensorFlow layout ([in, out] kernels)
@@ -185,6 +185,11 @@ struct PolicyArgs {
     int32_t *step_counter;             // device-side: keys the random stream, advanced once per launch
     uint32_t *blocks_done;
     uint32_t *cu_tickets;              // [kPolCuSlots] arrival counters, one per compute unit (see the kernel)
+    // optional row list (inference): process only rows row_index[0 .. *row_count), e.g. the agents that still act --
+    // an agent that has finished waits for its world to end and needs no policy output.  Both live on the device, so
+    // the launch geometry stays fixed (hipGraph replays): workgroups past the count leave at once.
+    const int32_t *row_index;
+    const int32_t *row_count;
     // TRAIN instantiation only (the trainer's forward pass): targets, the activations the backward pass and the
     // weight-gradient GEMMs need, and the gradient at the heads.  rows64 = rows rounded up to the 64-row tile.
     const float *y_r;                  // [rows] n-step returns
@@ -337,6 +342,19 @@ __device__ __forceinline__ int policy_div(int e, int d, float inv_d) {
     return q;
 }
 
+// the last workgroup of a launch that selects actions advances the device-side launch counter
+__device__ __forceinline__ void policy_finish(const PolicyArgs &p, int step, int tid) {
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(p.blocks_done, 1u) == gridDim.x - 1u) {
+            *p.blocks_done = 0u;
+            *p.step_counter = step + 1;
+            __threadfence();
+        }
+    }
+}
+
 template <int RT, bool TRAIN>
 __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_forward_kernel(const PolicyArgs p) {
     constexpr int kRows = 16 * RT;
@@ -346,11 +364,17 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
     float *lds_bias = act + kRows * kPolStride;
     int *wave_max = reinterpret_cast<int *>(lds_bias + kBiasFloats);
     int &ticket = wave_max[4];
+    int *tile_row = wave_max + 8;                          // [kRows] global row of each tile row (identity without a row list)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t row0 = (int64_t)blockIdx.x * kRows;
-    const int rows_here = p.rows - row0 < kRows ? (int)(p.rows - row0) : kRows;
+    const int64_t n_rows = (!TRAIN && p.row_count) ? (int64_t)*p.row_count : p.rows;
+    const int rows_here = n_rows - row0 < kRows ? (int)(n_rows - row0 > 0 ? n_rows - row0 : 0) : kRows;
     const int M = p.max_other;
     const int step = (!TRAIN && p.actions_out) ? *p.step_counter : 0;
+    if (!TRAIN && p.row_index && rows_here == 0) {         // uniform over the workgroup: nothing listed for this tile
+        if (p.actions_out) policy_finish(p, step, threadIdx.x);
+        return;
+    }
     POLICY_STAMP(0);
 #ifdef CAVOID_TRACE
     const unsigned long long trace_c0 = clock64();
@@ -365,8 +389,13 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
     // ---- input tile: gather + normalise into the padded layout above ------------------------------------------
     // One trip to memory: every global load of the prologue (inputs, normalisation vectors, biases) is issued
     // before the first of them is consumed.
+    if (!TRAIN && p.row_index) {                           // one extra (tiny) trip to memory: the tile's row list
+        if (tid < kRows) tile_row[tid] = tid < rows_here ? p.row_index[row0 + tid] : 0;
+        __syncthreads();
+    }
+    const bool listed = !TRAIN && p.row_index != nullptr;
     {
-        const float *src = p.x + row0 * p.stride;
+        const float *src = listed ? p.x : p.x + row0 * p.stride;
         const int wpad = 16 + 8 * M + 8;                   // padded row: [num,0,0,0, host(4), M x (x_t(7),0), 16 zeros]
         const float inv_wpad = 1.0f / (float)wpad;
         const int total = kRows * wpad;
@@ -397,7 +426,7 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
                 else if (c >= 8 && c < 8 + 8 * M && (c & 7) != 7) sc = 1 + kPolHost + kPolOther * ((c - 8) >> 3) + (c & 7);
                 const bool in = e < total && sc >= 0 && r < rows_here;
                 dst[u] = e < total ? r * kPolStride + kPolXCol + c : -1;
-                v[u] = in ? src[(int64_t)r * p.stride + sc] : 0.0f;
+                v[u] = in ? src[(int64_t)(listed ? tile_row[r] : r) * p.stride + sc] : 0.0f;
                 const bool norm = in && sc > 0 && p.avg != nullptr;
                 av[u] = norm ? p.avg[sc] : 0.0f;
                 sd[u] = norm ? p.std[sc] : 1.0f;
@@ -569,7 +598,9 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
             float sum = e;
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);
-            const int64_t row = row0 + 16 * wave + 4 * (lane >> 4) + r;
+            const int trow = 16 * wave + 4 * (lane >> 4) + r;             // row of the tile
+            const bool in_tile = TRAIN || trow < rows_here;
+            const int64_t row = listed ? (in_tile ? (int64_t)tile_row[trow] : p.rows) : row0 + trow;     // global row
             const float sm = e / sum;                      // softmax
             const float pj = col < A ? (sm + p.min_policy) * scale : 0.0f;
             if (!TRAIN && row < p.rows) {
@@ -642,17 +673,7 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
 #ifdef CAVOID_TRACE
     if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
 #endif
-    if (!TRAIN && p.actions_out) {                         // the last workgroup to finish advances the step counter
-        __syncthreads();
-        if (tid == 0) {
-            __threadfence();
-            if (atomicAdd(p.blocks_done, 1u) == gridDim.x - 1u) {
-                *p.blocks_done = 0u;
-                *p.step_counter = step + 1;
-                __threadfence();
-            }
-        }
-    }
+    if (!TRAIN && p.actions_out) policy_finish(p, step, tid);
 }
 
 // ---- backward (trainer) ---------------------------------------------------------------------------------

@@ -102,8 +102,8 @@ extern "C" int cavoid_policy_seed(cavoid_policy *h, uint64_t seed, void *stream)
     return CAVOID_OK;
 }
 
-extern "C" int cavoid_policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_t row_stride, float *p_out, float *v_out,
-                                     int32_t *actions_out, int32_t greedy, void *stream) {
+static int policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_t row_stride, const int32_t *row_index,
+                          const int32_t *row_count, float *p_out, float *v_out, int32_t *actions_out, int32_t greedy, void *stream) {
     if (!h || !x || !p_out || !v_out || rows < 0 || row_stride < h->in_size || row_stride > 256) return CAVOID_EINVAL;
     if (!h->loaded) return CAVOID_EINVAL;
     if (rows == 0) return CAVOID_OK;
@@ -114,12 +114,25 @@ extern "C" int cavoid_policy_forward(cavoid_policy *h, const float *x, int64_t r
     a.actions_out = actions_out; a.greedy = greedy ? 1 : 0;
     a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
     a.step_counter = h->step_counter; a.blocks_done = h->blocks_done; a.cu_tickets = h->cu_tickets;
+    a.row_index = row_index; a.row_count = row_count;
     const int tile = 16 * h->row_tiles;
     const int64_t blocks = (rows + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
     hipLaunchKernelGGL((policy_forward_kernel<4, false>), dim3((unsigned)blocks), dim3(256), policy_lds_bytes(4), static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
+}
+
+extern "C" int cavoid_policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_t row_stride, float *p_out, float *v_out,
+                                     int32_t *actions_out, int32_t greedy, void *stream) {
+    return policy_forward(h, x, rows, row_stride, nullptr, nullptr, p_out, v_out, actions_out, greedy, stream);
+}
+
+extern "C" int cavoid_policy_forward_rows(cavoid_policy *h, const float *x, int64_t rows, int64_t row_stride, const int32_t *row_index,
+                                          const int32_t *row_count, float *p_out, float *v_out, int32_t *actions_out, int32_t greedy,
+                                          void *stream) {
+    if (!row_index || !row_count) return CAVOID_EINVAL;
+    return policy_forward(h, x, rows, row_stride, row_index, row_count, p_out, v_out, actions_out, greedy, stream);
 }
 
 extern "C" int cavoid_policy_train(cavoid_policy *h, const float *x, int64_t rows, int64_t row_stride, const float *y_r,

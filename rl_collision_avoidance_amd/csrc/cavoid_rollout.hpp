@@ -263,6 +263,29 @@ __global__ void __launch_bounds__(256) rollout_episode_kernel(const RolloutCfg c
     s.ep_length[w] = 0;
 }
 
+// ---- the rows that still need a policy output ------------------------------------------------------------------
+// (world, agent) slots whose agent is learning and has not finished: obs column 0 (is_learning) is set, and either the
+// world has just restarted (game_over of the step that produced this observation) or the agent was not done in it.
+// A finished agent waits for its world's last learning agent (ProcessAgent.py:149-211 keeps stepping the env with
+// whatever action; the env ignores it) -- it needs no forward pass.  Order of the list is unspecified.
+__global__ void rollout_zero_kernel(int32_t *counter) { *counter = 0; }
+
+__global__ void __launch_bounds__(256) rollout_active_kernel(const RolloutCfg c, const float *obs, const uint8_t *done,
+                                                             const uint8_t *game_over, int32_t *row_index, int32_t *row_count) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool active = false;
+    if (slot < c.num_slots)
+        active = obs[slot * c.obs_width] > 0.5f && (game_over[slot / c.max_agents] != 0 || done[slot] == 0);
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0ull) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(row_count, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (active) row_index[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)slot;
+}
+
 // ---- hand-over: compact the emitted rows of the step blocks [step_lo, step_hi) into one batch -----------------
 struct CompactArgs {
     int32_t step_lo, step_hi;

@@ -104,3 +104,14 @@ extern "C" int cavoid_rollout_compact(cavoid_rollout *r, int32_t step_lo, int32_
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }
+
+extern "C" int cavoid_rollout_active_rows(cavoid_rollout *r, const float *obs, const uint8_t *done, const uint8_t *game_over,
+                                          int32_t *row_index, int32_t *row_count, void *stream) {
+    if (!r || !obs || !done || !game_over || !row_index || !row_count) return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rollout_zero_kernel, dim3(1), dim3(1), 0, s, row_count);      // (a kernel, not a memset node: see DESIGN)
+    hipLaunchKernelGGL(rollout_active_kernel, dim3((unsigned)((r->c.num_slots + 255) / 256)), dim3(256), 0, s, r->c, obs, done,
+                       game_over, row_index, row_count);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}

@@ -77,32 +77,39 @@ class FusedPolicy(object):
             self._keep.append(t)
         return t
 
-    def forward(self, x: torch.Tensor, sample: Optional[bool] = None, greedy: bool = False
+    def forward(self, x: torch.Tensor, sample: Optional[bool] = None, greedy: bool = False,
+                rows: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         """x float32 [B, input_size] (rows may be strided: a column slice of the env's obs tensor) ->
-        (p [B, A], v [B], actions int32 [B] or None)."""
+        (p [B, A], v [B], actions int32 [B] or None).  ``rows`` = (row_index int32 [B], row_count int32 [1]) on the
+        device restricts the pass to the listed rows; the others' outputs are zero."""
         if x.dim() != 2 or x.shape[1] != self.input_size or x.dtype != torch.float32 or x.device != self.device:
             raise ValueError("x must be float32 [B, %d] on %s" % (self.input_size, self.device))
         if x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < self.input_size):
             x = x.contiguous()
         B = x.shape[0]
         stride = x.stride(0) if B > 1 else self.input_size
-        p = torch.empty((B, self.num_actions), dtype=torch.float32, device=self.device)
-        v = torch.empty((B,), dtype=torch.float32, device=self.device)
+        new = torch.zeros if rows is not None else torch.empty
+        p = new((B, self.num_actions), dtype=torch.float32, device=self.device)
+        v = new((B,), dtype=torch.float32, device=self.device)
         want_actions = greedy if sample is None else (sample or greedy)
-        a = torch.empty((B,), dtype=torch.int32, device=self.device) if want_actions else None
-        _lib.check(self._lib.cavoid_policy_forward(self._h, C.c_void_p(x.data_ptr()), B, stride, C.c_void_p(p.data_ptr()),
-                                                   C.c_void_p(v.data_ptr()), C.c_void_p(a.data_ptr()) if a is not None else None,
-                                                   1 if greedy else 0, self._stream()), "cavoid_policy_forward")
+        a = new((B,), dtype=torch.int32, device=self.device) if want_actions else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        if rows is None:
+            _lib.check(self._lib.cavoid_policy_forward(self._h, ptr(x), B, stride, ptr(p), ptr(v), ptr(a), 1 if greedy else 0,
+                                                       self._stream()), "cavoid_policy_forward")
+        else:
+            _lib.check(self._lib.cavoid_policy_forward_rows(self._h, ptr(x), B, stride, ptr(rows[0]), ptr(rows[1]), ptr(p), ptr(v),
+                                                            ptr(a), 1 if greedy else 0, self._stream()), "cavoid_policy_forward_rows")
         return p, v, a
 
     def __call__(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         p, v, _ = self.forward(x, sample=False)
         return p, v
 
-    def act(self, x: torch.Tensor, greedy: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def act(self, x: torch.Tensor, greedy: bool = False, rows=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """predict + select_action (ProcessAgent.py:89-103,128-144): (actions int32 [B], p, v)."""
-        p, v, a = self.forward(x, sample=True, greedy=greedy)
+        p, v, a = self.forward(x, sample=True, greedy=greedy, rows=rows)
         return a, p, v
 
 

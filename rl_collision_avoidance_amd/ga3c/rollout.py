@@ -45,12 +45,19 @@ class BatchedRollout(object):
     def __init__(self, env: BatchedCollisionAvoidanceEnv, policy: Optional[Policy], time_max: Optional[int] = None,
                  discount: float = 0.97, ring_len: Optional[int] = None, dup_capacity: Optional[int] = None,
                  episode_capacity: Optional[int] = None, reflush_done: bool = True, greedy: bool = False,
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, skip_finished: Optional[bool] = None):
         self.env, self.policy = env, policy
         cfg = env.config
         self.time_max = int(time_max if time_max is not None else getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
         self.discount = float(getattr(cfg, "DISCOUNT", discount))
         self.greedy = greedy                     # PLAY_MODE / EVALUATE_MODE: argmax instead of sampling (:98-103)
+        # fused policy only: no forward pass for absent agents and for agents that have finished and wait for their world to
+        # end (the env ignores their action, nothing of theirs is recorded; ~30 % of the rows in the TrainPhase1 workload).
+        # Never in the faithful re-flush mode, whose quirk rows carry V(s) of exactly those agents.  Default: only when the
+        # batch is several rounds of 64-row tiles over the 256 CUs -- at 4 x 8192 (512 tiles = one round, two per CU) a
+        # shorter tile list does not shorten the launch and the list itself costs 13 us.
+        W_N = env.num_worlds * env.max_agents
+        self.skip_finished = (not reflush_done and W_N > 65536) if skip_finished is None else bool(skip_finished)
         self.generator = generator
         W, N, D = env.num_worlds, env.max_agents, env.obs_width - 1
         self.slots = W * N
@@ -75,6 +82,8 @@ class BatchedRollout(object):
         self.dup_count = torch.zeros((2,), dtype=torch.int32, device=dev)
         self.ep_out = torch.empty((self.episode_capacity, 3), dtype=torch.float32, device=dev)
         self.ep_count = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self.row_index = torch.zeros((self.slots,), dtype=torch.int32, device=dev)
+        self.row_count = torch.zeros((1,), dtype=torch.int32, device=dev)
         self._obs_buffers = [env.obs, torch.zeros_like(env.obs)]
         self._cur = 0
         self.step_index = 0                       # pushes done so far == the next step's index
@@ -110,6 +119,7 @@ class BatchedRollout(object):
         """Start every world's first episode (``env.reset()`` at ProcessAgent.py:107)."""
         self._cur = 0
         self.env.reset()
+        self.env.game_over.fill_(1)                # "every world has just (re)started": see cavoid_rollout_active_rows
         _lib.check(self._lib.cavoid_rollout_reset(self._h, self.env._stream()), "cavoid_rollout_reset")
         self.emit_t.fill_(-1)
         self.dup_count.zero_()
@@ -123,7 +133,14 @@ class BatchedRollout(object):
         W, N = self.env.num_worlds, self.env.max_agents
         if getattr(self.policy, "accepts_strided_obs", False):
             # fused kernel (ga3c/policy_kernel.py): reads the obs tensor in place and selects the action itself
-            actions, _, v = self.policy.act(obs.view(W * N, -1)[:, 1:], greedy=self.greedy)
+            rows = None
+            if self.skip_finished:
+                p = BatchedCollisionAvoidanceEnv._ptr
+                _lib.check(self._lib.cavoid_rollout_active_rows(self._h, p(obs), p(self.env.done), p(self.env.game_over),
+                                                                p(self.row_index), p(self.row_count), self.env._stream()),
+                           "cavoid_rollout_active_rows")
+                rows = (self.row_index, self.row_count)
+            actions, _, v = self.policy.act(obs.view(W * N, -1)[:, 1:], greedy=self.greedy, rows=rows)
             return actions.reshape(W, N), v.reshape(W, N)
         p, v = self.policy(obs[..., 1:].reshape(W * N, -1))
         if self.greedy:

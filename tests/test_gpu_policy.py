@@ -264,3 +264,52 @@ def test_trainers_accept_an_empty_batch():
     for tr in (A3CTrainer(net), FusedA3CTrainer(net)):
         loss = tr.train(x[:0], y[:0], a[:0] if isinstance(tr, FusedA3CTrainer) else torch.nn.functional.one_hot(a[:0], 11).float())
         assert float(loss) == 0.0 and tr.training_step == 1
+
+
+def test_row_list_pass_equals_the_full_pass_on_the_listed_rows():
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(3, seed=51)
+    B = 5000
+    x = _inputs(net, B, seed=6)
+    g = torch.Generator().manual_seed(1)
+    listed = torch.randperm(B, generator=g)[:3210].to(torch.int32).cuda()          # unordered, not a multiple of the tile
+    index = torch.zeros(B, dtype=torch.int32, device="cuda")
+    index[:listed.numel()] = listed
+    count = torch.tensor([listed.numel()], dtype=torch.int32, device="cuda")
+    pol = FusedPolicy(net, seed=77)
+    a_full, p_full, v_full = pol.act(x)
+    pol.seed(77)                                             # same launch counter -> same draws per row
+    a_rows, p_rows, v_rows = pol.act(x, rows=(index, count))
+    sel = listed.long()
+    assert torch.equal(p_rows[sel], p_full[sel]) and torch.equal(v_rows[sel], v_full[sel]) and torch.equal(a_rows[sel], a_full[sel])
+    rest = torch.ones(B, dtype=torch.bool, device="cuda")
+    rest[sel] = False
+    assert float(p_rows[rest].abs().sum()) == 0.0 and float(v_rows[rest].abs().sum()) == 0.0
+    count.zero_()                                            # an empty list is fine (every workgroup leaves at once)
+    a0, p0, v0 = pol.act(x, rows=(index, count))
+    assert float(p0.abs().sum()) == 0.0
+
+
+def test_skipping_finished_agents_does_not_change_the_rollout():
+    """No policy pass for agents that are done and wait for their world to end: same trajectories, same training rows."""
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    net = _net(3, seed=61)
+    out = []
+    for skip in (False, True):
+        env = BatchedCollisionAvoidanceEnv(256, seed=9, gen_min_agents=2)
+        roll = BatchedRollout(env, FusedPolicy(net, seed=3), reflush_done=False, skip_finished=skip, ring_len=200)
+        roll.reset()
+        for _ in range(150):
+            roll.step()
+        b = roll.drain(flush_all=True)
+        key = b.src[:, 0].long() * 100000 + b.src[:, 1].long() * 10000 + b.src[:, 2].long()
+        order = torch.argsort(key)
+        out.append((key[order], b.x[order], b.r[order], b.a_index[order], roll.drain_episodes()))
+        if skip:
+            assert int(roll.row_count.item()) < 256 * 4     # some rows really were skipped in the last step
+        roll.close(); env.close()
+    (k0, x0, r0, a0, e0), (k1, x1, r1, a1, e1) = out
+    assert torch.equal(k0, k1) and torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(a0, a1) and k0.numel() > 20000
+    assert e0.shape == e1.shape and e0.shape[0] > 100
