@@ -302,28 +302,42 @@ struct CompactArgs {
     int64_t capacity;
 };
 
-// One lane per (step block, slot); a wavefront appends its emitted rows with one atomic (ballot + prefix count).
-// Row order inside the batch is unspecified (the A3C loss is a sum over rows).
+// One lane per (step block, slot); a wavefront appends its emitted rows with one atomic (ballot + prefix count) and
+// then copies them together: the destination is one contiguous run of rows, the sources are (mostly adjacent) rows of
+// the wavefront's 64 slots, so both sides of the copy are coalesced.  Row order inside the batch is unspecified (the
+// A3C loss is a sum over rows).
 __global__ void __launch_bounds__(256) rollout_compact_kernel(const RolloutCfg c, const CompactArgs a) {
+    __shared__ int lane_of_rank[4][64];
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int step = a.step_lo + (int)blockIdx.y;
-    const int lane = threadIdx.x & 63, D = c.obs_width - 1;
-    const int64_t row = (int64_t)(step % c.ring_len) * c.num_slots + slot;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, D = c.obs_width - 1;
+    const int64_t block_row0 = (int64_t)(step % c.ring_len) * c.num_slots;
+    const int64_t row = block_row0 + slot;
     int32_t emitted = -1;
     if (slot < c.num_slots) emitted = a.emit_t[row];
     const bool take = emitted >= 0;
     const unsigned long long mask = __ballot(take);
     if (mask == 0ull) return;
     const int count = __popcll(mask), rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)mask) - 1;
     int base = 0;
-    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(a.out_count, count);
-    base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-    if (!take) return;
+    if (lane == leader) base = atomicAdd(a.out_count, count);
+    base = __shfl(base, leader, 64);
+    int fit = (int64_t)base + count <= a.capacity ? count : (int)(a.capacity > base ? a.capacity - base : 0);
+    if (lane == leader && fit < count) atomicAdd(a.out_count + 1, count - fit);
+    if (take) lane_of_rank[wave][rank] = lane;
+    __builtin_amdgcn_wave_barrier();                       // wave-private table: LDS operations of a wavefront are in order
+    const int64_t wave_row0 = row - lane;                  // ring row of this wavefront's lane 0
+    const float inv_d = 1.0f / (float)D;
+    for (int e = lane; e < fit * D; e += 64) {
+        int r = (int)((float)e * inv_d);
+        r -= (r * D > e) ? 1 : 0;
+        r += ((r + 1) * D <= e) ? 1 : 0;
+        const int k = e - r * D;
+        a.out_x[(int64_t)base * D + e] = a.x[(wave_row0 + lane_of_rank[wave][r]) * D + k];
+    }
+    if (!take || rank >= fit) return;
     const int64_t dst = (int64_t)base + rank;
-    if (dst >= a.capacity) { atomicAdd(a.out_count + 1, 1); return; }
-    const float *src = a.x + row * D;
-    float *out = a.out_x + dst * D;
-    for (int k = 0; k < D; ++k) out[k] = src[k];
     a.out_r[dst] = a.ret[row];
     a.out_a[dst] = (int32_t)a.act[row];
     if (a.out_src) {
