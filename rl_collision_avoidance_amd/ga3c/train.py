@@ -68,6 +68,8 @@ def main(argv=None) -> None:
     ap.add_argument("--checkpoint-dir", default=None, help="save network_%%08d.pt here (SAVE_MODELS)")
     ap.add_argument("--save-every", type=int, default=50000, help="SAVE_FREQUENCY, in episodes")
     ap.add_argument("--load", default=None, help="checkpoint file to start from (LOAD_CHECKPOINT)")
+    ap.add_argument("--pretrain-steps", type=int, default=0,
+                    help="supervised initialisation before RL (the role of Regression.py): Adam steps on teacher-driven rollouts")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--print-every", type=int, default=2000, help="stats line every n episodes (rank 0)")
     ap.add_argument("--faithful-reflush", action="store_true", help="keep the reference's post-done re-flush quirk")
@@ -101,6 +103,14 @@ def main(argv=None) -> None:
     episodes_before = 0
     if args.load:
         episodes_before = load_checkpoint(args.load, net, trainer, device)
+    if args.pretrain_steps > 0 and not args.load:
+        from .regression import pretrain
+        info = pretrain(net, env, steps=args.pretrain_steps, log_every=50 if rank == 0 and args.print_every else 0)
+        if size > 1:                                           # every replica starts RL from rank 0's regression result
+            for prm in net.parameters():
+                dist.broadcast(prm.data, src=0)
+        if rank == 0:
+            print("[Regression] done: %s" % info, flush=True)
     steps_before = trainer.training_step
     if fused is not None:
         fused.refresh(with_backward=isinstance(trainer, FusedA3CTrainer))      # weights may have come from a checkpoint

@@ -313,3 +313,21 @@ def test_skipping_finished_agents_does_not_change_the_rollout():
     (k0, x0, r0, a0, e0), (k1, x1, r1, a1, e1) = out
     assert torch.equal(k0, k1) and torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(a0, a1) and k0.numel() > 20000
     assert e0.shape == e1.shape and e0.shape[0] > 100
+
+
+def test_regression_pretraining_clones_the_teacher():
+    """Supervised initialisation (the role of Regression.py): after a few hundred rows per step the network picks the
+    teacher's action on fresh observations."""
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.ga3c.regression import pretrain, teacher_actions
+    env = BatchedCollisionAvoidanceEnv(512, seed=4)
+    net = _net(3, seed=71)
+    info = pretrain(net, env, steps=60, learning_rate=2e-3, rows_per_step=8192)
+    assert info["steps"] == 60 and info["p_loss_per_row"] < 0.2
+    obs = env.reset()
+    table = torch.as_tensor(__import__("rl_collision_avoidance_amd.actions", fromlist=["Actions"]).Actions().actions,
+                            dtype=torch.float32, device="cuda")
+    with torch.no_grad():
+        _, p, _ = net.forward(obs.view(512 * 4, -1)[:, 1:].contiguous())
+    agree = (p.argmax(dim=1).view(512, 4) == teacher_actions(obs, table).long()).float().mean().item()
+    assert agree > 0.9
