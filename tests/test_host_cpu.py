@@ -152,3 +152,20 @@ def test_reference_code_runs_on_our_seam():
             assert x_.ndim == 2 and x_.shape[1] == 26 and a_.shape == (len(r_), 11) and a_.dtype == np.float32
             rows += len(r_)
     assert rows > 0
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/cavoid.h is the drop-in boundary: it must compile as C99 (no C++, no torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "cavoid.h"\nint main(void) { cavoid_cfg c; cavoid_policy_weights w; cavoid_policy_train_buffers b;\n'
+                   '  (void)c; (void)w; (void)b; return (int)sizeof(cavoid_cfg) == 712 ? 0 : 1; }\n')
+    exe = tmp_path / "hdr"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
