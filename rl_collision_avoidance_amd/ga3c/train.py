@@ -68,6 +68,9 @@ def main(argv=None) -> None:
     ap.add_argument("--checkpoint-dir", default=None, help="save network_%%08d.pt here (SAVE_MODELS)")
     ap.add_argument("--save-every", type=int, default=50000, help="SAVE_FREQUENCY, in episodes")
     ap.add_argument("--load", default=None, help="checkpoint file to start from (LOAD_CHECKPOINT)")
+    ap.add_argument("--evaluate", type=int, default=0, metavar="ROUNDS",
+                    help="EVALUATE_MODE instead of training: ROUNDS x --worlds episodes with argmax actions, every agent must "
+                         "finish; prints success / collision / timeout rates (use with --load)")
     ap.add_argument("--pretrain-steps", type=int, default=0,
                     help="supervised initialisation before RL (the role of Regression.py): Adam steps on teacher-driven rollouts")
     ap.add_argument("--seed", type=int, default=0)
@@ -93,7 +96,7 @@ def main(argv=None) -> None:
     cfg = Cfg()
     offset, count = shard_range(args.worlds, rank, size)
     env = BatchedCollisionAvoidanceEnv(count, cfg, device=device, world_offset=offset, seed=1000 * args.seed,
-                                       gen_min_agents=min(args.min_agents, N))
+                                       gen_min_agents=min(args.min_agents, N), evaluate_mode=1 if args.evaluate else 0)
     net = NetworkVP_rnn(cfg, seed=args.seed).to(device)
     fused = None if (args.torch_policy or net.arch != "rnn") else FusedPolicy(net, seed=1000 * args.seed + rank)
     if args.autograd_trainer or net.arch != "rnn":
@@ -103,6 +106,18 @@ def main(argv=None) -> None:
     episodes_before = 0
     if args.load:
         episodes_before = load_checkpoint(args.load, net, trainer, device)
+    if args.evaluate:
+        from .evaluate import evaluate
+        if fused is not None:
+            fused.refresh()
+        res = evaluate(env, fused if fused is not None else net.predict_p_and_v, rounds=args.evaluate)
+        if rank == 0:
+            print("[Evaluate] " + "  ".join("%s %.4f" % (k, v) if isinstance(v, float) else "%s %d" % (k, v) for k, v in res.items()),
+                  flush=True)
+        env.close()
+        if size > 1:
+            dist.destroy_process_group()
+        return
     if args.pretrain_steps > 0 and not args.load:
         from .regression import pretrain
         info = pretrain(net, env, steps=args.pretrain_steps, log_every=50 if rank == 0 and args.print_every else 0)
