@@ -68,6 +68,10 @@ def main(argv=None) -> None:
     ap.add_argument("--checkpoint-dir", default=None, help="save network_%%08d.pt here (SAVE_MODELS)")
     ap.add_argument("--save-every", type=int, default=50000, help="SAVE_FREQUENCY, in episodes")
     ap.add_argument("--load", default=None, help="checkpoint file to start from (LOAD_CHECKPOINT)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend under torchrun (nccl = RCCL over xGMI; gloo only for dry runs)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="dry run of the multi-rank logic on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--evaluate", type=int, default=0, metavar="ROUNDS",
                     help="EVALUATE_MODE instead of training: ROUNDS x --worlds episodes with argmax actions, every agent must "
                          "finish; prints success / collision / timeout rates (use with --load)")
@@ -81,11 +85,16 @@ def main(argv=None) -> None:
     rank = int(os.environ.get("RANK", "0"))
     size = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     N = args.agents
 
