@@ -97,7 +97,7 @@ def python_baseline(N: int, budget_s: float):
             "sample": "oracle/cavoid_oracle.py, 1 world x %d agents, %d steps" % (N, steps)}
 
 
-def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int = 240, train_rows: int = 32768):
+def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int = 240, train_rows: int = 32768, brief: bool = False):
     """BASELINE configs[4]: everything on the device -- policy inference + action selection (fused f32-MFMA kernel,
     cavoid_policy_*), env.step, experience store / n-step returns (HIP), and Adam steps (PyTorch-ROCm autograd) on
     EVERY drained row, in minibatches of `train_rows` (policy replica per GPU, no collective).  Reports the
@@ -180,12 +180,15 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         return {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us, "issued_TFLOPs": flop / fused_us * 1e-6,
                 "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3, "bound": "mfma", "dtype": "f32",
                 "kernel": "cavoid::policy_forward_kernel"}
-    res = {"policy_kernel": policy_kernel(), "actors_only_fused_policy": regime(True, False), "full_loop_fused_policy_fused_trainer": regime(True, True, True),
-           "full_loop_fused_policy_autograd_trainer": regime(True, True),
-           "full_loop_torch_policy_autograd_trainer": regime(False, True),
+    res = {"policy_kernel": policy_kernel(), "actors_only_fused_policy": regime(True, False),
+           "full_loop_fused_policy_fused_trainer": regime(True, True, True)}
+    if not brief:                                            # the PyTorch comparison legs take most of the time
+        res["full_loop_fused_policy_autograd_trainer"] = regime(True, True)
+        res["full_loop_torch_policy_autograd_trainer"] = regime(False, True)
+    res.update({
            "steps_per_graph": per_graph, "train_rows_per_adam_step": train_rows, "policy_dtype": "f32",
            "note": "one hipGraph per %d env steps (policy + action selection + env + experience store); every drained row "
-                   "is trained on once; reference PPS datum: 563 (32 procs, laptop CPU)" % per_graph}
+                   "is trained on once; reference PPS datum: 563 (32 procs, laptop CPU)" % per_graph})
     return res
 
 
@@ -207,6 +210,7 @@ def main() -> None:
                     help="also time BASELINE configs[4]: batched env + NetworkVP_rnn policy + rollout bookkeeping + Adam steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-loop", action="store_true", help="skip the brief configs[4] extra of the default N = 1 run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 code path)")
     ap.add_argument("--share-device", action="store_true",
@@ -355,8 +359,14 @@ def main() -> None:
         except Exception as exc:      # noqa: BLE001
             extra["no_scenario_pool"] = {"error": repr(exc)}
 
-    if args.full_loop:
-        extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, Cfg(), device, W, N, rank, world_size, sync_all)
+    if args.full_loop or (world_size == 1 and not args.no_full_loop):
+        # configs[4] beside the headline: always at N = 1 (a brief version: actors only + the fused-trainer loop, ~15 s),
+        # the PyTorch comparison legs only with --full-loop
+        try:
+            extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, Cfg(), device, W, N, rank, world_size, sync_all,
+                                                brief=not args.full_loop, steps=240 if args.full_loop else 120)
+        except Exception as exc:      # noqa: BLE001  (an extra must never cost the contract line)
+            extra["full_ga3c_loop"] = {"error": repr(exc)}
 
     if args.sweep and rank == 0:
         sweep = []
