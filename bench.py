@@ -114,7 +114,9 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
         net = NetworkVP_rnn(cfg).to(device)
         pol = FusedPolicy(net, seed=rank) if fused else None
-        trainer = FusedA3CTrainer(net, pol) if fused_trainer else A3CTrainer(net)
+        # a policy replica per GPU and NO collective in this extra: ranks drain different row counts, so the number of
+        # optimiser steps differs between them
+        trainer = FusedA3CTrainer(net, pol, distributed=False) if fused_trainer else A3CTrainer(net, distributed=False)
         roll = BatchedRollout(env, pol if fused else net.predict_p_and_v, reflush_done=False)
         roll.reset()
         roll.capture(steps_per_graph=per_graph)              # policy + sampling + env.step + bookkeeping as ONE graph
@@ -359,9 +361,10 @@ def main() -> None:
         except Exception as exc:      # noqa: BLE001
             extra["no_scenario_pool"] = {"error": repr(exc)}
 
-    if args.full_loop or (world_size == 1 and not args.no_full_loop):
-        # configs[4] beside the headline: always at N = 1 (a brief version: actors only + the fused-trainer loop, ~15 s),
-        # the PyTorch comparison legs only with --full-loop
+    if args.full_loop or not args.no_full_loop:
+        # configs[4] beside the headline (a brief version: actors only + the fused-trainer loop, ~15 s; the PyTorch comparison
+        # legs only with --full-loop).  At N > 1 every rank runs it on its own shard and policy replica, concurrently and
+        # without any collective; rank 0 reports its own per-GPU figures.
         try:
             extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, Cfg(), device, W, N, rank, world_size, sync_all,
                                                 brief=not args.full_loop, steps=240 if args.full_loop else 120)
