@@ -231,6 +231,32 @@ class NetworkVP_rnn(nn.Module):
         return cost_p + cost_v, cost_p, cost_v
 
 
+def export_tf_variables(net: "NetworkVP_rnn") -> dict:
+    """{TensorFlow variable name: float32 ndarray} in the reference checkpoint's names and layouts (what
+    ``tf.train.load_checkpoint(path).get_tensor(name)`` returns there): dense kernels [in, out], LSTM kernel [7+64, 256]."""
+    return {TF_VARIABLE_NAMES[n]: p.detach().cpu().numpy().astype(np.float32).copy() for n, p in net.named_parameters()}
+
+
+def load_tf_variables(net: "NetworkVP_rnn", variables: dict, strict: bool = True) -> list:
+    """Assign the arrays of a reference checkpoint (dumped as {variable name: array}, e.g. an .npz written from
+    ``tf.train.load_checkpoint``) to the module.  Returns the names it did not find (raises if ``strict``)."""
+    missing = []
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            tf_name = TF_VARIABLE_NAMES[n]
+            key = tf_name if tf_name in variables else tf_name.split(":")[0]
+            if key not in variables:
+                missing.append(tf_name)
+                continue
+            arr = torch.as_tensor(np.asarray(variables[key]), dtype=p.dtype)
+            if tuple(arr.shape) != tuple(p.shape):
+                raise ValueError("%s: checkpoint shape %s, module shape %s" % (tf_name, tuple(arr.shape), tuple(p.shape)))
+            p.copy_(arr.to(p.device))
+    if missing and strict:
+        raise KeyError("variables missing from the checkpoint: %s" % ", ".join(missing))
+    return missing
+
+
 def input_normalisation(config):
     """NN_INPUT_AVG_VECTOR / NN_INPUT_STD_VECTOR exactly as Config.py:64-71 builds them."""
     avg, std = [], []

@@ -38,6 +38,11 @@ def save_checkpoint(directory: str, episode: int, net: NetworkVP_rnn, trainer: A
 
 def load_checkpoint(path: str, net: NetworkVP_rnn, trainer: A3CTrainer, device) -> int:
     """``NetworkVPCore.load`` (:238-262): returns the episode number the run resumes from."""
+    if path.endswith(".npz"):                                  # {TF variable name: array}, see network.load_tf_variables
+        import numpy as np
+        from .network import load_tf_variables
+        load_tf_variables(net, dict(np.load(path)))
+        return 0
     ck = torch.load(path, map_location=device)
     net.load_state_dict(ck["model"])
     if "optimizer" in ck:
@@ -67,7 +72,8 @@ def main(argv=None) -> None:
     ap.add_argument("--play", action="store_true", help="PLAY_MODE: argmax actions, trainers disabled (Server.py:134-137)")
     ap.add_argument("--checkpoint-dir", default=None, help="save network_%%08d.pt here (SAVE_MODELS)")
     ap.add_argument("--save-every", type=int, default=50000, help="SAVE_FREQUENCY, in episodes")
-    ap.add_argument("--load", default=None, help="checkpoint file to start from (LOAD_CHECKPOINT)")
+    ap.add_argument("--load", default=None, help="checkpoint file to start from (LOAD_CHECKPOINT): a network_%%08d.pt written "
+                                                 "by this CLI, or an .npz of the reference's TensorFlow variables by name")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend under torchrun (nccl = RCCL over xGMI; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true",

@@ -2,6 +2,7 @@
 against a plain per-row fp32 reference, the A3C loss against a NumPy statement of NetworkVPCore's
 formulas, and one optimiser step."""
 import numpy as np
+import pytest
 import torch
 
 from rl_collision_avoidance_amd.config import EnvConfig
@@ -143,3 +144,25 @@ def test_regression_teacher_and_action_index():
         logits, _, v = net(x)
     ce = -(torch.log_softmax(logits, 1)[torch.arange(32), a]).sum()
     assert abs(float(cost_p) - float(ce)) < 1e-4 and abs(float(cost_v) - 0.5 * float((v ** 2).sum())) < 1e-4
+
+
+def test_tf_variable_round_trip(tmp_path):
+    """Checkpoint interchange by TensorFlow variable name: export -> npz -> load into a fresh module -> same outputs."""
+    from rl_collision_avoidance_amd.ga3c.network import export_tf_variables, load_tf_variables
+    cfg = _cfg(4)
+    a, b = NetworkVP_rnn(cfg, seed=1), NetworkVP_rnn(cfg, seed=2)
+    variables = export_tf_variables(a)
+    assert "rnn/lstm_cell/kernel:0" in variables and variables["rnn/lstm_cell/kernel:0"].shape == (7 + 64, 256)
+    path = tmp_path / "vars.npz"
+    np.savez(path, **{k.replace("/", "__").replace(":", "--"): v for k, v in variables.items()})
+    loaded = {k.replace("__", "/").replace("--", ":"): v for k, v in np.load(path).items()}
+    assert load_tf_variables(b, loaded) == []
+    x = _batch(16, 3, seed=4)
+    with torch.no_grad():
+        assert torch.equal(a(x)[1], b(x)[1])
+    del loaded["logits_v/bias:0"]
+    with pytest.raises(KeyError):
+        load_tf_variables(b, loaded)
+    loaded["layer1/kernel:0"] = loaded["layer1/kernel:0"][:10]
+    with pytest.raises((ValueError, KeyError)):
+        load_tf_variables(b, loaded, strict=False)
