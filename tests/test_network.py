@@ -166,3 +166,12 @@ def test_tf_variable_round_trip(tmp_path):
     loaded["layer1/kernel:0"] = loaded["layer1/kernel:0"][:10]
     with pytest.raises((ValueError, KeyError)):
         load_tf_variables(b, loaded, strict=False)
+
+
+def test_split_k_factor():
+    from rl_collision_avoidance_amd.ga3c.network import split_k_factor
+    assert split_k_factor(32768) == 16 and split_k_factor(98304) == 48 and split_k_factor(2048) == 1
+    assert split_k_factor(26944) == 1                        # 64 * 421, 421 prime: nothing useful divides it
+    for rows in (4096, 6144, 65536, 100352):
+        s = split_k_factor(rows)
+        assert rows % s == 0 and (s == 1 or rows // s >= 2048)
