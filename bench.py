@@ -4,12 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path (cavoid_step_autoreset: decode, dynamics, pairwise sensing,
-rewards, done flags, sorted observation, in-kernel restart of finished worlds) over one batch of
-synthetic worlds: BASELINE configs[1], 4 agents x 8192 worlds per GPU, unicycle dynamics, random
-actions pre-generated on the device.  Weak scaling: every rank steps its own 8192 worlds (RNG
-keyed on global world ids); no data-path collective in the headline region (for N>1 the obs
-all-gather of configs[2] is timed afterwards and reported under "extra").  Rank 0 prints ONE JSON line.
+A "step" = one pass of the hot path (decode, dynamics, pairwise sensing, rewards, done flags, sorted
+observation, in-kernel restart of finished worlds) over one batch of synthetic worlds: BASELINE
+configs[1], 4 agents x 8192 worlds per GPU, unicycle dynamics, random actions pre-generated on the
+device.  The K timed steps go through `cavoid_step_autoreset_n`: launches of up to --slices steps, the
+world state staying in registers between the steps of a launch; EVERY step reads its action slice and
+writes its observations, rewards, done flags and game_over.  Weak scaling: every rank steps its own
+8192 worlds (RNG keyed on global world ids); no data-path collective in the headline region (for N>1
+the packed (obs|reward|done) all-gather of configs[2] -- `cavoid_gather_*`, RCCL -- is timed afterwards
+and reported under "extra").  `python bench.py --gpus N` without a launcher starts its own N ranks
+(torch.distributed.run, 127.0.0.1).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -194,6 +198,92 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     return res
 
 
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this script through
+    torch.distributed.run on 127.0.0.1 and pass their output through (rank 0 prints the JSON line)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def pmc_child(args) -> None:
+    """Child of `measure_traffic` (runs under `rocprofv3 --pmc ...`): the bench's launch pattern, nothing else."""
+    import torch
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+    N, W = args.agents, args.worlds
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+    env = BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=7)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    acts = torch.randint(0, env.num_actions, (args.slices, W, N), generator=g, device="cuda", dtype=torch.int32)
+    env.reset()
+    done = 0
+    while done < args.warmup + args.steps:
+        n = min(args.slices, args.warmup + args.steps - done)
+        env.step_autoreset_n(acts, n)
+        done += n
+    torch.cuda.synchronize()
+    env.close()
+
+
+def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 150.0):
+    """HBM bytes per launch of the step kernel from the PMC counters, collected live: one `rocprofv3 --pmc` pass per
+    counter (FETCH_SIZE and WRITE_SIZE do not fit one pass; only --kernel-trace beside --pmc) around a child that
+    repeats this bench's launch pattern.  Counters are KiB; gfx950 tallies 128-B read requests as 64 B, so FETCH_SIZE
+    is doubled (MI355X_MICROARCH.md, HBM section).  Returns None when rocprofv3 is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cavoid_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child", "--agents", str(N), "--worlds", str(W), "--slices", str(slices),
+               "--steps", str(steps), "--warmup", str(slices)]
+        try:
+            subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            total, n = 0.0, 0
+            for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        name = row["Kernel_Name"]
+                        if "env_kernel<%d, " % N in name and ("%d, 1>" % N in name or "%d, 4>" % N in name) \
+                                and row["Counter_Name"] == ctr:
+                            total += float(row["Counter_Value"])
+                            n += 1
+            if n == 0:
+                return None
+            res[ctr] = (total / n, n)
+        except Exception:      # noqa: BLE001 -- measurement aid only
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_kib, nf = res["FETCH_SIZE"]
+    write_kib, nw = res["WRITE_SIZE"]
+    return {"traffic": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+            "dispatches": min(nf, nw), "steps_per_launch": min(slices, steps),
+            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace around `bench.py --pmc-child`; "
+                      "mean per step-kernel dispatch; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B)"}
+
+
 def main() -> None:
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":        # child of cpu_baseline_all_cores: no torch, no GPU
         print(cpu_baseline(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]))["value"])
@@ -204,7 +294,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--worlds", type=int, default=8192, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=4)
-    ap.add_argument("--slices", type=int, default=64, help="distinct pre-generated action slices")
+    ap.add_argument("--slices", type=int, default=64, help="distinct pre-generated action slices = max steps per launch")
     ap.add_argument("--no-gather", action="store_true",
                     help="N>1: skip the extra measurement of the per-step RCCL all-gather of (obs,reward,done) (configs[2])")
     ap.add_argument("--sweep", action="store_true", help="add a worlds-per-GPU saturation sweep to the JSON line")
@@ -213,24 +303,47 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the brief configs[4] extra of the default N = 1 run")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the brief configs[3] (10 agents x 8192 worlds) extra")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live with rocprofv3 --pmc")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 code path)")
     ap.add_argument("--share-device", action="store_true",
                     help="dry run: every rank uses cuda:0 (exercises the multi-rank logic on a 1-GPU box; needs --backend gloo)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch / rendezvous / collective check of the N>1 path without touching a GPU (CPU boxes, gloo)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
-    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
-    from rl_collision_avoidance_amd.config import EnvConfig
 
     rank = int(os.environ.get("RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world_size))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
+    if args.rendezvous_only:
+        # what every N>1 run does around the timed region, with no GPU in it: rendezvous, barrier, MAX over ranks
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world_size > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([1.0 + rank], dtype=torch.float64)
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert float(t.item()) == float(world_size)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "n_gpus": world_size, "backend": "gloo"}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -244,10 +357,12 @@ def main() -> None:
 
     N, W = args.agents, args.worlds
 
-    class Cfg(EnvConfig):
-        def __init__(self):
-            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
-            EnvConfig.__init__(self)
+    def cfg_for(n_agents):
+        class Cfg(EnvConfig):
+            def __init__(self):
+                self.MAX_NUM_AGENTS_IN_ENVIRONMENT = n_agents
+                EnvConfig.__init__(self)
+        return Cfg()
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -255,15 +370,16 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    def make(Wl):
-        env = BatchedCollisionAvoidanceEnv(Wl, Cfg(), device=device, world_offset=rank * Wl, seed=1000 * 0 + 7)
+    def make(Wl, n_agents=N, **over):
+        env = BatchedCollisionAvoidanceEnv(Wl, cfg_for(n_agents), device=device, world_offset=rank * Wl, seed=1000 * 0 + 7, **over)
         g = torch.Generator(device=device)
         g.manual_seed(1234 + rank)
-        acts = torch.randint(0, env.num_actions, (args.slices, Wl, N), generator=g, device=device, dtype=torch.int32)
+        acts = torch.randint(0, env.num_actions, (args.slices, Wl, n_agents), generator=g, device=device, dtype=torch.int32)
         env.reset()
         return env, acts
 
     def run_steps(env, acts, k):
+        """k auto-reset steps in launches of up to T = --slices steps (step t of a launch reads acts[t])."""
         T = acts.shape[0]
         done = 0
         while done < k:
@@ -271,15 +387,25 @@ def main() -> None:
             env.step_autoreset_n(acts, n)
             done += n
 
+    def kernel_figures(env, acts, n_agents, Wl, k):
+        """per-launch HIP-event durations of the step kernel, in launches shaped like the timed region's"""
+        spl = min(acts.shape[0], k)
+        launch_ms = env.kernel_time_ms(acts, max(k, spl), spl)
+        bytes_per_launch = algorithmic_bytes_per_agent_step(n_agents - 1) * Wl * n_agents * spl
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "cavoid::env_kernel<%d, MODE_STEP_AUTORESET%s>" % (n_agents, "_PF" if spl > 1 and Wl * n_agents <= 131072 else ""),
+                "steps_per_launch": spl, "kernel_us": launch_ms * 1e3, "kernel_us_per_step": launch_ms * 1e3 / spl,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(n_agents - 1)}
+
     env, acts = make(W)
     run_steps(env, acts, args.warmup)
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks -------
     sync_all()
     t0 = time.perf_counter()
-    env.timer_begin()
     run_steps(env, acts, args.steps)
-    stream_ms = env.timer_end()          # HIP events on the launch stream (includes launch gaps)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
@@ -289,74 +415,108 @@ def main() -> None:
     ms_per_step = elapsed * 1e3 / args.steps
     value = world_size * W * N * args.steps / elapsed
 
-    # ---- roofline of the dominant (only) kernel: per-launch HIP-event durations ---------------------
-    kern_ms = env.kernel_time_ms(acts, args.steps)
-    bytes_per_launch = algorithmic_bytes_per_agent_step(N - 1) * W * N
-    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "cavoid::env_kernel<%d, MODE_STEP_AUTORESET>" % N,
-                "kernel_us": kern_ms * 1e3, "stream_us_per_step": stream_ms * 1e3 / args.steps,
-                "algorithmic_bytes_per_launch": bytes_per_launch}
-
-    # `traffic`: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) -- those
-    # cannot be collected from inside this process, so the committed summary of the PMC run of THIS command
-    # is quoted when it is for the same kernel and shape (profiles/*_pmc_traffic.json), else null.
-    try:
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-            pmc = json.load(open(path))
-            if pmc.get("worlds") == W and pmc.get("agents") == N:
-                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = os.path.relpath(path, ROOT)
-                break
-    except Exception:
-        pass
+    # ---- roofline of the dominant (only) kernel ------------------------------------------------------
+    roofline = kernel_figures(env, acts, N, W, args.steps)
+    single = env.kernel_time_ms(acts, min(args.steps, 256), 1)          # the closed-loop form: one step per launch
+    roofline["single_step_launch_us"] = single * 1e3
+    roofline["single_step_launch_frac"] = algorithmic_bytes_per_agent_step(N - 1) * W * N / (single * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     extra = {}
-    if world_size > 1 and args.backend == "nccl" and not args.no_gather:
-        # BASELINE configs[2]: the one real exchange of the path -- (obs | reward | done) of every world back to
-        # every rank in ONE packed RCCL all-gather per step.  Timed OUTSIDE the headline region (the headline is
-        # the sharded step with no data-path collective); a failure here must not cost the headline number.
+    if world_size > 1 and not args.no_gather:
+        # BASELINE configs[2]: the one real exchange of the path -- the packed (obs | reward | done) record of every world
+        # back to every rank, ONE all-gather per step.  nccl: the kernel writes the packed record and cavoid_gather_* issues
+        # ncclAllGather on the communicator's own stream, gather(t) overlapping step(t+1).  gloo dry run: torch.distributed.
+        # Timed OUTSIDE the headline region; a failure here must not cost the headline number.
         try:
-            from rl_collision_avoidance_amd.sharding import pack_step_outputs
-            width = env.obs_width
-            packed = torch.empty((W, N, width + 2), dtype=torch.float32, device=device)
-            out = torch.empty((world_size * W, N, width + 2), dtype=torch.float32, device=device)
+            from rl_collision_avoidance_amd.sharding import ShardedEnv
+            sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7)
+            sh.reset()
+            native = args.backend == "nccl"
 
-            def gather_once(step_too):
-                if step_too:
-                    env.step_autoreset(acts[0])
-                pack_step_outputs(env.obs, env.rewards, env.done, packed)
-                dist.all_gather_into_tensor(out, packed)
-            for _ in range(20):
-                gather_once(True)
+            def one(t):
+                if native:
+                    sh.gathered(sh.step_and_gather(acts[t % acts.shape[0]]))
+                else:
+                    sh.step_autoreset(acts[t % acts.shape[0]])
+                    sh.gather()
+            n_g = 200 if native else 10
+            for t in range(20 if native else 2):
+                one(t)
             sync_all()
             tg = time.perf_counter()
-            for _ in range(200):
-                gather_once(False)
+            for t in range(n_g):
+                one(t)
             sync_all()
-            t_gather = (time.perf_counter() - tg) / 200
+            t_both = (time.perf_counter() - tg) / n_g
             tg = time.perf_counter()
-            for _ in range(200):
-                gather_once(True)
+            for t in range(n_g):
+                sh.step_autoreset_packed(acts[t % acts.shape[0]], sh._send[0]) if native else sh.step_autoreset(acts[t % acts.shape[0]])
             sync_all()
-            t_both = (time.perf_counter() - tg) / 200
-            extra["allgather"] = {"ms_per_step_pack_and_gather": t_gather * 1e3, "ms_per_step_with_env_step": t_both * 1e3,
-                                  "bytes_per_rank": packed.numel() * 4, "bytes_received_per_rank": out.numel() * 4,
+            t_step = (time.perf_counter() - tg) / n_g
+            extra["allgather"] = {"path": "cavoid_gather_* (ncclAllGather, own stream, double-buffered)" if native else "torch.distributed (gloo dry run)",
+                                  "ms_per_step_with_gather": t_both * 1e3, "ms_per_single_step_launch_alone": t_step * 1e3,
+                                  "pack_cost_ms": 0.0 if native else None,
+                                  "bytes_per_rank": W * N * (env.obs_width + 2) * 4,
+                                  "bytes_received_per_rank": world_size * W * N * (env.obs_width + 2) * 4,
                                   "agent_steps_per_s_with_gather": world_size * W * N / t_both}
+            sh.close()
         except Exception as exc:      # noqa: BLE001 -- report, never lose the headline
             extra["allgather"] = {"error": repr(exc)}
+
+    if rank == 0 and world_size == 1 and not args.no_pmc:
+        try:
+            pmc = measure_traffic(N, W, args.slices, max(args.slices * 4, 256))
+            if pmc is not None:
+                # the PMC child's launches are `slices` steps long; scale to this run's launch length
+                per_step = pmc["traffic"] / pmc["steps_per_launch"]
+                roofline["traffic"] = per_step * roofline["steps_per_launch"]
+                roofline["traffic_source"] = pmc
+        except Exception:      # noqa: BLE001
+            pass
+    if roofline["traffic"] is None:
+        # fall back to the committed summary of a PMC run of this command (same kernel and shape), naming it
+        try:
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_traffic.json")), reverse=True):
+                pmc = json.load(open(path))
+                if pmc.get("worlds") == W and pmc.get("agents") == N and "traffic_bytes_per_step" in pmc:
+                    roofline["traffic"] = pmc["traffic_bytes_per_step"] * roofline["steps_per_launch"]
+                    roofline["traffic_source"] = os.path.relpath(path, ROOT)
+                    break
+        except Exception:      # noqa: BLE001
+            pass
+
+    if rank == 0 and not args.no_configs3 and N != 10:
+        # BASELINE configs[3] beside the headline: 10 agents (TrainPhase2 shape, 2..10 agents per world, M = 9) x 8192 worlds
+        try:
+            e3, a3 = make(8192, 10, gen_min_agents=2)
+            run_steps(e3, a3, 64)
+            torch.cuda.synchronize(device)
+            t3 = time.perf_counter()
+            run_steps(e3, a3, 640)
+            torch.cuda.synchronize(device)
+            dt3 = time.perf_counter() - t3
+            r3 = kernel_figures(e3, a3, 10, 8192, 640)
+            s3 = e3.kernel_time_ms(a3, 128, 1)
+            c3 = {"workload": "BASELINE configs[3]: 10 agents (2..10 present) x 8192 worlds, M = 9, obs width 69",
+                  "value": 8192 * 10 * 640 / dt3, "unit": "agent-steps/s", "ms_per_step": dt3 * 1e3 / 640, "roofline": r3,
+                  "single_step_launch_us": s3 * 1e3,
+                  "single_step_launch_frac": 360 * 81920 / (s3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if not args.no_cpu_baseline:
+                c3["cpu_baseline"] = cpu_baseline(10, 2048, min(3.0, args.cpu_seconds), int(e3.cfg.gen_pool_size))
+            extra["configs3_n10"] = c3
+            e3.close()
+            del e3, a3
+        except Exception as exc:      # noqa: BLE001
+            extra["configs3_n10"] = {"error": repr(exc)}
 
     if rank == 0 and args.sweep:
         # transparency: the same step with NO scenario pool (every restart runs GEN v1 in-kernel, exact (world,
         # episode) scenarios) -- the pool only moves scenario generation (E2) off the step's critical path
         try:
-            e0 = BatchedCollisionAvoidanceEnv(W, Cfg(), device=device, world_offset=rank * W, seed=7, gen_pool_size=0)
-            e0.reset()
-            run_steps(e0, acts, 100)
-            k0 = e0.kernel_time_ms(acts, 300)
-            extra["no_scenario_pool"] = {"kernel_us": k0 * 1e3, "agent_steps_per_s": W * N / (k0 * 1e-3)}
+            e0, a0 = make(W, N, gen_pool_size=0)
+            run_steps(e0, a0, 128)
+            extra["no_scenario_pool"] = kernel_figures(e0, a0, N, W, 256)
             e0.close()
         except Exception as exc:      # noqa: BLE001
             extra["no_scenario_pool"] = {"error": repr(exc)}
@@ -366,7 +526,7 @@ def main() -> None:
         # legs only with --full-loop).  At N > 1 every rank runs it on its own shard and policy replica, concurrently and
         # without any collective; rank 0 reports its own per-GPU figures.
         try:
-            extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, Cfg(), device, W, N, rank, world_size, sync_all,
+            extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, cfg_for(N), device, W, N, rank, world_size, sync_all,
                                                 brief=not args.full_loop, steps=240 if args.full_loop else 120)
         except Exception as exc:      # noqa: BLE001  (an extra must never cost the contract line)
             extra["full_ga3c_loop"] = {"error": repr(exc)}
@@ -375,24 +535,29 @@ def main() -> None:
         sweep = []
         for Ws in (1024, 8192, 65536, 262144, 1048576, 4194304):
             e2, a2 = make(Ws)
-            run_steps(e2, a2, 50)
-            k_ms = e2.kernel_time_ms(a2, 200)
+            run_steps(e2, a2, 64)
+            f = kernel_figures(e2, a2, N, Ws, 128)
+            k1 = e2.kernel_time_ms(a2, 64, 1)
             torch.cuda.synchronize(device)
-            gbs = algorithmic_bytes_per_agent_step(N - 1) * Ws * N / (k_ms * 1e-3) / 1e9
-            sweep.append({"worlds": Ws, "kernel_us": k_ms * 1e3, "agent_steps_per_s": Ws * N / (k_ms * 1e-3),
-                          "GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+            sweep.append({"worlds": Ws, "kernel_us_per_step": f["kernel_us_per_step"], "steps_per_launch": f["steps_per_launch"],
+                          "agent_steps_per_s": Ws * N / (f["kernel_us_per_step"] * 1e-6), "GBps": f["achieved"], "frac": f["frac"],
+                          "single_step_launch_us": k1 * 1e3,
+                          "single_step_launch_frac": algorithmic_bytes_per_agent_step(N - 1) * Ws * N / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS})
             e2.close()
             del e2, a2
         extra["saturation_sweep"] = sweep
 
+    which = {4: "configs[1]", 10: "configs[3]"}.get(N, "configs[1]-style")
     line = {
         "metric": "agent-steps/sec (env.step) at %d agents x %d worlds per GPU" % (N, W),
         "value": value, "unit": "agent-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %d agents x %d worlds per GPU, unicycle dynamics, "
-                               "GEN v1 synthetic scenarios, uniform random actions, in-kernel auto-reset" % (N, W),
-                   "worlds_per_gpu": W, "agents_per_world": N, "obs_width": env.obs_width,
+        "config": {"workload": "BASELINE %s: %d agents x %d worlds per GPU, unicycle dynamics, GEN v1 synthetic scenarios, "
+                               "uniform random actions pre-staged on the device, in-kernel auto-reset; launches of up to %d steps "
+                               "(world state in registers between the steps of a launch, every step's outputs written)"
+                               % (which, N, W, args.slices),
+                   "worlds_per_gpu": W, "agents_per_world": N, "obs_width": env.obs_width, "steps_per_launch": min(args.slices, args.steps),
                    "parallelism": "worlds sharded over %d GPU(s), no data-path collective" % world_size},
         "roofline": roofline,
     }

@@ -9,6 +9,10 @@
  *   cavoid_step ...................... `self.game.step(action)` -> 4-tuple        ga3c/GA3C/Environment.py:112
  *                                      (obs, rewards, game_over, which_agents_done) ga3c/GA3C/ProcessAgent.py:149-157
  *   cavoid_step_autoreset ............ the per-episode `env.reset()` + step loop  ga3c/GA3C/ProcessAgent.py:105-116
+ *   cavoid_*_packed .................. the same calls, returning ONE record per agent (obs | reward | done): what
+ *                                      an actor hands back per step                  ga3c/GA3C/ProcessAgent.py:149-157
+ *   cavoid_comm_* / cavoid_gather_* .. (new) the actors -> trainer hand-over across GPUs; the reference moves it
+ *                                      through mp.Queue between processes            ga3c/GA3C/ProcessAgent.py:221,238
  *   cavoid_step_continuous ........... the env-level continuous action space      run-ws/config.yaml:3-5 (ACTION_SPACE_TYPE)
  *   cavoid_observe ................... the obs half of reset()/step()             ga3c/GA3C/Environment.py:81-91
  *   cavoid_set_state/get_state ....... (new) explicit initial states for parity runs; env checkpointing
@@ -32,6 +36,8 @@
  *   done       u8     [W, N]          which_agents_done; 1 for absent agents
  *   game_over  u8     [W]             every *learning* agent of the world is done (TRAIN_MODE)
  *   actions    int32  [W, N]          index into the action table; ignored for done / scripted agents
+ *   packed     float  [W, N, 2+4+7M+2] the obs row followed by the step's reward and done (0.0f / 1.0f): the
+ *                                     per-agent record of the multi-GPU gather
  *   state_f64  double [4, W*N]        px, py, heading, t_remaining           (SoA, field-major)
  *   state_f32  float  [5, W*N]        gx, gy, radius, pref_speed, speed
  *   flags      u32    [W*N]           CAVOID_F_* bits
@@ -44,7 +50,7 @@
 extern "C" {
 #endif
 
-#define CAVOID_ABI_VERSION 1
+#define CAVOID_ABI_VERSION 2
 #define CAVOID_MAX_ACTIONS 32
 #define CAVOID_MAX_AGENTS 16
 
@@ -68,7 +74,8 @@ enum {
     CAVOID_ENOMEM = -2,    /* device allocation failed */
     CAVOID_EHIP = -3,      /* a HIP runtime call failed (see cavoid_last_hip_error) */
     CAVOID_EUNSUPPORTED = -4, /* max_agents outside the compiled range */
-    CAVOID_ENODEVICE = -5  /* no usable gfx950 device */
+    CAVOID_ENODEVICE = -5, /* no usable gfx950 device */
+    CAVOID_ECOMM = -6      /* an RCCL call failed (see cavoid_last_comm_error) */
 };
 
 typedef struct cavoid_cfg {
@@ -82,6 +89,10 @@ typedef struct cavoid_cfg {
     int32_t timeout_enabled;   /* default 1 */
     int32_t num_actions;       /* NUM_ACTIONS (Config.py:79) */
     int32_t evaluate_mode;     /* 0 (TRAIN_MODE): game over when every LEARNING agent is done; 1 (EVALUATE_MODE): every agent */
+    int32_t time_budget_from_goal_edge; /* U11: 1 (default): an agent's time budget is MAX_TIME_RATIO * (dist_to_goal -
+                                   NEAR_GOAL_THRESHOLD) / pref_speed (upstream agent.py as recalled); 0: SURVEY App. A's
+                                   MAX_TIME_RATIO * dist_to_goal / pref_speed.  Either way at least one DT. */
+    int32_t _pad0;
     double dt;                 /* DT 0.2 */
     double near_goal_threshold;/* 0.2 */
     double max_time_ratio;     /* 2.0 */
@@ -144,17 +155,52 @@ int cavoid_step_continuous(cavoid_env *env, const float *actions /* [W,N,2] */, 
  * observation of the new episode (rewards/done/game_over still describe the finished step) */
 int cavoid_step_autoreset(cavoid_env *env, const int32_t *actions, float *obs, float *rewards, uint8_t *done,
                           uint8_t *game_over, void *stream);
-/* n_steps back-to-back autoreset steps from one call; step t reads actions + t*action_stride
- * (int32 elements) and overwrites the same outputs.  Open-loop driver for benchmarks/scripted runs. */
+/* n_steps back-to-back autoreset steps in ONE launch; step t reads actions + t*action_stride
+ * (int32 elements) and overwrites the same outputs (after the call they hold the LAST step's).  Worlds are
+ * independent and a wavefront owns whole worlds, so the world state stays in registers between the steps: per
+ * step only the action slice is read and the outputs are written; the world buffer is updated once.
+ * Open-loop driver for benchmarks / scripted runs (a policy in the loop needs cavoid_step_autoreset). */
 int cavoid_step_autoreset_n(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
                             float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream);
 
-/* as cavoid_step_autoreset_n, but every launch carries its own HIP start/stop event pair (recorded
- * with the dispatch, so launch gaps are excluded); synchronises and returns the MEAN kernel
- * duration in milliseconds.  Measurement aid for bench.py's roofline figure. */
+/* ---- packed outputs: one record per agent, [W, N, cavoid_packed_width()] floats = (obs row | reward | done) ----
+ * The kernel assembles the record in its LDS tile and writes it with the same coalesced stores as the plain
+ * observation: no separate reward / done arrays, no pack pass before the multi-GPU gather.  reset / observe write
+ * reward 0 and the agents' current done state. */
+int32_t cavoid_packed_width(const cavoid_env *env);
+int cavoid_reset_packed(cavoid_env *env, const uint8_t *world_mask, float *packed, void *stream);
+int cavoid_observe_packed(cavoid_env *env, float *packed, void *stream);
+int cavoid_step_packed(cavoid_env *env, const int32_t *actions, float *packed, uint8_t *game_over, void *stream);
+int cavoid_step_autoreset_packed(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+                                 float *packed, uint8_t *game_over, void *stream);
+
+/* ---- multi-GPU hand-over: ONE all-gather of every rank's packed shard (RCCL over xGMI) ------------------------------
+ * One process per GPU, contiguous world ranges (rank r owns worlds [r*W, (r+1)*W)).  The communicator is created from
+ * a 128-byte id made on rank 0 by cavoid_comm_unique_id and handed to the other ranks out of band (the host side uses
+ * its process-group store).  cavoid_gather_begin(slot) enqueues, on the communicator's OWN stream, an ncclAllGather of
+ * `floats_per_rank` floats from `send` into `recv` [nranks * floats_per_rank] after everything enqueued so far on
+ * `producer_stream` (the step that wrote `send`); it returns at once.  cavoid_gather_wait(slot) makes a stream wait
+ * for the last gather begun in that slot (no host synchronisation).  Two slots: with send / recv double-buffered and
+ * slot = t % 2, step t+1 (writing the other buffer) overlaps gather t; before step t+2 re-uses the buffers the
+ * producer stream waits on the slot.  With nranks == 1 the gather is a device copy.
+ * Errors: CAVOID_ECOMM (see cavoid_last_comm_error). */
+typedef struct cavoid_comm cavoid_comm;
+#define CAVOID_COMM_ID_BYTES 128
+#define CAVOID_COMM_SLOTS 2
+int cavoid_comm_unique_id(void *id_out);
+int cavoid_comm_create(const void *unique_id, int32_t nranks, int32_t rank, int device, cavoid_comm **out);
+void cavoid_comm_destroy(cavoid_comm *comm);
+int cavoid_gather_begin(cavoid_comm *comm, int32_t slot, const float *send, float *recv, int64_t floats_per_rank,
+                        void *producer_stream);
+int cavoid_gather_wait(cavoid_comm *comm, int32_t slot, void *consumer_stream);
+int cavoid_last_comm_error(void);               /* raw ncclResult_t of the last CAVOID_ECOMM */
+
+/* as cavoid_step_autoreset_n in launches of `steps_per_launch` steps, every launch carrying its own HIP start/stop
+ * event pair (recorded with the dispatch, so launch gaps are excluded); synchronises and returns the MEAN duration
+ * of a launch in milliseconds.  Measurement aid for bench.py's roofline figure. */
 int cavoid_step_autoreset_n_timed(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
-                                  float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream,
-                                  float *mean_kernel_ms);
+                                  int32_t steps_per_launch, float *obs, float *rewards, uint8_t *done, uint8_t *game_over,
+                                  void *stream, float *mean_launch_ms);
 
 /* ---- batched GA3C actor bookkeeping (rollout) -------------------------------------------------------
  * Stands in for one ProcessAgent per world: ProcessAgent.run_episode / _accumulate_rewards /

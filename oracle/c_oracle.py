@@ -24,7 +24,8 @@ class OracleCfg(C.Structure):
         "reward_at_goal", "reward_collision", "reward_getting_close", "reward_time_step",
         "sensing_horizon", "close_penalty_slope", "max_turn_rate", "reward_clip_lo", "reward_clip_hi")] + [
         (n, C.c_int32) for n in ("max_agents", "max_other", "sort_method", "actions_fp32",
-                                 "timeout_enabled", "dynamics", "num_actions", "evaluate_mode")] + [
+                                 "timeout_enabled", "dynamics", "num_actions", "evaluate_mode",
+                                 "time_budget_from_goal_edge", "_pad0")] + [
         ("actions", (C.c_double * 2) * MAX_ACTIONS)]
 
 

@@ -41,7 +41,7 @@ void oracle_default_cfg(oracle_cfg *c, int32_t max_agents, int32_t max_other) {
     c->reward_getting_close = -0.1; c->reward_time_step = 0.0; c->sensing_horizon = INFINITY;
     c->close_penalty_slope = -0.5; c->max_turn_rate = 3.0; c->reward_clip_lo = -0.25; c->reward_clip_hi = 1.0;
     c->max_agents = max_agents; c->max_other = max_other; c->sort_method = SORT_CLOSEST_LAST;
-    c->actions_fp32 = 1; c->timeout_enabled = 1; c->dynamics = DYN_UNICYCLE; c->num_actions = 11;
+    c->actions_fp32 = 1; c->timeout_enabled = 1; c->time_budget_from_goal_edge = 1; c->dynamics = DYN_UNICYCLE; c->num_actions = 11;
     /* E4: 5 headings at full speed (step pi/12), 3 at half speed, 3 at zero speed (step pi/6) */
     const double fr[3] = {1.0, 0.5, 0.0}, st[3] = {PI / 12, PI / 6, PI / 6};
     const int cnt[3] = {5, 3, 3};
@@ -325,7 +325,7 @@ static void generate_world(const oracle_cfg *c, const oracle_gen *g, uint64_t se
             pol = u01(b[3]) < g->static_fraction ? POLICY_STATIC : POLICY_NONCOOP;
         double tx = (double)gx - px, ty = (double)gy - py;
         double dxg = px - (double)gx, dyg = py - (double)gy;
-        double straight = (sqrt(dxg * dxg + dyg * dyg) - c->near_goal_threshold) / (double)pref;
+        double straight = (sqrt(dxg * dxg + dyg * dyg) - (c->time_budget_from_goal_edge ? c->near_goal_threshold : 0.0)) / (double)pref;
         s->px[k] = px; s->py[k] = py; s->heading[k] = atan2(ty, tx);
         s->t_remaining[k] = fmax(c->max_time_ratio * straight, c->dt);
         s->gx[k] = gx; s->gy[k] = gy; s->radius[k] = radius; s->pref_speed[k] = pref; s->speed[k] = 0.0f;

@@ -24,6 +24,8 @@ typedef struct oracle_cfg {
     int32_t dynamics;          /* 0 unicycle, 1 unicycle max-turn-rate, 2 holonomic */
     int32_t num_actions;
     int32_t evaluate_mode;     /* game over when EVERY agent is done (EVALUATE_MODE) instead of every learning agent */
+    int32_t time_budget_from_goal_edge; /* U11: budget = ratio*(dist - near_goal)/pref (1, default) or ratio*dist/pref (0) */
+    int32_t _pad0;
     double actions[ORACLE_MAX_ACTIONS][2];
 } oracle_cfg;
 

@@ -95,6 +95,8 @@ class OracleConfig:
     dynamics: int = DYN_UNICYCLE         # U3
     max_turn_rate: float = 3.0           # rad/s, only DYN_UNICYCLE_MAX_TURN
     evaluate_mode: bool = False          # EVALUATE_MODE: the episode ends when EVERY agent is done
+    time_budget_from_goal_edge: bool = True   # U11: budget = ratio*(dist - NEAR_GOAL_THRESHOLD)/pref (upstream agent.py as
+                                         # recalled) vs SURVEY App. A's ratio*dist/pref (False)
     # min/max of the env's list of possible reward values; rewards are clipped into it
     reward_clip_lo: float = -0.25
     reward_clip_hi: float = 1.0
@@ -134,7 +136,8 @@ class Agent:
         self.policy = policy
         # time budget: MAX_TIME_RATIO x straight-line time, never below one step (run-ws/config.yaml:115-117)
         dxg, dyg = float(px) - float(gx), float(py) - float(gy)
-        straight = (math.sqrt(dxg * dxg + dyg * dyg) - cfg.near_goal_threshold) / self.pref_speed
+        offset = cfg.near_goal_threshold if cfg.time_budget_from_goal_edge else 0.0
+        straight = (math.sqrt(dxg * dxg + dyg * dyg) - offset) / self.pref_speed
         self.t_remaining = max(cfg.max_time_ratio * straight, cfg.dt)
         self.is_at_goal = False
         self.was_at_goal_already = False

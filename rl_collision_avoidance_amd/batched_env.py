@@ -102,7 +102,51 @@ class BatchedCollisionAvoidanceEnv(object):
         self.rewards = torch.zeros((W, N), dtype=torch.float32, device=self.device)
         self.done = torch.zeros((W, N), dtype=torch.uint8, device=self.device)
         self.game_over = torch.zeros((W,), dtype=torch.uint8, device=self.device)
+        self.packed_width = self.obs_width + 2
         self.seed(seed)
+
+    # -- packed outputs: one (obs | reward | done) record per agent, written by the kernel itself ---------------
+    def new_packed(self) -> torch.Tensor:
+        """A [W, N, obs_width + 2] float32 buffer for the ``*_packed`` calls (the multi-GPU gather record)."""
+        return torch.zeros((self.num_worlds, self.max_agents, self.packed_width), dtype=torch.float32, device=self.device)
+
+    def _packed(self, packed: torch.Tensor) -> torch.Tensor:
+        want = (self.num_worlds, self.max_agents, self.packed_width)
+        if packed.device != self.device or packed.dtype != torch.float32 or tuple(packed.shape) != want or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous float32 %s tensor on %s" % (want, self.device))
+        return packed
+
+    def reset_packed(self, packed: torch.Tensor, world_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        mask = None if world_mask is None else self._want(world_mask, (self.num_worlds,), torch.uint8, "world_mask")
+        _lib.check(self._lib.cavoid_reset_packed(self._h, self._ptr(mask), self._ptr(self._packed(packed)), self._stream()),
+                   "cavoid_reset_packed")
+        return packed
+
+    def observe_packed(self, packed: torch.Tensor) -> torch.Tensor:
+        _lib.check(self._lib.cavoid_observe_packed(self._h, self._ptr(self._packed(packed)), self._stream()), "cavoid_observe_packed")
+        return packed
+
+    def step_packed(self, actions: torch.Tensor, packed: torch.Tensor):
+        """``step`` with ONE output tensor: packed[..., :width] = obs, [..., width] = reward, [..., width+1] = done."""
+        a = self._actions(actions)
+        _lib.check(self._lib.cavoid_step_packed(self._h, self._ptr(a), self._ptr(self._packed(packed)), self._ptr(self.game_over),
+                                                self._stream()), "cavoid_step_packed")
+        return packed, self.game_over
+
+    def step_autoreset_packed(self, actions: torch.Tensor, packed: torch.Tensor, n_steps: Optional[int] = None):
+        """``step_autoreset`` (actions [W,N]) or ``step_autoreset_n`` (actions [T,W,N]) into a packed record buffer."""
+        if actions.dim() == 2:
+            a, n, stride = self._actions(actions), 1, 0
+        else:
+            T = actions.shape[0]
+            n = T if n_steps is None else int(n_steps)
+            if n > T:
+                raise ValueError("n_steps > number of action slices")
+            a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
+            stride = self.num_worlds * self.max_agents
+        _lib.check(self._lib.cavoid_step_autoreset_packed(self._h, self._ptr(a), stride, n, self._ptr(self._packed(packed)),
+                                                          self._ptr(self.game_over), self._stream()), "cavoid_step_autoreset_packed")
+        return packed, self.game_over
 
     # -- lifetime ------------------------------------------------------------------------------
     def close(self) -> None:
@@ -231,8 +275,9 @@ class BatchedCollisionAvoidanceEnv(object):
         return obs, self.rewards, self.done, self.game_over
 
     def step_autoreset_n(self, actions: torch.Tensor, n_steps: Optional[int] = None):
-        """Open-loop run: actions int32 [T,W,N]; launches ``n_steps`` (default T) steps back to back
-        from C, step t reading ``actions[t % T]`` only when n_steps <= T."""
+        """Open-loop run: actions int32 [T,W,N]; ``n_steps`` (default T, at most T) auto-reset steps in ONE launch --
+        the world state stays in registers between the steps, step t reads ``actions[t]``; the outputs hold the last
+        step's values afterwards."""
         T = actions.shape[0]
         n = T if n_steps is None else int(n_steps)
         if n > T:
@@ -245,22 +290,25 @@ class BatchedCollisionAvoidanceEnv(object):
         return self.obs, self.rewards, self.done, self.game_over
 
     # -- measurement -------------------------------------------------------------------------------
-    def kernel_time_ms(self, actions: torch.Tensor, n_steps: int) -> float:
-        """Run ``n_steps`` autoreset steps (cycling through actions [T,W,N]) with a HIP event pair per
-        launch; returns the mean kernel duration in ms (launch gaps excluded)."""
+    def kernel_time_ms(self, actions: torch.Tensor, n_steps: int, steps_per_launch: int = 1) -> float:
+        """Run ``n_steps`` autoreset steps (cycling through actions [T,W,N]) in launches of ``steps_per_launch`` steps,
+        a HIP event pair per launch; returns the mean duration of ONE LAUNCH in ms (launch gaps excluded)."""
         T = actions.shape[0]
         a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
         stride = self.num_worlds * self.max_agents
-        total, left = 0.0, int(n_steps)
+        spl = max(1, min(int(steps_per_launch), T))
+        total, launches, left = 0.0, 0, int(n_steps)
         while left > 0:
-            n = min(T, left)
+            n = min((T // spl) * spl, left)
             ms = C.c_float(0.0)
             _lib.check(self._lib.cavoid_step_autoreset_n_timed(
-                self._h, self._ptr(a), stride, n, self._ptr(self.obs), self._ptr(self.rewards), self._ptr(self.done),
+                self._h, self._ptr(a), stride, n, spl, self._ptr(self.obs), self._ptr(self.rewards), self._ptr(self.done),
                 self._ptr(self.game_over), self._stream(), C.byref(ms)), "cavoid_step_autoreset_n_timed")
-            total += ms.value * n
+            k = -(-n // spl)
+            total += ms.value * k
+            launches += k
             left -= n
-        return total / n_steps
+        return total / launches
 
     def timer_begin(self) -> None:
         _lib.check(self._lib.cavoid_timer_begin(self._h, self._stream()), "cavoid_timer_begin")

@@ -10,13 +10,21 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
-SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
-           os.path.join(CSRC, "cavoid_policy_capi.hip")]
+SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_multistep.hip"),
+           os.path.join(CSRC, "cavoid_rollout_capi.hip"),
+           os.path.join(CSRC, "cavoid_policy_capi.hip"), os.path.join(CSRC, "cavoid_comm_capi.hip")]
 HEADERS = {
-    "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_host.hpp"],
+    "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
+    "cavoid_multistep.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_host.hpp"],
     "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_host.hpp"],
+    "cavoid_comm_capi.hip": ["cavoid_host.hpp"],
 }
+# per-file extra flags.  The multi-step env kernels run their step loop inside the launch; MachineLICM would hoist every
+# constant materialisation of the body (float64 polynomial coefficients, config scalars) out of that loop into
+# registers live across it: 128 VGPRs + 276 B/lane of scratch instead of 128 VGPRs + 12 B (N = 4).
+EXTRA_FLAGS = {"cavoid_multistep.hip": ["-mllvm", "-disable-machine-licm"]}
+STAMP_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so.stamp")
 DEPS = SOURCES + [os.path.join(CSRC, h) for hs in HEADERS.values() for h in hs] + [os.path.join(ROOT, "include", "cavoid.h")]
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 # -ffp-contract=off: the reference env is unfused NumPy float64; keep mul/add separate so that the
@@ -32,32 +40,51 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built on this machine")
 
 
+def source_digest() -> str:
+    """sha256 over the flags and the contents of every source the library is built from (mtimes do not survive a
+    copy of the tree to another box; contents do)."""
+    import hashlib
+    h = hashlib.sha256(repr((FLAGS[:5], sorted(EXTRA_FLAGS.items()))).encode())
+    for d in sorted(DEPS):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """The in-tree binary does not match the in-tree sources (or is missing)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != source_digest()
 
 
 def _compile_objects(extra_flags, tag: str, force: bool, verbose: bool):
-    """One object per translation unit, rebuilt only when it (or a header it includes) changed."""
+    """One object per translation unit, rebuilt only when it (or a header it includes) changed; the stale ones are
+    compiled concurrently (each hipcc is single-threaded and the env kernels take ~1.5 min)."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         name = os.path.basename(src)
         obj = os.path.join(OBJ_DIR, name.replace(".hip", tag + ".o"))
         deps = [src, os.path.join(ROOT, "include", "cavoid.h")] + [os.path.join(CSRC, h) for h in HEADERS[name]]
         if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
-            cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+            cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(name, []) + list(extra_flags) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         objs.append(obj)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+            list(pool.map(subprocess.check_call, jobs))
     return objs
 
 
 def _link(objs, out: str, verbose: bool) -> str:
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    # RCCL by SONAME: inside a PyTorch process the loader binds to the librccl.so PyTorch has already mapped
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -67,6 +94,8 @@ def _link(objs, out: str, verbose: bool) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
         _link(_compile_objects([], "", force, verbose), LIB_PATH, verbose)
+        with open(STAMP_PATH, "w") as f:
+            f.write(source_digest() + "\n")
     return LIB_PATH
 
 

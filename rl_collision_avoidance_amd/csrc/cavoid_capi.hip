@@ -12,28 +12,11 @@
 #include "cavoid.h"
 #include "cavoid_host.hpp"
 #include "cavoid_kernels.hpp"
+#include "cavoid_launch.hpp"
 
 using namespace cavoid;
 
 thread_local int g_last_hip_error = 0;
-
-struct cavoid_env {
-    int device = 0;
-    int64_t W = 0, A = 0, world_offset = 0;
-    cavoid_cfg cfg{};
-    KCfg k{};
-    KState st{};
-    PoolRec *pool = nullptr;     // pre-generated scenarios (GEN v1 worlds 0..P-1, episode 0), 64-byte records
-    uint32_t *pool_episode = nullptr;   // [P] scratch episode counters for the fill launch
-    int64_t pool_size = 0;
-    void *slab = nullptr;
-    void *pool_slab = nullptr;
-    double *d_actions = nullptr;
-    int waves_per_block = 4;
-    size_t lds_bytes = 0;
-    int grid = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
 
 extern "C" int cavoid_abi_version(void) { return CAVOID_ABI_VERSION; }
 
@@ -47,6 +30,7 @@ extern "C" const char *cavoid_strerror(int code) {
         case CAVOID_EHIP: return "HIP runtime call failed (see cavoid_last_hip_error)";
         case CAVOID_EUNSUPPORTED: return "max_agents outside the compiled range [1,16]";
         case CAVOID_ENODEVICE: return "no usable HIP device";
+        case CAVOID_ECOMM: return "RCCL call failed (see cavoid_last_comm_error)";
         default: return "unknown error";
     }
 }
@@ -78,6 +62,7 @@ extern "C" int cavoid_default_cfg(cavoid_cfg *c, int32_t max_agents, int32_t max
     c->dynamics = CAVOID_DYN_UNICYCLE;
     c->actions_fp32 = 1;
     c->timeout_enabled = 1;
+    c->time_budget_from_goal_edge = 1;
     c->dt = 0.2;
     c->near_goal_threshold = 0.2;
     c->max_time_ratio = 2.0;
@@ -142,7 +127,7 @@ static int alloc_state(size_t worlds, size_t agents, size_t extra, void **slab, 
 }
 
 static int grid_for(const cavoid_env *e, int64_t worlds) {
-    const int wpw = 64 / e->cfg.max_agents;
+    const int wpw = e->k.wpw;
     const int64_t waves = (worlds + wpw - 1) / wpw;
     return (int)((waves + e->waves_per_block - 1) / e->waves_per_block);
 }
@@ -190,6 +175,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     KCfg &k = e->k;
     k.dt = cfg->dt;
     k.near_goal = cfg->near_goal_threshold;
+    k.budget_offset = cfg->time_budget_from_goal_edge ? cfg->near_goal_threshold : 0.0;
     k.near_goal_sq = cfg->near_goal_threshold * cfg->near_goal_threshold;
     k.max_time_ratio = cfg->max_time_ratio;
     k.collision_dist = cfg->collision_dist;
@@ -206,34 +192,45 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.gen_min_agents = cfg->gen_min_agents; k.gen_max_agents = cfg->gen_max_agents;
     k.pool_size = cfg->gen_pool_size;
     k.evaluate_mode = cfg->evaluate_mode ? 1 : 0;
-    // latency mode: with at most ~2 wavefronts per SIMD the step is latency bound and every lane
-    // pre-loads its next pool entry (+52 B read per agent-step) to keep a restart off a second
-    // dependent trip to memory; larger batches are bandwidth bound and gather on demand
-    k.prefetch_pool = (num_worlds * cfg->max_agents <= 64 * 2048) ? 1 : 0;
-    if (const char *ov = std::getenv("CAVOID_PREFETCH_POOL")) k.prefetch_pool = std::atoi(ov) != 0;
     k.seed_lo = 0; k.seed_hi = 0;
     k.num_worlds = num_worlds; k.world_offset = world_offset;
     k.action_table = e->d_actions;
 
-    // launch geometry: a wavefront owns floor(64/N) worlds; up to 4 wavefronts per workgroup,
-    // fewer when the per-wave LDS obs tile is large (keep a workgroup <= 64 KiB of LDS)
-    const int N = cfg->max_agents, wpw = 64 / N, lanes = wpw * N;
-    // obs tile: the wavefront's rows in ONE pass when the batch is latency bound (few wavefronts per SIMD) or
-    // when they fit ~9 KiB; else several passes of a multiple of 4 rows, so that the LDS footprint (and the
-    // wavefronts resident per CU) does not scale with N*(1+D)   [N=10: +7 % at saturation, -13 % at 8192 worlds]
-    int tile_rows = (int)(9216 / ((size_t)k.width * sizeof(float))) & ~3;
+    // launch geometry: a wavefront owns floor(64/N) whole worlds.  (Measured at 4 x 8192, 32-step launches: 16 / 8 / 4 /
+    // 2 / 1 worlds per wavefront -> 3.07 / 3.09 / 3.56 / 6.05 / 10.4 us per step: a wavefront's float64 chain costs the
+    // same issue slots whether 16 or 64 lanes are live, so emptier wavefronts only multiply the issue work.)
+    // CAVOID_WPW overrides it for such A/B runs.
+    const int N = cfg->max_agents, wpw_max = 64 / N;
+    int wpw = wpw_max;
+    if (const char *ov = std::getenv("CAVOID_WPW")) { int v = std::atoi(ov); if (v >= 1 && v <= wpw_max) wpw = v; }
+    k.wpw = wpw;
+    const int lanes = wpw * N;
+    // latency mode (at most ~2 full wavefronts per SIMD): multi-step launches keep every lane's NEXT pool record in
+    // registers (64 B read per agent per LAUNCH and per restart), so a restart never costs a dependent trip to
+    // memory.  Single-step launches gather on demand unless CAVOID_PREFETCH_POOL=1 (then +64 B per agent-step).
+    e->latency_mode = (num_worlds * cfg->max_agents <= 64 * 2048 && cfg->gen_pool_size > 0) ? 1 : 0;
+    if (const char *ov = std::getenv("CAVOID_PREFETCH_POOL")) {
+        const int v = std::atoi(ov);
+        e->latency_mode = (v != 0 && cfg->gen_pool_size > 0) ? 1 : 0;
+        e->prefetch_single = e->latency_mode;
+    }
+    k.prefetch_pool = e->latency_mode;
+    // obs tile (rows of width + 2 floats: the packed record is the widest row): the wavefront's rows in ONE pass when
+    // the batch is latency bound or when they fit ~9 KiB; else several passes of a multiple of 4 rows, so that the LDS
+    // footprint (and the wavefronts resident per CU) does not scale with N*(1+D)   [N=10: +7 % at saturation]
+    const int row_floats = k.width + 2;
+    int tile_rows = (int)(9216 / ((size_t)row_floats * sizeof(float))) & ~3;
     if (tile_rows < 4) tile_rows = 4;
-    const bool one_pass_fits = (size_t)(lds_floats_fixed() + lanes * k.width + 4) * sizeof(float) <= 65536;
-    if (tile_rows > lanes || (k.prefetch_pool && one_pass_fits)) tile_rows = lanes;
+    const bool one_pass_fits = (size_t)(lds_floats_block() + lds_floats_fixed() + lanes * row_floats + 4) * sizeof(float) <= 65536;
+    if (tile_rows > lanes || (e->latency_mode && one_pass_fits)) tile_rows = lanes;
     if (const char *ov = std::getenv("CAVOID_TILE_ROWS")) { int v = std::atoi(ov); if (v >= 1 && v <= lanes) tile_rows = v; }
     k.tile_rows = tile_rows;
-    const size_t per_wave = (size_t)(lds_floats_fixed() + ((tile_rows * k.width + 3) & ~3)) * sizeof(float);
-    int wpb = (int)((size_t)65536 / per_wave);
+    const size_t per_wave = (size_t)(lds_floats_fixed() + ((tile_rows * row_floats + 3) & ~3)) * sizeof(float);
+    int wpb = (int)(((size_t)65536 - lds_floats_block() * sizeof(float)) / per_wave);
     if (wpb < 1) { cavoid_destroy(e); return CAVOID_EUNSUPPORTED; }
     if (wpb > 4) wpb = 4;
     if (const char *ov = std::getenv("CAVOID_WAVES_PER_BLOCK")) { int v = std::atoi(ov); if (v >= 1 && v <= wpb) wpb = v; }
     e->waves_per_block = wpb;
-    e->lds_bytes = per_wave * wpb;
     e->grid = grid_for(e, num_worlds);
     *out = e;
     return CAVOID_OK;
@@ -250,29 +247,6 @@ extern "C" void cavoid_destroy(cavoid_env *e) {
 
 extern "C" int64_t cavoid_num_worlds(const cavoid_env *e) { return e ? e->W : 0; }
 extern "C" int32_t cavoid_obs_width(const cavoid_env *e) { return e ? e->k.width : 0; }
-
-template <int MODE>
-static int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int grid_x, const KIO &io, hipStream_t s,
-                     hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const dim3 grid(grid_x), block(64 * e->waves_per_block);
-    const size_t lds = e->lds_bytes;
-#define CAVOID_CASE(NN) \
-    case NN:                                                                                                            \
-        if (ev_start || ev_stop)                                                                                        \
-            hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, k, st, e->pool, io); \
-        else /* plain launch: capturable into a hipGraph */                                                             \
-            hipLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, k, st, e->pool, io);                         \
-        break;
-    switch (e->cfg.max_agents) {
-        CAVOID_CASE(1) CAVOID_CASE(2) CAVOID_CASE(3) CAVOID_CASE(4) CAVOID_CASE(5) CAVOID_CASE(6)
-        CAVOID_CASE(7) CAVOID_CASE(8) CAVOID_CASE(9) CAVOID_CASE(10) CAVOID_CASE(11) CAVOID_CASE(12)
-        CAVOID_CASE(13) CAVOID_CASE(14) CAVOID_CASE(15) CAVOID_CASE(16)
-        default: return CAVOID_EUNSUPPORTED;
-    }
-#undef CAVOID_CASE
-    HIP_TRY(hipGetLastError());
-    return CAVOID_OK;
-}
 
 template <int MODE>
 static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
@@ -292,6 +266,7 @@ static int fill_pool(cavoid_env *e, hipStream_t s) {
     st.episode = e->pool_episode;                              // the only world-buffer field the fill launch touches
     KIO io{};
     io.pool_out = e->pool;
+    io.n_steps = 1; io.obs_stride = k.width;
     return launch_on<MODE_RESET>(e, k, st, grid_for(e, e->pool_size), io, s, nullptr, nullptr);
 }
 
@@ -331,19 +306,44 @@ extern "C" int cavoid_get_state(cavoid_env *e, double *f64, float *f32, uint32_t
     return CAVOID_OK;
 }
 
+// output wiring of one launch: plain (obs / rewards / done arrays) or packed (one record per agent)
+static KIO plain_io(const cavoid_env *e, float *obs, float *rew, uint8_t *done, uint8_t *game_over) {
+    KIO io{};
+    io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    io.obs_stride = e->k.width; io.packed = 0; io.n_steps = 1;
+    return io;
+}
+static KIO packed_io(const cavoid_env *e, float *packed, uint8_t *game_over) {
+    KIO io{};
+    io.obs = packed; io.game_over = game_over;
+    io.obs_stride = e->k.width + 2; io.packed = 1; io.n_steps = 1;
+    return io;
+}
+
+extern "C" int32_t cavoid_packed_width(const cavoid_env *e) { return e ? e->k.width + 2 : 0; }
+
 extern "C" int cavoid_reset(cavoid_env *e, const uint8_t *world_mask, float *obs, void *stream) {
     if (!e) return CAVOID_EINVAL;
-    KIO io{};
+    KIO io = plain_io(e, obs, nullptr, nullptr, nullptr);
     io.mask = world_mask;
-    io.obs = obs;
+    return launch<MODE_RESET>(e, io, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_reset_packed(cavoid_env *e, const uint8_t *world_mask, float *packed, void *stream) {
+    if (!e || !packed) return CAVOID_EINVAL;
+    KIO io = packed_io(e, packed, nullptr);
+    io.mask = world_mask;
     return launch<MODE_RESET>(e, io, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cavoid_observe(cavoid_env *e, float *obs, void *stream) {
     if (!e || !obs) return CAVOID_EINVAL;
-    KIO io{};
-    io.obs = obs;
-    return launch<MODE_OBSERVE>(e, io, static_cast<hipStream_t>(stream));
+    return launch<MODE_OBSERVE>(e, plain_io(e, obs, nullptr, nullptr, nullptr), static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_observe_packed(cavoid_env *e, float *packed, void *stream) {
+    if (!e || !packed) return CAVOID_EINVAL;
+    return launch<MODE_OBSERVE>(e, packed_io(e, packed, nullptr), static_cast<hipStream_t>(stream));
 }
 
 static int step_args(cavoid_env *e, const void *actions, float *rew, uint8_t *done, uint8_t *go) {
@@ -353,69 +353,89 @@ static int step_args(cavoid_env *e, const void *actions, float *rew, uint8_t *do
 extern "C" int cavoid_step(cavoid_env *e, const int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
     if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
     if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;   // holonomic needs velocity actions
-    KIO io{};
-    io.actions = actions; io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    KIO io = plain_io(e, obs, rew, done, game_over);
+    io.actions = actions;
+    return launch<MODE_STEP>(e, io, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_step_packed(cavoid_env *e, const int32_t *actions, float *packed, uint8_t *game_over, void *stream) {
+    if (!e || !actions || !packed || !game_over) return CAVOID_EINVAL;
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
+    KIO io = packed_io(e, packed, game_over);
+    io.actions = actions;
     return launch<MODE_STEP>(e, io, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cavoid_step_continuous(cavoid_env *e, const float *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
     if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
-    KIO io{};
-    io.cont = actions; io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    KIO io = plain_io(e, obs, rew, done, game_over);
+    io.cont = actions;
     return launch<MODE_STEP>(e, io, static_cast<hipStream_t>(stream));
+}
+
+// the auto-reset step, n_steps >= 1 steps in ONE launch.  Latency mode (small batch with a scenario pool) takes the
+// register-prefetch instantiation for multi-step launches (and for single steps when CAVOID_PREFETCH_POOL=1).
+static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+                            hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
+    if (n_steps < 1 || action_stride < 0) return CAVOID_EINVAL;
+    io.actions = actions;
+    io.action_stride = action_stride;
+    io.n_steps = n_steps;
+    if (n_steps > 1 || e->prefetch_single)                      // the in-launch step loop lives in cavoid_multistep.hip
+        return cavoid_launch_multistep(e, io, e->latency_mode != 0, s, ev_start, ev_stop);
+    return launch<MODE_STEP_AUTORESET>(e, io, s, ev_start, ev_stop);
 }
 
 extern "C" int cavoid_step_autoreset(cavoid_env *e, const int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
     if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
-    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
-    KIO io{};
-    io.actions = actions; io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
-    return launch<MODE_STEP_AUTORESET>(e, io, static_cast<hipStream_t>(stream));
+    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), actions, 0, 1, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cavoid_step_autoreset_n(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
                                        float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
-    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 0 || action_stride < 0) return CAVOID_EINVAL;
-    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
-    KIO io{};
-    io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
-    for (int32_t t = 0; t < n_steps; ++t) {
-        io.actions = actions + (int64_t)t * action_stride;
-        int rc = launch<MODE_STEP_AUTORESET>(e, io, static_cast<hipStream_t>(stream));
-        if (rc != CAVOID_OK) return rc;
-    }
-    return CAVOID_OK;
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 0) return CAVOID_EINVAL;
+    if (n_steps == 0) return CAVOID_OK;
+    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), actions, action_stride, n_steps, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_step_autoreset_packed(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+                                            float *packed, uint8_t *game_over, void *stream) {
+    if (!e || !actions || !packed || !game_over || n_steps < 0) return CAVOID_EINVAL;
+    if (n_steps == 0) return CAVOID_OK;
+    return launch_autoreset(e, packed_io(e, packed, game_over), actions, action_stride, n_steps, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
-                                             float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream,
-                                             float *mean_kernel_ms) {
-    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 1 || action_stride < 0 || !mean_kernel_ms) return CAVOID_EINVAL;
-    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
+                                             int32_t steps_per_launch, float *obs, float *rew, uint8_t *done, uint8_t *game_over,
+                                             void *stream, float *mean_launch_ms) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 1 || steps_per_launch < 1 || !mean_launch_ms) return CAVOID_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int kPool = 128;
     hipEvent_t ev[2 * kPool];
     for (int i = 0; i < 2 * kPool; ++i) HIP_TRY(hipEventCreate(&ev[i]));
-    KIO io{};
-    io.obs = obs; io.rew = rew; io.done = done; io.game_over = game_over;
+    const KIO io = plain_io(e, obs, rew, done, game_over);
     double total_ms = 0.0;
-    int rc = CAVOID_OK;
-    for (int32_t t0 = 0; t0 < n_steps && rc == CAVOID_OK; t0 += kPool) {
-        const int32_t n = (n_steps - t0) < kPool ? (n_steps - t0) : kPool;
-        for (int32_t t = 0; t < n && rc == CAVOID_OK; ++t) {
-            io.actions = actions + (int64_t)(t0 + t) * action_stride;
-            rc = launch<MODE_STEP_AUTORESET>(e, io, s, ev[2 * t], ev[2 * t + 1]);
+    int rc = CAVOID_OK, launches = 0;
+    int32_t t0 = 0;
+    while (t0 < n_steps && rc == CAVOID_OK) {
+        int n = 0;
+        for (; n < kPool && t0 < n_steps && rc == CAVOID_OK; ++n) {
+            const int32_t k = (n_steps - t0) < steps_per_launch ? (n_steps - t0) : steps_per_launch;
+            rc = launch_autoreset(e, io, actions + (int64_t)t0 * action_stride, action_stride, k, s, ev[2 * n], ev[2 * n + 1]);
+            t0 += k;
         }
         if (rc != CAVOID_OK) break;
         if (hipStreamSynchronize(s) != hipSuccess) { rc = CAVOID_EHIP; break; }
-        for (int32_t t = 0; t < n; ++t) {
+        for (int t = 0; t < n; ++t) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev[2 * t], ev[2 * t + 1]) != hipSuccess) { rc = CAVOID_EHIP; break; }
             total_ms += ms;
         }
+        launches += n;
     }
     for (int i = 0; i < 2 * kPool; ++i) (void)hipEventDestroy(ev[i]);
-    if (rc == CAVOID_OK) *mean_kernel_ms = (float)(total_ms / n_steps);
+    if (rc == CAVOID_OK) *mean_launch_ms = (float)(total_ms / launches);
     return rc;
 }
 

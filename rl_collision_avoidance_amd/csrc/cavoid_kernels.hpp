@@ -6,7 +6,8 @@
 // (obs layout ga3c/GA3C/Config.py:40,72-76).
 //
 // Mapping (DESIGN.md "Kernels"):
-//   * one lane per agent ("host"), one 64-lane wavefront per tile of floor(64/N) whole worlds;
+//   * one lane per agent ("host"), one 64-lane wavefront per tile of up to floor(64/N) whole worlds
+//     (fewer for small batches, so that every SIMD has wavefronts to interleave);
 //     flat agent index a = w*N + i, so a wavefront's agents are CONTIGUOUS in every SoA field
 //     and each field is one coalesced global_load per wavefront;
 //   * post-move agent state (pos, vel, radius) is staged in LDS, wave-private, and the O(N^2)
@@ -47,7 +48,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 // kernel-argument POD (by value).  The action table lives in device memory (per-lane index).
 struct KCfg {
-    double dt, near_goal_sq, near_goal, max_time_ratio, collision_dist, close_range;
+    double dt, near_goal_sq, near_goal, budget_offset, max_time_ratio, collision_dist, close_range;
     double r_goal, r_coll, r_close, r_step, close_slope, clip_lo, clip_hi, horizon, max_turn_rate;
     double gen_nonlearning, gen_static, gen_goal_jitter, gen_angle_jitter;
     int32_t max_other, width, sort_method, dynamics, actions_fp32, timeout_enabled, num_actions;
@@ -55,6 +56,7 @@ struct KCfg {
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
+    int32_t wpw;                 // worlds per wavefront, 1..floor(64/N): small batches spread over more, emptier wavefronts
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
@@ -81,13 +83,17 @@ static_assert(sizeof(PoolRec) == 64, "pool record must be one 64-byte line");
 
 struct KIO {
     PoolRec *pool_out;       // MODE_RESET only: write the generated agents here (pool fill) instead of the world buffer
-    const int32_t *actions;  // [W,N] or null
+    const int32_t *actions;  // [n_steps][W,N] (slice t at actions + t*action_stride) or null
     const float *cont;       // [W,N,2] or null
     const uint8_t *mask;     // reset mask [W] or null
-    float *obs;              // [W,N,width] or null
-    float *rew;              // [W,N]
-    uint8_t *done;           // [W,N]
+    float *obs;              // [W,N,obs_stride] or null
+    float *rew;              // [W,N]; null in packed mode
+    uint8_t *done;           // [W,N]; null in packed mode
     uint8_t *game_over;      // [W]
+    int64_t action_stride;   // int32 elements between the action slices of consecutive steps
+    int32_t n_steps;         // steps taken by ONE launch (MODE_STEP_AUTORESET; 1 elsewhere)
+    int32_t obs_stride;      // floats per output row: width, or width + 2 in packed mode
+    int32_t packed;          // != 0: reward and done (as 0.0f / 1.0f) are columns width, width+1 of the agent's row
 };
 
 __device__ __forceinline__ double wrap_angle(double a) {
@@ -127,15 +133,11 @@ struct Agent {
     uint32_t flags;
 };
 
-template <int N>
-struct Geometry {
-    static constexpr int kWorldsPerWave = 64 / N;
-    static constexpr int kLanes = kWorldsPerWave * N;  // active lanes per wavefront
-};
-
-// LDS carve per wavefront: 4 double[64] (pos, vel) + float[64] (radius) + double[64] (action
-// table, 32 x 2) + obs tile float[kLanes*width]
-__host__ __device__ constexpr int lds_floats_fixed() { return 64 * 2 * 4 + 64 + 64 * 2; }
+// LDS carve: per workgroup double[64] (the action table, 32 x 2: every wavefront writes the same values, so no
+// workgroup barrier is needed), then per wavefront 4 double[64] (pos, vel) + float[64] (radius) + the obs tile
+// float[tile_rows * obs_stride]
+__host__ __device__ constexpr int lds_floats_block() { return 64 * 2; }
+__host__ __device__ constexpr int lds_floats_fixed() { return 64 * 2 * 4 + 64; }
 
 // sin/cos for |x| up to a few thousand: 2-term Cody-Waite reduction by pi/2 and the degree-13/14
 // kernels of the classic fdlibm sin/cos (max error ~1 ulp).  Headings live in [-pi, pi), so the
@@ -194,7 +196,7 @@ __device__ __forceinline__ void generate_agent(const KCfg &c, uint32_t gw, uint3
     if (i > 0 && u01(q.z) < c.gen_nonlearning) pol = u01(q.w) < c.gen_static ? 1u : 2u;
     const double tx = (double)a.gx - a.px, ty = (double)a.gy - a.py;
     const double dxg = a.px - (double)a.gx, dyg = a.py - (double)a.gy;
-    const double straight = (sqrt(dxg * dxg + dyg * dyg) - c.near_goal) / (double)a.pref;
+    const double straight = (sqrt(dxg * dxg + dyg * dyg) - c.budget_offset) / (double)a.pref;   // U11 (x - 0.0 is exact)
     a.heading = atan2(ty, tx);
     a.t_rem = fmax(c.max_time_ratio * straight, c.dt);
     a.vx = a.vy = 0.0;
@@ -339,7 +341,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
                                              const double *lds_vy, const float *lds_r, const int (&gr)[Others<N>::K],
                                              const float (&gapf)[Others<N>::K], uint32_t others, uint32_t near, float *tile,
-                                             float *obs_dst, int rows_active) {
+                                             float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f) {
     constexpr int K = Others<N>::K, NO = N - 1;
     const int M = c.max_other, width = c.width;
     const bool present = active && (a.flags & CAVOID_F_PRESENT);
@@ -425,7 +427,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     const int rpp = c.tile_rows;                                 // rows per pass
     for (int p0 = 0; p0 < rows_active; p0 += rpp) {
     if (active && lane >= p0 && lane < p0 + rpp) {
-        float *row = tile + (lane - p0) * width;
+        float *row = tile + (lane - p0) * ostride;
         row[0] = (present && (a.flags & CAVOID_F_LEARNING)) ? 1.0f : 0.0f;
         row[1] = (float)kept;                                   // 0 for an absent agent (others == 0)
         row[2] = present ? (float)e.dist : 0.0f;
@@ -449,10 +451,11 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
             f[6] = gapf[o];
         }
         for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;   // unfilled slots
+        if (packed) { row[width] = rew_f; row[width + 1] = done_f; }   // (obs | reward | done) gather record
     }
     wave_lds_sync();
     const int rows_here = rows_active - p0 < rpp ? rows_active - p0 : rpp;
-    flush_tile(tile, obs_dst + (int64_t)p0 * width, rows_here * width, lane);
+    flush_tile(tile, obs_dst + (int64_t)p0 * ostride, rows_here * ostride, lane);
     if (p0 + rpp < rows_active) wave_lds_sync();                 // the next pass overwrites the tile
     }
 }
@@ -501,41 +504,58 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, 
     }
 }
 
-enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESET = 3 };
+enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESET = 3, MODE_STEP_AUTORESET_PF = 4, MODE_STEP_AUTORESET_N = 5 };
 
 #ifndef CAVOID_OCC4_MAX_N
 #define CAVOID_OCC4_MAX_N 4
 #endif
+// MODE_STEP_AUTORESET    one auto-reset step per launch (a policy in the loop);
+// MODE_STEP_AUTORESET_N  io.n_steps steps per launch: a wavefront owns whole worlds and nothing crosses worlds, so the
+//                        world state stays in registers between steps; per step only the action slice is read and the
+//                        step's outputs (obs, reward, done, game_over) are written; the world buffer is written back once,
+//                        after the last step.  This removes the launch boundary and the state round trip from every step
+//                        but the first;
+// MODE_STEP_AUTORESET_PF the same with the NEXT episode's pool record of every lane held in registers (loaded with the
+//                        state, re-loaded after a restart): latency mode for small batches, where a wavefront is alone on
+//                        its SIMD and a restart must not cost a dependent trip to memory (may use more registers).
 template <int N, int MODE>
 // (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
 //  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
-__global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
-    using G = Geometry<N>;
+__global__ void __launch_bounds__(256, (MODE == MODE_STEP_AUTORESET_PF ? 2 : (N <= CAVOID_OCC4_MAX_N ? 4 : 1)))
+env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
+    constexpr bool kAuto = MODE == MODE_STEP_AUTORESET || MODE == MODE_STEP_AUTORESET_PF || MODE == MODE_STEP_AUTORESET_N;
+    constexpr bool kLoop = MODE == MODE_STEP_AUTORESET_PF || MODE == MODE_STEP_AUTORESET_N;
+    constexpr bool kStepping = MODE == MODE_STEP || kAuto;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int width = c.width;
-    const int tile_floats = (c.tile_rows * width + 3) & ~3;
+    const int width = c.width, ostride = io.obs ? io.obs_stride : width;
+    const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
     const int per_wave_floats = lds_floats_fixed() + tile_floats;
-    float *wbase = reinterpret_cast<float *>(smem) + (size_t)wave_in_block * per_wave_floats;
+    double *lds_tab = reinterpret_cast<double *>(smem);
+    float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
     double *lds_px = reinterpret_cast<double *>(wbase);
-    double *lds_py = lds_px + 64, *lds_vx = lds_py + 64, *lds_vy = lds_vx + 64, *lds_tab = lds_vy + 64;
-    float *lds_r = reinterpret_cast<float *>(lds_tab + 64);
+    double *lds_py = lds_px + 64, *lds_vx = lds_py + 64, *lds_vy = lds_vx + 64;
+    float *lds_r = reinterpret_cast<float *>(lds_vy + 64);
     float *tile = lds_r + 64;
 
+    const int wpw = c.wpw, lanes_used = wpw * N;          // worlds / lanes this wavefront really owns
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-    const int64_t w0 = wave * G::kWorldsPerWave;           // first world of this wavefront
+    const int64_t w0 = wave * wpw;                         // first world of this wavefront
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = w0 + lw;
-    const bool active = lane < G::kLanes && w < c.num_worlds;
-    const int base = lane < G::kLanes ? lw * N : 0;        // first lane of this lane's world
+    const bool active = lane < lanes_used && w < c.num_worlds;
+    const int base = lane < lanes_used ? lw * N : 0;       // first lane of this lane's world
     const int64_t a_idx = w * N + i;                       // == w0*N + lane: contiguous per wave
-    const bool stepping = MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET;
+    const bool packed = io.packed != 0;
+    int64_t worlds_here = c.num_worlds - w0;
+    if (worlds_here > wpw) worlds_here = wpw;
+    if (worlds_here < 0) worlds_here = 0;
     CAVOID_STAMP(0);
 
     // action table -> LDS: the load is issued first and lands together with the state loads; the
     // decode then needs no second trip to memory
     double tab_v = 0.0;
-    const bool use_table = stepping && io.actions != nullptr;
+    const bool use_table = kStepping && io.actions != nullptr;
     if (use_table && lane < 2 * c.num_actions) tab_v = c.action_table[lane];
 
     Agent a;
@@ -544,41 +564,39 @@ __global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_ker
     a.flags = 0u;
     uint32_t episode = 0u;
     bool fresh = false;                                    // this lane's world starts a new episode
-    int act = 0;
+    int act_next = 0;                                      // the NEXT step's action index, loaded one step ahead
     float c0 = 0.f, c1 = 0.f;
     if (active) {
         if (MODE == MODE_RESET) {
             fresh = io.mask == nullptr || io.mask[w] != 0;
             episode = s.episode[w] + (fresh ? 1u : 0u);
-        } else if (MODE == MODE_STEP_AUTORESET) {
+        } else if (kAuto) {
             episode = s.episode[w];
         }
         if (!fresh) {
             load_agent(s, a_idx, a);
-            if (!stepping) a.speed = s.speed[a_idx];
+            if (!kStepping) a.speed = s.speed[a_idx];
         }
-        if (stepping) {
+        if (kStepping) {
             if (io.cont) { c0 = io.cont[2 * a_idx]; c1 = io.cont[2 * a_idx + 1]; }
-            else act = io.actions[a_idx];
+            else act_next = io.actions[a_idx];
         }
     }
     if (use_table) lds_tab[lane] = tab_v;
     CAVOID_STAMP(1);                                        // loads landed
 #ifdef CAVOID_ABLATE
-    // development aid: the memory skeleton of the step (same loads, same stores, no arithmetic) --
+    // development aid: the memory skeleton of ONE step (same loads, same stores, no arithmetic) --
     // the launch + memory floor the real kernel is measured against
-    if (stepping) {
-        if (use_table) lds_tab[lane] = tab_v;
+    if (kStepping) {
         if (active && lane < c.tile_rows) {
-            float *row = tile + lane * width;
-            for (int k = 0; k < width; ++k) row[k] = (float)a.px + (float)k + (float)act;
+            float *row = tile + lane * ostride;
+            for (int k = 0; k < ostride; ++k) row[k] = (float)a.px + (float)k + (float)act_next;
         }
         wave_lds_sync();
-        int64_t worlds_here = c.num_worlds - w0;
-        if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
-        if (io.obs && worlds_here > 0) flush_tile(tile, io.obs + w0 * N * width, (int)worlds_here * N * width, lane);
+        if (io.obs && worlds_here > 0) flush_tile(tile, io.obs + w0 * N * ostride, (int)worlds_here * N * ostride, lane);
         if (active) {
-            io.rew[a_idx] = (float)a.py; io.done[a_idx] = 0;
+            if (io.rew) io.rew[a_idx] = (float)a.py;
+            if (io.done) io.done[a_idx] = 0;
             if (i == 0) io.game_over[w] = 0;
             s.px[a_idx] = a.px + 1.0; s.py[a_idx] = a.py + 1.0; s.heading[a_idx] = a.heading; s.t_rem[a_idx] = a.t_rem - 0.2;
             s.speed[a_idx] = a.pref; s.flags[a_idx] = a.flags;
@@ -586,16 +604,13 @@ __global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_ker
         return;
     }
 #endif
-    // small batches are latency bound: fetch the NEXT episode's pool entry up front, together with the
-    // state loads, so a restarting world does not pay a second dependent trip to memory
+    // latency mode: the NEXT episode's pool entry is fetched up front, together with the state loads, and again
+    // right after a restart consumed it -- a restarting world never pays a second dependent trip to memory
     Agent nxt = a;
-    const bool prefetched = MODE == MODE_STEP_AUTORESET && c.prefetch_pool != 0 && c.pool_size > 0;
-    if (prefetched && active) {
+    constexpr bool kPrefetch = MODE == MODE_STEP_AUTORESET_PF;
+    if (kPrefetch && active)
         load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
-    }
-    const uint32_t flags_in = a.flags;
-    const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
-    const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
+    const bool present_first = active && (a.flags & CAVOID_F_PRESENT);   // presence changes only at a restart
 
     if (MODE == MODE_RESET) {
         if (fresh) new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
@@ -607,7 +622,25 @@ __global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_ker
         a.vy = (double)a.speed * sn;
     }
 
-    if (stepping) {
+    const int n_steps = kLoop ? io.n_steps : 1;
+    bool restarted_any = false, moved_any = false;         // what the write-back after the last step must cover
+    const int lane0 = lane, i0 = i, base0 = base;
+    const int64_t a_idx0 = a_idx;
+    for (int t = 0; t < n_steps; ++t) {
+    // Everything derived from the lane id is loop invariant, and the compiler would hoist all of it (LDS addresses of
+    // the N-1 others, every output address) out of the step loop into registers that stay live across the whole body --
+    // measured: 128 VGPRs + 350 B/lane of scratch instead of 127 VGPRs.  Re-materialising the ids per step keeps the
+    // body's register footprint that of the single-step kernel.
+    int lane = lane0, i = i0, base = base0;
+    int64_t a_idx = a_idx0;
+    if (kLoop) asm volatile("" : "+v"(lane), "+v"(i), "+v"(base), "+v"(a_idx));
+    const uint32_t flags_in = a.flags;
+    const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
+    const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
+    int act = act_next;
+    if (kLoop && t + 1 < n_steps && active) act_next = io.actions[(int64_t)(t + 1) * io.action_stride + a_idx];
+
+    if (kStepping) {
         // ---- E4 decode ------------------------------------------------------------------------------
         wave_lds_sync();
         const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
@@ -629,6 +662,7 @@ __global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_ker
         if (c.actions_fp32) { a0 = (double)(float)a0; a1 = (double)(float)a1; }
         // ---- E5 dynamics (computed by every lane, committed only by agents still running) ------------
         const bool moving = present_in && !done_in;
+        moved_any = moved_any || moving;
         double npx, npy, nh, nvx, nvy, nsp;
         if (c.dynamics == CAVOID_DYN_HOLONOMIC) {
             nsp = sqrt(a0 * a0 + a1 * a1);
@@ -676,8 +710,8 @@ __global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_ker
     pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, gr, gapf, others, near, hit, min_gap);
 
     CAVOID_STAMP(4);                                        // ego frame + pair pass done
-    bool restart = false;
-    if (stepping) {
+    float rew_f = 0.0f, done_f = (present && (a.flags & CAVOID_F_DONE_MASK) == 0u) ? 0.0f : 1.0f;   // reset / observe, packed
+    if (kStepping) {
         // ---- E7 rewards, E8 done ---------------------------------------------------------------------
         double r = 0.0;
         bool done = true;
@@ -695,19 +729,27 @@ __global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_ker
         const unsigned long long running = __ballot(present && ((a.flags & CAVOID_F_LEARNING) || c.evaluate_mode) && !done);
         const unsigned long long wmask = ((1ull << N) - 1ull) << base;
         const bool game_over = (running & wmask) == 0ull;
+        rew_f = (float)r;
+        done_f = done ? 1.0f : 0.0f;
         if (active) {
-            io.rew[a_idx] = (float)r;
-            io.done[a_idx] = done ? 1 : 0;
+            if (!packed) {
+                io.rew[a_idx] = rew_f;
+                io.done[a_idx] = done ? 1 : 0;
+            }
             if (i == 0) io.game_over[w] = game_over ? 1 : 0;
         }
-        if (MODE == MODE_STEP_AUTORESET) {
-            restart = active && game_over;
+        if (kAuto) {
+            const bool restart = active && game_over;
             if (__ballot(restart) != 0ull) {               // wave-uniform: some world of this tile restarts
                 wave_lds_sync();                           // every lane is done reading the old positions
                 if (restart) {
                     episode += 1u;
-                    if (prefetched) a = nxt;
-                    else new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
+                    restarted_any = true;
+                    if (kPrefetch) {
+                        a = nxt;
+                        if (t + 1 < n_steps)               // re-arm: the record of the episode after this one
+                            load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
+                    } else new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
                     present = (a.flags & CAVOID_F_PRESENT) != 0u;
                     lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = 0.0; lds_vy[lane] = 0.0;
                     lds_r[lane] = present ? a.radius : -1.0f;
@@ -726,22 +768,21 @@ __global__ void __launch_bounds__(256, (N <= CAVOID_OCC4_MAX_N ? 4 : 1)) env_ker
     CAVOID_STAMP(5);                                        // rewards / restart done
     // ---- E9 observation: once per step, after the restart decision -----------------------------------
     if (io.obs) {
-        int64_t worlds_here = c.num_worlds - w0;
-        if (worlds_here > G::kWorldsPerWave) worlds_here = G::kWorldsPerWave;
-        if (worlds_here < 0) worlds_here = 0;
         CAVOID_STAMP(6);
         assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, gr, gapf, others, near, tile,
-                        io.obs + w0 * N * width, (int)worlds_here * N);
+                        io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f);
     }
-
     CAVOID_STAMP(7);                                        // tile flushed
-    // ---- state write-back ---------------------------------------------------------------------------
-    if (stepping) {
-        if (restart) {                                     // fresh episode: every field of every row
+    if (kLoop && n_steps > 1) wave_lds_sync();             // the next step re-stages the LDS arrays and the tile
+    }   // step loop
+
+    // ---- state write-back (once per launch) -----------------------------------------------------------
+    if (kStepping) {
+        if (restarted_any) {                               // a fresh episode started: every field of every row
             store_agent(s, a_idx, a);
             if (i == 0) s.episode[w] = episode;
-        } else if (present_in) {
-            if (!done_in) {                                // frozen agents keep pos / heading / time
+        } else if (present_first) {
+            if (moved_any) {                               // agents frozen throughout keep pos / heading / time
                 s.px[a_idx] = a.px; s.py[a_idx] = a.py; s.heading[a_idx] = a.heading; s.t_rem[a_idx] = a.t_rem;
             }
             s.speed[a_idx] = a.speed;

@@ -1,0 +1,67 @@
+// cavoid_launch.hpp -- host-side launch plumbing shared by the translation units that instantiate env_kernel:
+// cavoid_capi.hip (single-step / reset / observe instantiations) and cavoid_multistep.hip (the instantiations with the
+// in-launch step loop, compiled with -mllvm -disable-machine-licm, see build.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "cavoid.h"
+#include "cavoid_host.hpp"
+#include "cavoid_kernels.hpp"
+
+struct cavoid_env {
+    int device = 0;
+    int64_t W = 0, A = 0, world_offset = 0;
+    cavoid_cfg cfg{};
+    cavoid::KCfg k{};
+    cavoid::KState st{};
+    cavoid::PoolRec *pool = nullptr;     // pre-generated scenarios (GEN v1 worlds 0..P-1, episode 0), 64-byte records
+    uint32_t *pool_episode = nullptr;   // [P] scratch episode counters for the fill launch
+    int64_t pool_size = 0;
+    void *slab = nullptr;
+    void *pool_slab = nullptr;
+    double *d_actions = nullptr;
+    int waves_per_block = 4;
+    int grid = 0;
+    int latency_mode = 0;        // small batch: multi-step launches keep the next pool record in registers (MODE_STEP_AUTORESET_PF)
+    int prefetch_single = 0;     // ... and single-step launches too (CAVOID_PREFETCH_POOL=1; costs 64 B of reads per agent-step)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+
+namespace cavoid {
+
+template <int MODE>
+static inline int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int grid_x, const KIO &io, hipStream_t s,
+                     hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const dim3 grid(grid_x), block(64 * e->waves_per_block);
+    // dynamic LDS: the action table + per wavefront the staging arrays and an obs tile of this launch's row width
+    const int row = io.obs ? io.obs_stride : k.width;
+    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed() + ((k.tile_rows * row + 3) & ~3))) * sizeof(float);
+#define CAVOID_CASE(NN) \
+    case NN:                                                                                                            \
+        if (ev_start || ev_stop)                                                                                        \
+            hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, k, st, e->pool, io); \
+        else /* plain launch: capturable into a hipGraph */                                                             \
+            hipLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, k, st, e->pool, io);                         \
+        break;
+    switch (e->cfg.max_agents) {
+#ifdef CAVOID_DEV_ONLY_N   /* development builds: instantiate two sizes only (compile time) */
+        CAVOID_CASE(4) CAVOID_CASE(10)
+#else
+        CAVOID_CASE(1) CAVOID_CASE(2) CAVOID_CASE(3) CAVOID_CASE(4) CAVOID_CASE(5) CAVOID_CASE(6)
+        CAVOID_CASE(7) CAVOID_CASE(8) CAVOID_CASE(9) CAVOID_CASE(10) CAVOID_CASE(11) CAVOID_CASE(12)
+        CAVOID_CASE(13) CAVOID_CASE(14) CAVOID_CASE(15) CAVOID_CASE(16)
+#endif
+        default: return CAVOID_EUNSUPPORTED;
+    }
+#undef CAVOID_CASE
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}
+
+
+}  // namespace cavoid
+
+// multi-step auto-reset launch (cavoid_multistep.hip): prefetch != 0 -> MODE_STEP_AUTORESET_PF, else MODE_STEP_AUTORESET_N
+int cavoid_launch_multistep(cavoid_env *e, const cavoid::KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);

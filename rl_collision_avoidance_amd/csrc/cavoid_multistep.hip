@@ -1,0 +1,13 @@
+// cavoid_multistep.hip -- the env_kernel instantiations that take several auto-reset steps inside ONE launch
+// (cavoid_step_autoreset_n / cavoid_step_autoreset_packed with n_steps > 1): MODE_STEP_AUTORESET_PF (small batches: the next
+// scenario-pool record of every lane is held in registers) and MODE_STEP_AUTORESET_N (restarts gather on demand).
+// Own translation unit because it is compiled with -mllvm -disable-machine-licm (build.py): MachineLICM would hoist every
+// constant materialisation of the step body out of the step loop into registers live across it.
+#include "cavoid_launch.hpp"
+
+using namespace cavoid;
+
+int cavoid_launch_multistep(cavoid_env *e, const KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (prefetch) return launch_on<MODE_STEP_AUTORESET_PF>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
+    return launch_on<MODE_STEP_AUTORESET_N>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
+}

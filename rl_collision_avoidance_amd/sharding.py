@@ -6,12 +6,17 @@ rank r owns worlds [offset_r, offset_r + count_r), its scenario RNG is keyed on 
 (`world_offset`), and the sharded run reproduces the unsharded one bit for bit.
 
 The one real exchange the north-star names is returning per-world (obs, reward, done) to a
-trainer: `gather_step_outputs` packs them into one contiguous float32 buffer per rank and issues
-ONE `all_gather_into_tensor` (RCCL over xGMI with backend "nccl"; gloo on CPU for tests).  For the
-full GA3C loop keep a policy replica per GPU and skip this gather.
+trainer.  The env kernel writes the packed per-agent record (obs | reward | done) itself
+(`cavoid_step*_packed`), and `NativeGather` issues ONE `ncclAllGather` per step through the C ABI
+(`cavoid_gather_begin/wait`, RCCL over xGMI) on the communicator's own stream, double-buffered so
+that gather(t) overlaps step(t+1) -- `ShardedEnv.step_and_gather`.  `gather_step_outputs` is the
+same exchange through `torch.distributed` (`all_gather_into_tensor`; gloo on CPU for the tests,
+ragged shards padded).  For the full GA3C loop keep a policy replica per GPU and skip this gather
+(SURVEY.md section 8e).
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Tuple
 
 import torch
@@ -65,6 +70,64 @@ def gather_step_outputs(packed: torch.Tensor, total_worlds: int, group=None) -> 
     return torch.cat([recv[r, :counts[r]] for r in range(size)], dim=0)
 
 
+class NativeGather(object):
+    """The all-gather behind the C ABI: one RCCL communicator per process (one process per GPU), created from a
+    128-byte id that rank 0 makes and the process group hands round (any backend: only 128 bytes travel that way)."""
+
+    SLOTS = 2
+
+    def __init__(self, device, group=None):
+        from . import _lib
+        self._libmod = _lib
+        self._lib = _lib.lib()
+        self.device = torch.device(device)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.size = dist.get_world_size(group) if dist.is_initialized() else 1
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.size > 1:
+            if self.rank == 0:
+                buf = (C.c_ubyte * 128)()
+                _lib.check(self._lib.cavoid_comm_unique_id(buf), "cavoid_comm_unique_id")
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            backend = dist.get_backend(group)
+            carrier = ident.to(self.device) if backend == "nccl" else ident
+            dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = carrier.cpu()
+        raw = (C.c_ubyte * 128)(*ident.tolist())
+        handle = C.c_void_p()
+        _lib.check(self._lib.cavoid_comm_create(raw, self.size, self.rank, self.device.index or 0, C.byref(handle)),
+                   "cavoid_comm_create")
+        self._h = handle
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def begin(self, slot: int, send: torch.Tensor, recv: torch.Tensor) -> None:
+        """Enqueue gather `slot` of `send` (this rank's packed shard) into `recv` [size * send.numel()] behind the work
+        already on the current stream; returns at once."""
+        if send.dtype != torch.float32 or recv.dtype != torch.float32 or not send.is_contiguous() or not recv.is_contiguous():
+            raise ValueError("send / recv must be contiguous float32 tensors")
+        if recv.numel() != self.size * send.numel():
+            raise ValueError("recv must hold %d x send" % self.size)
+        self._libmod.check(self._lib.cavoid_gather_begin(self._h, slot, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                                         send.numel(), self._stream()), "cavoid_gather_begin")
+
+    def wait(self, slot: int) -> None:
+        """Make the current stream wait for the last gather begun in `slot` (no host synchronisation)."""
+        self._libmod.check(self._lib.cavoid_gather_wait(self._h, slot, self._stream()), "cavoid_gather_wait")
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.cavoid_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedEnv(object):
     """This rank's shard of a `total_worlds`-world env (one process per GPU)."""
 
@@ -80,14 +143,52 @@ class ShardedEnv(object):
         self.env = BatchedCollisionAvoidanceEnv(self.count, config, device=device, world_offset=self.offset, seed=seed,
                                                 **cfg_overrides)
         self._packed = None
+        self._native = None
+        self._send = self._recv = None
+        self._t = 0
 
     def __getattr__(self, name):
         return getattr(self.env, name)
 
     def gather(self) -> torch.Tensor:
-        """(obs | reward | done) of ALL worlds on every rank: [total_worlds, N, width+2] float32."""
+        """(obs | reward | done) of ALL worlds on every rank: [total_worlds, N, width+2] float32, from the env's plain
+        outputs through torch.distributed (works for ragged shards and on any backend)."""
         e = self.env
         self._packed = pack_step_outputs(e.obs, e.rewards, e.done, self._packed)
         if self.size == 1:
             return self._packed
         return gather_step_outputs(self._packed, self.total_worlds, self.group)
+
+    # -- the native path: packed records straight from the kernel, ncclAllGather behind the C ABI, overlapped ---------
+    def _native_setup(self):
+        if self.total_worlds % self.size:
+            raise ValueError("the native gather needs equal shards (total_worlds %% world_size == 0)")
+        e = self.env
+        self._native = NativeGather(e.device, self.group)
+        self._send = [e.new_packed() for _ in range(NativeGather.SLOTS)]
+        self._recv = [torch.zeros((self.total_worlds, e.max_agents, e.packed_width), dtype=torch.float32, device=e.device)
+                      for _ in range(NativeGather.SLOTS)]
+
+    def step_and_gather(self, actions: torch.Tensor) -> int:
+        """One auto-reset step of this shard into a packed buffer + the all-gather of it, begun but not waited for:
+        the NEXT call's step runs while this gather is on the wire.  Returns the slot; `gathered(slot)` makes the
+        current stream wait for it and returns [total_worlds, N, width+2] (valid until the slot's next use)."""
+        if self._native is None:
+            self._native_setup()
+        slot = self._t % NativeGather.SLOTS
+        self._t += 1
+        self._native.wait(slot)                     # gather(t-2) is done with send[slot] / recv[slot]
+        self.env.step_autoreset_packed(actions, self._send[slot])
+        self._native.begin(slot, self._send[slot], self._recv[slot])
+        return slot
+
+    def gathered(self, slot: int) -> torch.Tensor:
+        self._native.wait(slot)
+        return self._recv[slot]
+
+    def close(self) -> None:
+        if self._native is not None:
+            torch.cuda.synchronize(self.env.device)
+            self._native.close()
+            self._native = None
+        self.env.close()

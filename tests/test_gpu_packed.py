@@ -1,0 +1,199 @@
+"""GPU tests of the round-2 launch forms of the env step (through the C ABI):
+
+* packed outputs -- the kernel writes one (obs | reward | done) record per agent -- must equal, bit for bit, the plain
+  outputs packed by `sharding.pack_step_outputs` (the three-launch torch pack it replaces);
+* multi-step launches (`cavoid_step_autoreset_n`: the world state stays in registers between steps) must equal the same
+  steps launched one by one, in both instantiations (register prefetch of the next pool record / on-demand gather) and
+  for every wavefront geometry (worlds per wavefront);
+* BASELINE configs[2] at full size on ONE GPU: 8 shard envs of 8192 worlds with world_offset = r*8192 against one
+  65 536-world env, 50 auto-reset steps, concatenated packed buffers bitwise equal -- the workload and the gather layout
+  of the 8-GPU run;
+* the native all-gather (`cavoid_comm_*`, `cavoid_gather_*`) with one rank (a device copy on the communicator's stream),
+  driven through the double-buffered overlap protocol of `ShardedEnv.step_and_gather`.
+
+The oracle comparison of the same arithmetic is in test_gpu_parity.py; these tests pin the new launch forms to the
+single-step plain path that those parity tests cover, plus one direct oracle check of a multi-step packed run."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(W, N, M=None, seed=0, offset=0, **over):
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            self.MAX_NUM_OTHER_AGENTS_OBSERVED = N - 1 if M is None else M
+            EnvConfig.__init__(self)
+    return BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=seed, world_offset=offset, **over)
+
+
+def _acts(T, W, N, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 11, size=(T, W, N))
+    a[rng.random((T, W, N)) < 0.6] = 2                      # mostly straight ahead: goals are reached, worlds restart
+    return torch.from_numpy(a.astype(np.int32)).cuda()
+
+
+@pytest.mark.parametrize("N,M,W,nonl,gen_min", [(4, None, 1000, 0.0, 4), (10, None, 333, 0.3, 2), (7, 3, 129, 0.2, 3), (2, None, 65, 0.0, 2)])
+def test_packed_outputs_equal_plain_outputs(N, M, W, nonl, gen_min):
+    from rl_collision_avoidance_amd.sharding import pack_step_outputs
+    kw = dict(gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
+    a, b = _env(W, N, M, seed=3, **kw), _env(W, N, M, seed=3, **kw)
+    pk = b.new_packed()
+    acts = _acts(60, W, N, 1)
+    a.reset()
+    b.reset_packed(pk)
+    width = a.obs_width
+    assert torch.equal(pk[..., :width], a.obs) and torch.equal(pk[..., width], torch.zeros_like(a.rewards))
+    assert torch.equal(pk[..., width + 1], ((a.get_state()[2].view(W, N) & 0x20) == 0).float())   # absent rows are 'done'
+    for t in range(60):
+        if t % 3 == 2:                                      # plain step (no restart) / auto-reset step alternate
+            o, r, d, g = a.step(acts[t])
+            p, g2 = b.step_packed(acts[t], pk)
+        else:
+            o, r, d, g = a.step_autoreset(acts[t])
+            p, g2 = b.step_autoreset_packed(acts[t], pk)
+        assert torch.equal(p, pack_step_outputs(o, r, d)), t
+        assert torch.equal(g, g2), t
+    assert torch.equal(b.observe_packed(pk)[..., :width], a.observe())
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)
+    assert a.episode.max().item() >= 1
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("N,W,pool,wpw", [
+    (4, 300, 65536, None),     # latency mode: next pool record in registers
+    (4, 300, 0, None),         # in-kernel generator
+    (4, 5000, 500, 16),        # full wavefronts
+    (4, 5000, 500, 1),         # one world per wavefront
+    (10, 257, 300, None),
+    (10, 257, 0, 3),
+    (3, 1000, 7, 5),
+    (16, 130, 64, None),
+])
+def test_multi_step_launch_equals_single_steps(N, W, pool, wpw, monkeypatch):
+    if wpw is not None:
+        monkeypatch.setenv("CAVOID_WPW", str(wpw))
+    T = 48
+    kw = dict(gen_pool_size=pool, gen_min_agents=max(1, N // 2), gen_nonlearning_fraction=0.2)
+    acts = _acts(T, W, N, 5)
+    a = _env(W, N, seed=9, **kw)
+    monkeypatch.delenv("CAVOID_WPW", raising=False)
+    b = _env(W, N, seed=9, **kw)                            # default geometry, single steps
+    a.reset(); b.reset()
+    for lo, n in ((0, 1), (1, 7), (8, 24), (32, 16)):       # chunks of different lengths, incl. n = 1
+        a.step_autoreset_n(acts[lo:lo + n])
+        for t in range(lo, lo + n):
+            b.step_autoreset(acts[t])
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.rewards, b.rewards), (lo, n)
+        assert torch.equal(a.done, b.done) and torch.equal(a.game_over, b.game_over), (lo, n)
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert torch.equal(x, y), (lo, n)
+        assert torch.equal(a.episode, b.episode)
+    assert a.episode.max().item() >= 1
+    a.close(); b.close()
+
+
+def test_multi_step_packed_run_against_the_oracle():
+    """One direct check of the new launch form against the float64 oracle: 40 steps in one launch, packed record."""
+    W, N, T, seed = 512, 4, 40, 21
+    env = _env(W, N, seed=seed)
+    env.reset()
+    pk = env.new_packed()
+    acts = _acts(T, W, N, 2)
+    env.step_autoreset_packed(acts, pk)
+    ocfg, ogen = co.default_cfg(N), co.default_gen(N, N, pool_size=int(env.cfg.gen_pool_size))
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    for t in range(T):
+        oobs, orew, odone, ogo = co.step_autoreset(ocfg, ogen, seed, st, ep, acts[t].cpu().numpy())
+    p = pk.cpu().numpy()
+    width = env.obs_width
+    d = np.abs(p[..., :width] - oobs)
+    d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2 * np.pi))
+    assert d.max() <= 1e-5 and np.abs(p[..., width] - orew).max() <= 1e-5
+    assert np.array_equal(p[..., width + 1].astype(np.uint8), odone) and np.array_equal(env.game_over.cpu().numpy(), ogo)
+    assert np.array_equal(env.get_state()[2].cpu().numpy().view(np.uint32), st.flags)
+    assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep) and ep.max() >= 1
+    env.close()
+
+
+def test_configs2_eight_shards_of_8192_equal_one_65536_world_env():
+    """BASELINE configs[2] on one GPU: the concatenated packed (obs | reward | done) buffers of 8 shard envs equal the
+    unsharded env's, bitwise, over 50 auto-reset steps (global-world-id RNG keying + the gather layout at full size)."""
+    R, Wl, N, steps, seed = 8, 8192, 4, 50, 77
+    W = R * Wl
+    full = _env(W, N, seed=seed)
+    shards = [_env(Wl, N, seed=seed, offset=r * Wl) for r in range(R)]
+    pk_full = full.new_packed()
+    pk = [e.new_packed() for e in shards]
+    full.reset_packed(pk_full)
+    for e, p in zip(shards, pk):
+        e.reset_packed(p)
+    assert torch.equal(torch.cat(pk), pk_full)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(steps):
+        acts = torch.randint(0, 11, (W, N), generator=g, device="cuda", dtype=torch.int32)
+        acts[torch.rand((W, N), generator=g, device="cuda") < 0.6] = 2
+        full.step_autoreset_packed(acts, pk_full)
+        for r, (e, p) in enumerate(zip(shards, pk)):
+            e.step_autoreset_packed(acts[r * Wl:(r + 1) * Wl], p)
+        assert torch.equal(torch.cat(pk), pk_full), t
+        assert torch.equal(torch.cat([e.game_over for e in shards]), full.game_over), t
+    assert torch.equal(torch.cat([e.episode for e in shards]), full.episode) and full.episode.max().item() >= 1
+    # and the same 50 steps again as ONE multi-step launch per env (the bench's launch form)
+    acts = _acts(10, W, N, 3)
+    full.step_autoreset_packed(acts, pk_full)
+    for r, (e, p) in enumerate(zip(shards, pk)):
+        e.step_autoreset_packed(acts[:, r * Wl:(r + 1) * Wl].contiguous(), p)
+    assert torch.equal(torch.cat(pk), pk_full)
+    for e in shards + [full]:
+        e.close()
+
+
+def test_native_gather_single_rank_overlap_protocol():
+    """cavoid_comm_* with one rank: the all-gather degenerates to a device copy on the communicator's own stream; the
+    double-buffered step/gather protocol must hand every step's packed record through unchanged."""
+    from rl_collision_avoidance_amd.sharding import ShardedEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+    W, N, steps, seed = 2048, 4, 30, 13
+    sh = ShardedEnv(W, EnvConfig(), device=torch.device("cuda", 0), seed=seed)
+    ref = _env(W, N, seed=seed)
+    sh.reset(); ref.reset()
+    acts = _acts(steps, W, N, 8)
+    pk = ref.new_packed()
+    prev = None
+    for t in range(steps):
+        slot = sh.step_and_gather(acts[t])
+        ref.step_autoreset_packed(acts[t], pk)
+        if prev is not None:                                  # consume gather t-1 while gather t is in flight
+            assert torch.equal(sh.gathered(prev[0]), prev[1]), t - 1
+        prev = (slot, pk.clone())
+    assert torch.equal(sh.gathered(prev[0]), prev[1])
+    sh.close(); ref.close()
+
+
+def test_comm_rejects_bad_arguments():
+    import ctypes as C
+    from rl_collision_avoidance_amd import _lib
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.cavoid_comm_create(None, 2, 0, 0, C.byref(h)) == -1          # nranks > 1 needs an id
+    assert lib.cavoid_comm_create(None, 1, 1, 0, C.byref(h)) == -1          # rank out of range
+    assert lib.cavoid_comm_create(None, 1, 0, 0, C.byref(h)) == 0
+    buf = torch.zeros(16, device="cuda")
+    assert lib.cavoid_gather_begin(h, 2, C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), 16, None) == -1   # slot
+    assert lib.cavoid_gather_wait(h, 0, None) == 0
+    lib.cavoid_comm_destroy(h)

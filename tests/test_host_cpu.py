@@ -24,8 +24,7 @@ def test_library_exports_every_declared_symbol():
     handle = _lib.lib()
     for name in declared:
         assert hasattr(handle, name)
-    assert handle.cavoid_abi_version() == 1
-    assert C.sizeof(_lib.CavoidCfg) == 712
+    assert handle.cavoid_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_error_codes_without_gpu():
@@ -162,10 +161,13 @@ def test_header_is_plain_c(tmp_path):
     if gcc is None:
         pytest.skip("no gcc")
     src = tmp_path / "hdr.c"
-    src.write_text('#include "cavoid.h"\nint main(void) { cavoid_cfg c; cavoid_policy_weights w; cavoid_policy_train_buffers b;\n'
-                   '  (void)c; (void)w; (void)b; return (int)sizeof(cavoid_cfg) == 712 ? 0 : 1; }\n')
+    src.write_text('#include <stdio.h>\n#include "cavoid.h"\nint main(void) { cavoid_cfg c; cavoid_policy_weights w; cavoid_policy_train_buffers b;\n'
+                   '  (void)c; (void)w; (void)b; printf("%d %d %d\\n", (int)sizeof(c), (int)sizeof(w), (int)sizeof(b)); return 0; }\n')
     exe = tmp_path / "hdr"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                            str(src), "-o", str(exe)])
-    assert subprocess.call([str(exe)]) == 0
+    from rl_collision_avoidance_amd import _lib
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    # the ctypes mirrors of the binding must have the C compiler's layout
+    assert sizes == [C.sizeof(_lib.CavoidCfg), C.sizeof(_lib.CavoidPolicyWeights), C.sizeof(_lib.CavoidPolicyTrainBuffers)]

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--plain", action="store_true", help="also launch 60 plain (no auto-reset) steps per size")
     ap.add_argument("--gen-min", type=int, default=None)
+    ap.add_argument("--spl", type=int, nargs="+", default=[1, 32], help="steps per launch")
     args = ap.parse_args()
     import torch
     from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
@@ -35,16 +36,17 @@ def main():
         env.reset()
         env.step_autoreset_n(acts)
         env.step_autoreset_n(acts)
-        ms = env.kernel_time_ms(acts, args.steps)
-        rec = {"W": W, "N": N, "kernel_us": round(ms * 1e3, 3), "Gagent_steps_s": round(W * N / ms / 1e6, 3),
-               "GBps": round(bytes_as * W * N / ms / 1e6, 1)}
+        for spl in args.spl:
+            ms = env.kernel_time_ms(acts, args.steps, spl) / min(spl, 32)
+            rec = {"W": W, "N": N, "spl": spl, "us_per_step": round(ms * 1e3, 3), "Gagent_steps_s": round(W * N / ms / 1e6, 3),
+                   "GBps": round(bytes_as * W * N / ms / 1e6, 1), "wpw": os.environ.get("CAVOID_WPW", "auto")}
+            out.append(rec)
+            print(json.dumps(rec), flush=True)
         if args.plain:
             env.reset()
             for t in range(60):
                 env.step(acts[t % 32])
             torch.cuda.synchronize()
-        out.append(rec)
-        print(json.dumps(rec), flush=True)
         env.close()
 
 
