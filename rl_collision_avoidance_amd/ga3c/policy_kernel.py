@@ -176,8 +176,12 @@ class FusedA3CTrainer(object):
         net, pol = self.net, self.policy
         n = int(x.shape[0])
         if n == 0:
-            return torch.as_tensor(self._base.train(x, y_r, a if a.dim() == 2 else
+            # (multi-GPU padding step: this rank has no rows, but the all-reduced gradients of the others still move its
+            #  parameters -- the packed MFMA weights must follow, or this replica's actors keep acting on stale weights)
+            loss = torch.as_tensor(self._base.train(x, y_r, a if a.dim() == 2 else
                                                     torch.nn.functional.one_hot(a.long(), net.num_actions).float()), device=self.device)
+            pol.refresh(with_backward=True)
+            return loss
         x = x.to(torch.float32).contiguous()
         y_r = y_r.to(torch.float32).contiguous()
         a_idx = (a.argmax(dim=1) if a.dim() == 2 else a).to(torch.int32).contiguous()

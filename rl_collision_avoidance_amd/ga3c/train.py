@@ -58,6 +58,9 @@ def main(argv=None) -> None:
     ap.add_argument("--min-agents", type=int, default=2)
     ap.add_argument("--episodes", type=int, default=20000, help="stop after this many finished episodes (all ranks)")
     ap.add_argument("--steps-per-graph", type=int, default=4)
+    ap.add_argument("--scenario-pool", type=int, default=0,
+                    help="0 (default): every episode runs the scenario generator; > 0: episodes gather from a pool of that many "
+                         "pre-generated scenarios (benchmark aid, NOT the reference's distribution of fresh random test cases)")
     ap.add_argument("--train-rows", type=int, default=32768,
                     help="rows per Adam step: every drained row is trained on exactly once, in minibatches of this size")
     ap.add_argument("--torch-policy", action="store_true",
@@ -110,8 +113,11 @@ def main(argv=None) -> None:
             EnvConfig.__init__(self)
     cfg = Cfg()
     offset, count = shard_range(args.worlds, rank, size)
+    # training draws a FRESH scenario for every episode (in-kernel generator, gen_pool_size = 0): the 65 536-entry scenario
+    # pool is a latency aid for benchmarks and would make a 20k..2M-episode run revisit a fixed scenario set
     env = BatchedCollisionAvoidanceEnv(count, cfg, device=device, world_offset=offset, seed=1000 * args.seed,
-                                       gen_min_agents=min(args.min_agents, N), evaluate_mode=1 if args.evaluate else 0)
+                                       gen_min_agents=min(args.min_agents, N), evaluate_mode=1 if args.evaluate else 0,
+                                       gen_pool_size=args.scenario_pool)
     net = NetworkVP_rnn(cfg, seed=args.seed).to(device)
     fused = None if (args.torch_policy or net.arch != "rnn") else FusedPolicy(net, seed=1000 * args.seed + rank)
     if args.autograd_trainer or net.arch != "rnn":
@@ -144,8 +150,15 @@ def main(argv=None) -> None:
     steps_before = trainer.training_step
     if fused is not None:
         fused.refresh(with_backward=isinstance(trainer, FusedA3CTrainer))      # weights may have come from a checkpoint
+    if args.steps_per_graph < 2 or args.steps_per_graph % 2:
+        raise SystemExit("--steps-per-graph must be an even number >= 2")
+    # the experience ring must hold every block from 'final' (older than TIME_MAX + 2 steps) back to the last drain, i.e.
+    # one replay of steps_per_graph steps, plus slack; the re-flush quirk can emit up to one duplicate per slot and step
+    time_max = int(getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
+    ring_len = (time_max + 2) + args.steps_per_graph + 8
     roll = BatchedRollout(env, fused if fused is not None else net.predict_p_and_v, reflush_done=args.faithful_reflush,
-                          greedy=args.play)
+                          greedy=args.play, ring_len=max(ring_len, 2 * (time_max + 2) + 8),
+                          dup_capacity=(count * N * (args.steps_per_graph + 1) + 1024) if args.faithful_reflush else None)
     stats = EpisodeStats(print_every=args.print_every if rank == 0 else 0, agents=count)
     anneal_over = args.annealing_episodes or args.episodes
     next_save = episodes_before + args.save_every
@@ -156,11 +169,15 @@ def main(argv=None) -> None:
     t0 = time.time()
     while True:
         # linear annealing of the learning rate and the entropy weight over the episode count (Server.py:139-147)
-        frac = min(finished, anneal_over - 1) / float(anneal_over)
+        # (a resumed run continues where the checkpoint stopped: Server.py sets episode_count to the loaded episode)
+        frac = min(episodes_before + finished, anneal_over - 1) / float(anneal_over)
         trainer.opt.param_groups[0]["lr"] = args.lr + ((args.lr_end if args.lr_end is not None else args.lr) - args.lr) * frac
         net.beta = args.beta + ((args.beta_end if args.beta_end is not None else args.beta) - args.beta) * frac
         roll.replay(1)
         batch = roll.drain(provenance=False)
+        if roll.lost_blocks or batch.dropped:      # never train on a silently thinned stream
+            raise RuntimeError("rollout lost training rows (%d ring blocks overwritten, %d duplicate rows dropped): "
+                               "raise ring_len / dup_capacity or lower --steps-per-graph" % (roll.lost_blocks, batch.dropped))
         # multi-GPU: every rank must enter the same number of gradient all-reduces
         n_chunks = max(1, -(-len(batch) // args.train_rows)) if (len(batch) > 0 or size > 1) else 0
         if args.play:
@@ -186,7 +203,7 @@ def main(argv=None) -> None:
         if args.checkpoint_dir and rank == 0 and not args.play and episodes_before + finished >= next_save:
             save_checkpoint(args.checkpoint_dir, episodes_before + finished, net, trainer)      # Server.save_model (:126-127)
             next_save += args.save_every
-        if finished >= args.episodes:
+        if episodes_before + finished >= args.episodes:      # EPISODES counts from the loaded checkpoint on (Server.py:135-147)
             break
     if args.checkpoint_dir and rank == 0 and not args.play:
         save_checkpoint(args.checkpoint_dir, episodes_before + finished, net, trainer)

@@ -33,8 +33,8 @@ def main():
         acts = rng.integers(0, 11, size=(steps, W, N)).astype(np.int32)
         acts[rng.random((steps, W, N)) < 0.7] = 2
         init = [po.world_to_arrays(wd) for wd in worlds]
-        obs = np.zeros((steps, W, N, cfg.obs_width), np.float32)
-        rew = np.zeros((steps, W, N), np.float32)
+        obs = np.zeros((steps, W, N, cfg.obs_width), np.float64)        # float64: the oracle's own precision (no storage rounding)
+        rew = np.zeros((steps, W, N), np.float64)
         done = np.ones((steps, W, N), np.uint8)
         over = np.zeros((steps, W), np.uint8)
         flags = np.zeros((steps, W, N), np.uint32)

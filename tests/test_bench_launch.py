@@ -1,0 +1,46 @@
+"""bench.py's N>1 plumbing: `python bench.py --gpus N` with no launcher around it starts its own ranks
+(torch.distributed.run on 127.0.0.1), they rendezvous, barrier and MAX-reduce, rank 0 prints ONE JSON line.
+CPU box: the GPU-free `--rendezvous-only` form over gloo.  GPU box: a 2-rank dry run of the real bench on ONE device
+(`--backend gloo --share-device`), including the configs[2] gather extra."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, BENCH] + args, env=env, cwd=ROOT, timeout=timeout, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]            # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_and_they_rendezvous():
+    line = _run(["--gpus", "2", "--backend", "gloo", "--rendezvous-only"], 300)
+    assert line == {"rendezvous": "ok", "n_gpus": 2, "backend": "gloo"}
+
+
+def test_bench_refuses_a_mismatched_launcher_environment():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], env=env, cwd=ROOT, timeout=120,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_dry_run_on_one_device():
+    line = _run(["--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "40", "--warmup", "8", "--worlds", "2048",
+                 "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc"], 900)
+    assert line["n_gpus"] == 2 and line["steps"] == 40 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 2 * 2048 * 4 * 40 / (line["ms_per_step"] * 40e-3)) / line["value"] < 1e-6
+    assert "error" not in line["extra"]["allgather"], line["extra"]["allgather"]
+    assert line["extra"]["allgather"]["bytes_received_per_rank"] == 2 * 2048 * 4 * 29 * 4
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"]

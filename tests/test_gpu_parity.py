@@ -194,9 +194,10 @@ def test_continuous_actions_parity(dyn):
 
 
 def test_u_switches_follow_the_oracle():
-    """close-penalty sign (U5), float64 action array, timeout off (U1): flipped on both sides."""
+    """close-penalty sign (U5), float64 action array, timeout off (U1), time budget from the goal centre (U11):
+    flipped on both sides."""
     W, N, steps, seed = 300, 4, 120, 8
-    over = dict(close_penalty_slope=0.5, actions_fp32=0, timeout_enabled=0)
+    over = dict(close_penalty_slope=0.5, actions_fp32=0, timeout_enabled=0, time_budget_from_goal_edge=0)
     ocfg, ogen = _oracle(N, **over)
     env = _env(W, N, seed=seed, **over)
     st = co.State.empty(W, N)
@@ -358,7 +359,7 @@ def test_hip_path_reproduces_committed_env_golden():
             assert np.array_equal(_pull(env)[2].reshape(W, N), g[name + "_flags"][t]), (name, t)
             d = np.abs(obs.astype(np.float64) - g[name + "_obs"][t])
             d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2 * np.pi))
-            assert d.max() <= OBS_TOL + 2e-6, (name, t, d.max())          # + float32 storage of the fixture
+            assert g[name + "_obs"].dtype == np.float64 and d.max() <= OBS_TOL, (name, t, d.max())
             assert np.abs(rew - g[name + "_rew"][t]).max() <= OBS_TOL
         env.close()
 

@@ -144,6 +144,33 @@ def test_timeout():
     assert all(ag.ran_out_of_time and not ag.is_at_goal for ag in w.agents)
 
 
+def test_time_budget_switch_u11():
+    """U11: MAX_TIME_RATIO * (dist - NEAR_GOAL_THRESHOLD) / pref_speed (default, upstream agent.py as recalled) against
+    SURVEY App. A's MAX_TIME_RATIO * dist / pref_speed; never below one DT; Python and C statements agree bitwise."""
+    for edge, budget, steps in ((True, 2.0 * (5.05 - 0.2), 49), (False, 2.0 * 5.05, 51)):
+        cfg = po.OracleConfig(max_agents=2, max_other_agents_observed=1, time_budget_from_goal_edge=edge)
+        a = po.Agent(0.0, 0.0, 5.05, 0.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+        b = po.Agent(0.0, 50.0, 5.05, 50.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+        assert a.t_remaining == pytest.approx(budget, abs=1e-12)
+        w = po.World([a, b], cfg)
+        for k in range(1, 200):
+            if w.step({0: 9, 1: 9})[2]:
+                break
+        assert k == steps == math.ceil(budget / 0.2)
+        near = po.Agent(0.0, 0.0, 0.21, 0.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+        assert near.t_remaining == (0.2 if edge else pytest.approx(0.42))          # floor of one DT
+        # generated worlds: the C statement makes the same choice, bit for bit
+        ccfg = co.default_cfg(4, time_budget_from_goal_edge=int(edge))
+        gen = po.GenConfig(min_agents=2, max_agents=4)
+        cgen = co.default_gen(2, 4)
+        st = co.State.empty(50, 4)
+        co.generate(ccfg, cgen, 77, st, np.zeros(50, np.uint32))
+        pcfg = po.OracleConfig(time_budget_from_goal_edge=edge)
+        for wd in range(50):
+            f64, _, _ = po.world_to_arrays(po.generate_world(77, wd, 0, pcfg, gen))
+            assert np.array_equal(f64[3], st.f64[3, 4 * wd:4 * wd + 4])
+
+
 def test_obs_layout_and_sorting():
     cfg = po.OracleConfig(max_agents=4, max_other_agents_observed=3)
     host = po.Agent(0.0, 0.0, 10.0, 0.0, 0.5, 1.0, None, po.POLICY_EXTERNAL, cfg)
@@ -199,8 +226,8 @@ def test_worlds_are_independent_and_permutation_equivariant():
 
 def test_c_oracle_reproduces_committed_env_golden():
     """tests/golden/env_golden.npz was generated by the reference-STYLE Python oracle (parity unpinned: it is a
-    regression anchor, not a reference output).  The C oracle must reproduce it (obs/rewards are stored as
-    float32, flags exactly)."""
+    regression anchor, not a reference output).  The C oracle must reproduce it: observations and rewards are
+    stored in float64 and compared EXACTLY (the two statements are the same arithmetic), flags bit for bit."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "env_golden.npz"))
     for name in g["cases"]:
@@ -209,7 +236,7 @@ def test_c_oracle_reproduces_committed_env_golden():
         st = co.State(g[name + "_f64"].copy(), g[name + "_f32"].copy(), g[name + "_flags0"].copy())
         for t in range(steps):
             obs, rew, done, go = co.step(cfg, st, g[name + "_actions"][t])
-            assert np.array_equal(obs.astype(np.float32), g[name + "_obs"][t]), (name, t)
-            assert np.array_equal(rew.astype(np.float32), g[name + "_rew"][t]), (name, t)
+            assert g[name + "_obs"].dtype == np.float64 and np.array_equal(obs, g[name + "_obs"][t]), (name, t)
+            assert np.array_equal(rew, g[name + "_rew"][t]), (name, t)
             assert np.array_equal(done, g[name + "_done"][t]) and np.array_equal(go, g[name + "_over"][t])
             assert np.array_equal(st.flags.reshape(W, N), g[name + "_flags"][t])
