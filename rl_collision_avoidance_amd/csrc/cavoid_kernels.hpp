@@ -96,9 +96,16 @@ struct KIO {
     int32_t packed;          // != 0: reward and done (as 0.0f / 1.0f) are columns width, width+1 of the agent's row
 };
 
+// wrap to [-pi, pi) by repeated +-2*pi, exactly the oracle's `while` loops: one branch-free fold each way covers every
+// table action (|heading + delta| < 3*pi); anything still outside (huge continuous actions) takes the loops, as a
+// wave-uniform branch.  A fold that does not apply leaves the value untouched, so the results are bit-identical.
 __device__ __forceinline__ double wrap_angle(double a) {
-    while (a >= kPi) a -= 2.0 * kPi;
-    while (a < -kPi) a += 2.0 * kPi;
+    a = a >= kPi ? a - 2.0 * kPi : a;
+    a = a < -kPi ? a + 2.0 * kPi : a;
+    if (__ballot(a >= kPi || a < -kPi) != 0ull) {
+        while (a >= kPi) a -= 2.0 * kPi;
+        while (a < -kPi) a += 2.0 * kPi;
+    }
     return a;
 }
 
@@ -272,22 +279,37 @@ __device__ __forceinline__ int other_index(int i, int o, int n) {
     return j >= n ? j - n : j;
 }
 
+// float32 -> uint32 whose unsigned order is the float order (-0 canonicalised to +0 first)
+__device__ __forceinline__ uint32_t orderable(float f) {
+    const uint32_t u = __float_as_uint(f + 0.0f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// Sort key of one neighbour, 63 bits: hi = 2^30 - bucket (far -> near is ASCENDING in hi), lo = the orderable float32
+// lateral offset.  bucket = rint(gap*100) (order-isomorphic to round(gap, 2)); |gap| < 1e7 m keeps hi in [1, 2^31).
+// A neighbour that is absent or beyond the sensing horizon gets a sentinel above every real key (and distinct per
+// slot), so the ranking needs no validity masks: sentinels simply sort last.
+struct Key { uint32_t hi, lo; };
+constexpr uint32_t kKeyBias = 1u << 30;
+__device__ __forceinline__ int key_bucket(const Key &k) { return (int)(kKeyBias - k.hi); }
+
 // E6: centre distances to the other agents of the lane's world (from the LDS-staged positions), the
 // collision test and the nearest gap.  All 64 lanes call this together.  What E9 needs later is kept
-// in its cheapest form -- the gap as the float32 that goes into the observation, its centimetre bucket
-// as an int32 sort key, and one "within the sensing horizon" bit -- not the float64 distance (the
-// register budget decides how many wavefronts a SIMD holds, and with it how much memory latency hides).
+// in its cheapest form -- the gap as the float32 that goes into the observation and one 63-bit sort key
+// per neighbour (its centimetre bucket and the float32 rounding of the lateral offset ry*tx - rx*ty, the
+// tie-break inside a bucket) -- not the float64 values (the register budget decides how many wavefronts a
+// SIMD holds, and with it how much memory latency hides).  float32 rounding is monotonic, so two DIFFERENT
+// float32 laterals order exactly as the float64 ones do; equal keys fall back to the exact comparison.
 template <int N>
-__device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, bool present, int i, int base,
+__device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
                                           const double *lds_px, const double *lds_py, const float *lds_r,
-                                          int (&gr)[Others<N>::K], float (&gapf)[Others<N>::K], uint32_t &others, uint32_t &near,
-                                          bool &hit, double &min_gap) {
+                                          Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K],
+                                          uint32_t &valid, bool &hit, double &min_gap) {
     const double ri = (double)a.radius;
-    others = 0u;
-    near = 0u;
+    valid = 0u;
     hit = false;
     min_gap = INFINITY;
-    gr[0] = 0; gapf[0] = 0.0f;
+    key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f;
 #pragma unroll
     for (int o = 0; o < N - 1; ++o) {
         const int j = base + other_index(i, o, N);
@@ -299,13 +321,14 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, bool pr
         const double gap_c = d - (ri + (double)rjf);
         min_gap = other ? fmin(min_gap, gap_c) : min_gap;
         hit = hit || (other && gap_c <= c.collision_dist);
-        others |= other ? (1u << o) : 0u;
-        near |= !(d > c.horizon) ? (1u << o) : 0u;
+        const bool seen = other && !(d > c.horizon);
+        valid |= seen ? (1u << o) : 0u;
         // the observation's gap, host-side association (d - r_host) - r_other; rint(gap*100) is
-        // order-isomorphic to round(gap, 2) and integer-valued: exact in int32 (|gap| < 2e7 m)
+        // order-isomorphic to round(gap, 2) and integer-valued: exact in int32 (|gap| < 1e7 m)
         const double gap_o = d - ri - (double)rjf;
-        gr[o] = (int)rint(gap_o * 100.0);
         gapf[o] = (float)gap_o;
+        key[o].hi = seen ? kKeyBias - (uint32_t)(int)rint(gap_o * 100.0) : 0x7FFFFFFFu;
+        key[o].lo = seen ? orderable((float)(ry * e.tx - rx * e.ty)) : (uint32_t)o;
     }
 }
 
@@ -333,25 +356,105 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
     }
 }
 
+// Ranking by a round-robin tournament in integer arithmetic.  For every unordered pair (p, q), p < q, one bit says
+// "p comes first" (the borrow of the 64-bit difference of their keys); the position of a neighbour in the order is the
+// number of pairs it lost.  No wave masks are produced (a comparison per pair would park 2 x N(N-1)/2 of them in scalar
+// registers) and no branch is taken; `tie` comes back true when two keys were EQUAL (then the caller ranks the exact way).
+template <int NO>
+struct Tournament {
+    static constexpr int kPairs = NO * (NO - 1) / 2;
+    uint32_t t[(kPairs + 31) / 32 > 0 ? (kPairs + 31) / 32 : 1];
+    template <bool ASC_BUCKET, int KK>
+    __device__ __forceinline__ bool play(const Key (&key)[KK]) {
+#pragma unroll
+        for (int w = 0; w < (int)(sizeof(t) / sizeof(t[0])); ++w) t[w] = 0u;
+        uint32_t differ = 0xFFFFFFFFu;
+        int k = 0;
+#pragma unroll
+        for (int p = 0; p < NO; ++p)
+#pragma unroll
+            for (int q = p + 1; q < NO; ++q, ++k) {
+                // near -> far order (closest_first) flips the bucket half of the key; sentinels stay on top
+                const uint64_t kp = ((uint64_t)(ASC_BUCKET ? ((key[p].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[p].hi) : key[p].hi) << 32) | key[p].lo;
+                const uint64_t kq = ((uint64_t)(ASC_BUCKET ? ((key[q].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[q].hi) : key[q].hi) << 32) | key[q].lo;
+                const uint64_t d = kp - kq;                              // both < 2^63: bit 63 of d <=> kp < kq
+                t[k >> 5] |= (uint32_t)(d >> 63) << (k & 31);
+                const uint32_t nz = (uint32_t)d | (uint32_t)(d >> 32);
+                differ = nz < differ ? nz : differ;
+            }
+        return differ == 0u;
+    }
+    // number of neighbours that come before o
+    __device__ __forceinline__ int position(int o) const {
+        int lost = 0, k = 0;
+#pragma unroll
+        for (int p = 0; p < NO; ++p)
+#pragma unroll
+            for (int q = p + 1; q < NO; ++q, ++k) {
+                const uint32_t bit = (t[k >> 5] >> (k & 31)) & 1u;
+                if (q == o) lost += (int)bit;                            // p came first
+                if (p == o) lost += (int)(bit ^ 1u);                     // q came first
+            }
+        return lost;
+    }
+};
+
+// slot numbers of the (up to 15) others of a lane, 4 bits each, in two registers instead of N-1
+struct Slots {
+    uint64_t v;
+    __device__ __forceinline__ void clear() { v = 0ull; }
+    __device__ __forceinline__ void set(int o, int slot) { v |= (uint64_t)(uint32_t)slot << (4 * o); }
+    __device__ __forceinline__ int get(int o) const { return (int)((v >> (4 * o)) & 15ull); }
+};
+static_assert(CAVOID_MAX_AGENTS - 1 <= 15, "a slot number must fit 4 bits");
+
+// the same for a compile-time float count (the common shape: a full wavefront of rows of the default width): every
+// round but the last is unpredicated
+template <int NF>
+__device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, int lane) {
+    static_assert(NF % 4 == 0, "whole float4s");
+    constexpr int n4 = NF / 4, rounds = (n4 + 63) / 64;
+    const float4 *src4 = reinterpret_cast<const float4 *>(tile);
+    float4 *dst4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+    for (int r0 = 0; r0 < rounds; r0 += 8) {                   // 8 LDS reads in flight, then 8 stores
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            if (r < rounds) {
+                const int k = lane + 64 * r;
+                v[u] = ((r + 1) * 64 <= n4 || k < n4) ? src4[k] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            if (r < rounds) {
+                const int k = lane + 64 * r;
+                if ((r + 1) * 64 <= n4 || k < n4) dst4[k] = v[u];
+            }
+        }
+    }
+}
+
 // E9: neighbour ordering by counting ranks, the lane's observation row into the LDS tile, and the
 // coalesced write-out.  The tile holds c.tile_rows rows; wide rows (large N) go out in several passes so
 // that the LDS footprint -- and with it the wavefronts resident per CU -- does not scale with N*(1+D).
 template <int N>
 __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
-                                             const double *lds_vy, const float *lds_r, const int (&gr)[Others<N>::K],
-                                             const float (&gapf)[Others<N>::K], uint32_t others, uint32_t near, float *tile,
-                                             float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f) {
+                                             const double *lds_vy, const float *lds_r, const Key (&key)[Others<N>::K],
+                                             const float (&gapf)[Others<N>::K], uint32_t valid, float *tile,
+                                             float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave) {
     constexpr int K = Others<N>::K, NO = N - 1;
     const int M = c.max_other, width = c.width;
     const bool present = active && (a.flags & CAVOID_F_PRESENT);
     const double ri = (double)a.radius;
-    // sort criteria: gap rounded to centimetres (gr, from the pair pass), then the lateral offset; its
-    // sign-preserving un-normalised form ry*tx - rx*ty orders the same; full ties fall back to the agent
-    // index (what a stable sort does).  The lateral key matters only between two neighbours in the same
-    // centimetre bucket, so it is computed on demand (wave-uniform branch) instead of living in 2*(N-1)
-    // registers.
-    const uint32_t valid = others & near;
+    // sort criteria: gap rounded to centimetres, then the lateral offset (its sign-preserving un-normalised form
+    // ry*tx - rx*ty orders the same), then the agent index (what a stable sort does).  Fast path: the integer
+    // tournament over the 63-bit keys of the pair pass.  Two neighbours with EQUAL keys (same bucket, same float32
+    // lateral) need the exact float64 laterals and the index rule: the generic path below (wave-uniform branch).
     // index tie-break without an index array: others run in ring order j = (i+1+o) mod N, so for p < q
     // j_p < j_q unless the wrap (at o = N-1-i) falls between them
     const int wrap_o = N - 1 - i;
@@ -373,57 +476,95 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     const int m = __popc(valid);
     const int first = m > M ? m - M : 0;
     const int kept = m - first;
-    int pos[K];
-#pragma unroll
-    for (int o = 0; o < K; ++o) pos[o] = 0;
-    if (c.sort_method == CAVOID_SORT_TIME_TO_IMPACT) {
-        double tti[K];
-        tti[0] = 0.0;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int j = base + other_index(i, o, N);
-            tti[o] = time_to_impact(lds_px[j] - a.px, lds_py[j] - a.py, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + (double)lds_r[j]);
-        }
-#pragma unroll
-        for (int p = 0; p < NO; ++p)           // far -> near: larger time first, then larger gap, then smaller lateral
-#pragma unroll
-            for (int q = p + 1; q < NO; ++q) {
-                const bool tied = tti[p] == tti[q] && gr[p] == gr[q] && ((valid >> p) & (valid >> q) & 1u);
-                const bool p_first = (tti[p] > tti[q]) || (tti[p] == tti[q] && gr[p] > gr[q]) || (tied && tie_first(p, q, tied));
-                pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
-                pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
-            }
-    } else {
-#pragma unroll
-        for (int p = 0; p < NO; ++p)           // far -> near: larger gap first, then smaller lateral, then index
-#pragma unroll
-            for (int q = p + 1; q < NO; ++q) {
-                const bool tied = gr[p] == gr[q] && ((valid >> p) & (valid >> q) & 1u);
-                const bool p_first = (gr[p] > gr[q]) || (tied && tie_first(p, q, tied));
-                pos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
-                pos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
-            }
-    }
+    Slots pos;
+    pos.clear();
     uint32_t keep = 0u;
+    bool generic = c.sort_method == CAVOID_SORT_TIME_TO_IMPACT;
+    if (!generic) {
+        Tournament<NO> tour;                                   // far -> near: larger bucket first, then smaller lateral
+        const bool tie = tour.template play<false>(key);
+        generic = __ballot(tie) != 0ull;                        // wave-uniform: redo this tile's ranks the exact way
+        if (!generic) {
 #pragma unroll
-    for (int o = 0; o < K; ++o) {
-        keep |= (((valid >> o) & 1u) && pos[o] >= first) ? (1u << o) : 0u;
-        pos[o] -= first;                                         // pos now IS the slot (closest_last / time_to_impact)
+            for (int o = 0; o < NO; ++o) pos.set(o, tour.position(o));
+        }
     }
-    if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {      // kept set re-ranked near -> far; full ties keep index order
+    if (generic) {
+        int gpos[K];
 #pragma unroll
-        for (int o = 0; o < K; ++o) pos[o] = 0;
+        for (int o = 0; o < K; ++o) gpos[o] = 0;
+        if (c.sort_method == CAVOID_SORT_TIME_TO_IMPACT) {
+            double tti[K];
+            tti[0] = 0.0;
 #pragma unroll
-        for (int p = 0; p < NO; ++p)
-#pragma unroll
-            for (int q = p + 1; q < NO; ++q) {
-                const bool tied = gr[p] == gr[q] && ((keep >> p) & (keep >> q) & 1u);
-                const bool p_first = (gr[p] < gr[q]) || (tied && tie_first(p, q, tied));
-                pos[q] += (p_first && ((keep >> p) & 1u)) ? 1 : 0;
-                pos[p] += (!p_first && ((keep >> q) & 1u)) ? 1 : 0;
+            for (int o = 0; o < NO; ++o) {
+                const int j = base + other_index(i, o, N);
+                tti[o] = time_to_impact(lds_px[j] - a.px, lds_py[j] - a.py, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + (double)lds_r[j]);
             }
+#pragma unroll
+            for (int p = 0; p < NO; ++p)           // far -> near: larger time first, then larger gap, then smaller lateral
+#pragma unroll
+                for (int q = p + 1; q < NO; ++q) {
+                    const int gp = key_bucket(key[p]), gq = key_bucket(key[q]);
+                    const bool tied = tti[p] == tti[q] && gp == gq && ((valid >> p) & (valid >> q) & 1u);
+                    const bool p_first = (tti[p] > tti[q]) || (tti[p] == tti[q] && gp > gq) || (tied && tie_first(p, q, tied));
+                    gpos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
+                    gpos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
+                }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NO; ++p)           // far -> near: larger gap first, then smaller lateral, then index
+#pragma unroll
+                for (int q = p + 1; q < NO; ++q) {
+                    const int gp = key_bucket(key[p]), gq = key_bucket(key[q]);
+                    const bool tied = gp == gq && ((valid >> p) & (valid >> q) & 1u);
+                    const bool p_first = (gp > gq) || (tied && tie_first(p, q, tied));
+                    gpos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
+                    gpos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
+                }
+        }
+        pos.clear();
+#pragma unroll
+        for (int o = 0; o < NO; ++o) pos.set(o, gpos[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) keep |= (((valid >> o) & 1u) && pos.get(o) >= first) ? (1u << o) : 0u;
+    // pos - first IS the slot (closest_last / time_to_impact); subtracted at the use
+    int slot_bias = first;
+    if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {      // kept set re-ranked near -> far; full ties keep index order
+        slot_bias = 0;
+        Key k2[K];
+#pragma unroll
+        for (int o = 0; o < K; ++o) {                          // neighbours that were clipped away become sentinels
+            k2[o].hi = ((keep >> o) & 1u) ? key[o].hi : 0x7FFFFFFFu;
+            k2[o].lo = ((keep >> o) & 1u) ? key[o].lo : (uint32_t)o;
+        }
+        Tournament<NO> tour;
+        const bool tie = tour.template play<true>(k2);
+        pos.clear();
+        if (__ballot(tie) == 0ull) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) pos.set(o, tour.position(o));
+        } else {
+            int gpos[K];
+#pragma unroll
+            for (int o = 0; o < K; ++o) gpos[o] = 0;
+#pragma unroll
+            for (int p = 0; p < NO; ++p)
+#pragma unroll
+                for (int q = p + 1; q < NO; ++q) {
+                    const int gp = key_bucket(key[p]), gq = key_bucket(key[q]);
+                    const bool tied = gp == gq && ((keep >> p) & (keep >> q) & 1u);
+                    const bool p_first = (gp < gq) || (tied && tie_first(p, q, tied));
+                    gpos[q] += (p_first && ((keep >> p) & 1u)) ? 1 : 0;
+                    gpos[p] += (!p_first && ((keep >> q) & 1u)) ? 1 : 0;
+                }
+#pragma unroll
+            for (int o = 0; o < NO; ++o) pos.set(o, gpos[o]);
+        }
     }
 
+    CAVOID_STAMP(9);                                             // ranks done
     const int rpp = c.tile_rows;                                 // rows per pass
     for (int p0 = 0; p0 < rows_active; p0 += rpp) {
     if (active && lane >= p0 && lane < p0 + rpp) {
@@ -441,7 +582,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
             const double rj = (double)lds_r[j];
             const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
             const double ovx = lds_vx[j], ovy = lds_vy[j];
-            float *f = row + 6 + 7 * pos[o];
+            float *f = row + 6 + 7 * (pos.get(o) - slot_bias);
             f[0] = (float)(rx * e.prll_x + ry * e.prll_y);
             f[1] = (float)(ry * e.prll_x - rx * e.prll_y);
             f[2] = (float)(ovx * e.prll_x + ovy * e.prll_y);
@@ -454,8 +595,17 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         if (packed) { row[width] = rew_f; row[width + 1] = done_f; }   // (obs | reward | done) gather record
     }
     wave_lds_sync();
+    CAVOID_STAMP(10);                                            // rows in the LDS tile
     const int rows_here = rows_active - p0 < rpp ? rows_active - p0 : rpp;
-    flush_tile(tile, obs_dst + (int64_t)p0 * ostride, rows_here * ostride, lane);
+    {
+        constexpr int kRows = (64 / N) * N, kW = 6 + 7 * (N - 1);   // a full wavefront, the default row widths
+        constexpr bool kPlainOk = (kRows * kW) % 4 == 0, kPackedOk = (kRows * (kW + 2)) % 4 == 0;
+        float *dst = obs_dst + (int64_t)p0 * ostride;
+        const bool whole = rows_here == kRows && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+        if (kPlainOk && whole && ostride == kW) flush_tile_fixed<kPlainOk ? kRows * kW : 4>(tile, dst, lane);
+        else if (kPackedOk && whole && ostride == kW + 2) flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4>(tile, dst, lane);
+        else flush_tile(tile, dst, rows_here * ostride, lane);
+    }
     if (p0 + rpp < rows_active) wave_lds_sync();                 // the next pass overwrites the tile
     }
 }
@@ -506,6 +656,9 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, 
 
 enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESET = 3, MODE_STEP_AUTORESET_PF = 4, MODE_STEP_AUTORESET_N = 5 };
 
+#ifndef CAVOID_OCC_LARGE_N
+#define CAVOID_OCC_LARGE_N 2
+#endif
 #ifndef CAVOID_OCC4_MAX_N
 #define CAVOID_OCC4_MAX_N 4
 #endif
@@ -521,7 +674,7 @@ enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESE
 template <int N, int MODE>
 // (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
 //  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
-__global__ void __launch_bounds__(256, (MODE == MODE_STEP_AUTORESET_PF ? 2 : (N <= CAVOID_OCC4_MAX_N ? 4 : 1)))
+__global__ void __launch_bounds__(256, (MODE == MODE_STEP_AUTORESET_PF ? 2 : (N <= CAVOID_OCC4_MAX_N ? 4 : CAVOID_OCC_LARGE_N)))
 env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     constexpr bool kAuto = MODE == MODE_STEP_AUTORESET || MODE == MODE_STEP_AUTORESET_PF || MODE == MODE_STEP_AUTORESET_N;
     constexpr bool kLoop = MODE == MODE_STEP_AUTORESET_PF || MODE == MODE_STEP_AUTORESET_N;
@@ -634,6 +787,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     int lane = lane0, i = i0, base = base0;
     int64_t a_idx = a_idx0;
     if (kLoop) asm volatile("" : "+v"(lane), "+v"(i), "+v"(base), "+v"(a_idx));
+    CAVOID_STAMP(2);                                        // step t begins
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
@@ -702,12 +856,12 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     lds_r[lane] = present ? a.radius : -1.0f;              // radius < 0 marks an absent row
     wave_lds_sync();
     Ego e = ego_frame_obs(a);
-    int gr[Others<N>::K];
+    Key key[Others<N>::K];
     float gapf[Others<N>::K];
-    uint32_t others, near;
+    uint32_t valid;
     bool hit;
     double min_gap;
-    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, gr, gapf, others, near, hit, min_gap);
+    pair_pass<N>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap);
 
     CAVOID_STAMP(4);                                        // ego frame + pair pass done
     float rew_f = 0.0f, done_f = (present && (a.flags & CAVOID_F_DONE_MASK) == 0u) ? 0.0f : 1.0f;   // reset / observe, packed
@@ -759,7 +913,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
                     e = ego_frame_obs(a);
                     bool hit2;
                     double gap2;
-                    pair_pass<N>(c, a, present, i, base, lds_px, lds_py, lds_r, gr, gapf, others, near, hit2, gap2);
+                    pair_pass<N>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit2, gap2);
                 }
             }
         }
@@ -769,8 +923,8 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     // ---- E9 observation: once per step, after the restart decision -----------------------------------
     if (io.obs) {
         CAVOID_STAMP(6);
-        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, gr, gapf, others, near, tile,
-                        io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f);
+        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, key, gapf, valid, tile,
+                        io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave);
     }
     CAVOID_STAMP(7);                                        // tile flushed
     if (kLoop && n_steps > 1) wave_lds_sync();             // the next step re-stages the LDS arrays and the tile

@@ -11,3 +11,11 @@ int cavoid_launch_multistep(cavoid_env *e, const KIO &io, bool prefetch, hipStre
     if (prefetch) return launch_on<MODE_STEP_AUTORESET_PF>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
     return launch_on<MODE_STEP_AUTORESET_N>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
 }
+
+#ifdef CAVOID_TRACE
+// development build only: this translation unit's copy of the phase-stamp pointer
+int cavoid_debug_trace_multistep(unsigned long long *dev_ptr) {
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dev_ptr, sizeof(dev_ptr)));
+    return CAVOID_OK;
+}
+#endif

@@ -466,3 +466,46 @@ def test_baseline_config0_two_agent_single_world_1000_steps():
         episode += 1
     assert episode >= 5
     one_env.close()
+
+
+@pytest.mark.parametrize("sort", [0, 1, 2])
+def test_exact_sort_ties_take_the_generic_rank_path(sort):
+    """Two neighbours mirrored about the host's goal axis have the SAME centimetre bucket and the SAME lateral offset
+    (ry*tx - rx*ty, bit for bit): the 63-bit tournament keys coincide and the kernel must fall back to the exact rule
+    (float64 lateral, then agent index -- what the oracle's stable sort does).  Worlds without ties share the tile."""
+    W, N = 40, 4
+    ocfg, _ = _oracle(N, sort_method=sort)
+    env = _env(W, N, sort_method=sort)
+    st = co.State.empty(W, N)
+    rng = np.random.default_rng(4)
+    for w in range(W):
+        k = slice(w * N, (w + 1) * N)
+        if w % 2 == 0:        # host 0 at the origin heading for (5, 0); others mirrored in x, one below
+            st.f64[0, k] = [0.0, 1.0, -1.0, 0.0]
+            st.f64[1, k] = [0.0, 0.8, 0.8, -2.0]
+            st.f32[0, k] = [5.0, 1.0, -1.0, 0.0]
+            st.f32[1, k] = [0.0, 5.0, 5.0, -6.0]
+            st.f32[2, k] = 0.3
+        else:
+            st.f64[0, k] = rng.uniform(-4, 4, N)
+            st.f64[1, k] = rng.uniform(-4, 4, N)
+            st.f32[0, k] = rng.uniform(-6, 6, N)
+            st.f32[1, k] = rng.uniform(-6, 6, N)
+            st.f32[2, k] = rng.uniform(0.2, 0.5, N)
+        st.f32[3, k] = 1.0
+        st.f64[2, k] = np.arctan2(st.f32[1, k] - st.f64[1, k], st.f32[0, k] - st.f64[0, k])
+        st.f64[3, k] = 50.0
+        st.flags[k] = 0x20 | 0x40
+    _push(env, st)
+    want = co.observe(ocfg, st)
+    got = env.observe().cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=OBS_TOL)
+    # the tie really is one: host 0 of an even world sees its two mirrored neighbours at the same rounded gap
+    row = want[0, 0]
+    gaps = row[6 + 6::7][:3]
+    assert np.sum(np.isclose(gaps, gaps[np.argmax(np.bincount(np.round(gaps * 100).astype(int) - int(np.round(gaps.min() * 100))))], atol=1e-12)) >= 2
+    # and a few steps from there (the tie persists while the mirrored pair moves symmetrically)
+    for t in range(5):
+        acts = np.full((W, N), 2, np.int32)
+        _compare_step(("ties", sort, t), env.step(torch.from_numpy(acts).cuda()), co.step(ocfg, st, acts), env, st)
+    env.close()

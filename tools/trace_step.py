@@ -17,12 +17,13 @@ from rl_collision_avoidance_amd import _lib
 from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
 from rl_collision_avoidance_amd.config import EnvConfig
 
-NAMES = ["start", "loads issued", "-", "dynamics", "ego+pairs", "reward/restart", "obs in LDS", "tile flushed", "stores issued"]
+NAMES = ["start", "loads issued", "step begins", "dynamics", "ego+pairs", "reward/restart", "obs in LDS", "tile flushed", "stores issued"]
 
 
 def main():
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # steps per launch (stamps 2..7 = the LAST step's)
 
     class Cfg(EnvConfig):
         def __init__(self):
@@ -41,14 +42,22 @@ def main():
     assert lib.cavoid_debug_trace(C.c_void_p(trace.data_ptr())) == 0
     for rep in range(3):
         trace.zero_()
-        env.step_autoreset(acts[rep])
+        if K == 1:
+            env.step_autoreset(acts[rep])
+        else:
+            env.step_autoreset_n(acts[:K])
         torch.cuda.synchronize()
         t = trace.cpu().numpy()[: waves - 8].astype(np.int64)
-        used = [k for k in range(9) if k != 2]
+        used = list(range(9))
+        if K > 1:
+            print("   per-wave (end - start) / K steps: median %.0f clk" % np.median((t[:, 8] - t[:, 0]) / K))
         t0 = t[:, 0].min()
         print("rep %d: launch span (first wave start -> last wave end) = %d clk; per-wave total median %d max %d"
               % (rep, t[:, 8].max() - t0, np.median(t[:, 8] - t[:, 0]), (t[:, 8] - t[:, 0]).max()))
         print("   wave start spread: %d clk" % (t[:, 0].max() - t0))
+        for a, b in ((6, 9), (9, 10), (10, 7)):
+            d = t[:, b] - t[:, a]
+            print("   [obs] %d -> %d median %6d  p90 %6d" % (a, b, np.median(d), np.percentile(d, 90)))
         for a, b in zip(used[:-1], used[1:]):
             d = t[:, b] - t[:, a]
             print("   %-16s -> %-16s median %6d  p90 %6d  max %6d" % (NAMES[a], NAMES[b], np.median(d), np.percentile(d, 90), d.max()))
