@@ -26,7 +26,7 @@ enum {
     F_WAS_IN_COLL = 1u << 4, F_PRESENT = 1u << 5, F_LEARNING = 1u << 6, F_POLICY_SHIFT = 8
 };
 #define F_DONE_MASK (F_AT_GOAL | F_RAN_OUT | F_IN_COLL)
-enum { POLICY_EXTERNAL = 0, POLICY_STATIC = 1, POLICY_NONCOOP = 2 };
+enum { POLICY_EXTERNAL = 0, POLICY_STATIC = 1, POLICY_NONCOOP = 2, POLICY_RVO = 3 };
 enum { SORT_CLOSEST_LAST = 0, SORT_CLOSEST_FIRST = 1, SORT_TTI = 2 };
 enum { DYN_UNICYCLE = 0, DYN_UNICYCLE_MAX_TURN = 1, DYN_HOLONOMIC = 2 };
 
@@ -40,6 +40,8 @@ void oracle_default_cfg(oracle_cfg *c, int32_t max_agents, int32_t max_other) {
     c->getting_close_range = 0.2; c->reward_at_goal = 1.0; c->reward_collision = -0.25;
     c->reward_getting_close = -0.1; c->reward_time_step = 0.0; c->sensing_horizon = INFINITY;
     c->close_penalty_slope = -0.5; c->max_turn_rate = 3.0; c->reward_clip_lo = -0.25; c->reward_clip_hi = 1.0;
+    /* RVO_TIME_HORIZON :237-239, RVO_COLLAB_COEFF :234-236; radius inflation and turn limit: upstream RVOPolicy as recalled */
+    c->rvo_time_horizon = 5.0; c->rvo_collab_coeff = 0.5; c->rvo_radius_scale = 1.05; c->rvo_max_delta_heading = PI / 6;
     c->max_agents = max_agents; c->max_other = max_other; c->sort_method = SORT_CLOSEST_LAST;
     c->actions_fp32 = 1; c->timeout_enabled = 1; c->time_budget_from_goal_edge = 1; c->dynamics = DYN_UNICYCLE; c->num_actions = 11;
     /* E4: 5 headings at full speed (step pi/12), 3 at half speed, 3 at zero speed (step pi/6) */
@@ -201,6 +203,121 @@ static void observe_world(const oracle_cfg *c, agent_t *ag, int n, double *obs /
     }
 }
 
+/* ---- RVO scripted policy: ORCA (van den Berg et al., ISRR 2009), float64, neighbours in agent-index order.
+ * Same statement as oracle/cavoid_oracle.py (orca_lines, _lp_on_line, _lp_plane, _lp_least_penetration, rvo_action). */
+#define RVO_EPSILON 1e-5
+typedef struct { double px, py, dx, dy; } line_t;
+static double det2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
+
+static int orca_lines(const oracle_cfg *c, const agent_t *ag, int n, int hi, line_t *out) {
+    const agent_t *h = &ag[hi];
+    const double inv_h = 1.0 / c->rvo_time_horizon;
+    int m = 0;
+    for (int j = 0; j < n; ++j) {
+        if (j == hi) continue;
+        const agent_t *o = &ag[j];
+        double rpx = o->px - h->px, rpy = o->py - h->py, rvx = h->vx - o->vx, rvy = h->vy - o->vy;
+        double dist_sq = rpx * rpx + rpy * rpy;
+        double comb = c->rvo_radius_scale * h->radius + c->rvo_radius_scale * o->radius, comb_sq = comb * comb;
+        double dx, dy, ucx, ucy;
+        if (dist_sq > comb_sq) {
+            double wx = rvx - inv_h * rpx, wy = rvy - inv_h * rpy, w_sq = wx * wx + wy * wy, dot1 = wx * rpx + wy * rpy;
+            if (dot1 < 0.0 && dot1 * dot1 > comb_sq * w_sq) {
+                double w_len = sqrt(w_sq), ux = wx / w_len, uy = wy / w_len, scale = comb * inv_h - w_len;
+                dx = uy; dy = -ux; ucx = scale * ux; ucy = scale * uy;
+            } else {
+                double leg = sqrt(dist_sq - comb_sq);
+                if (det2(rpx, rpy, wx, wy) > 0.0) { dx = (rpx * leg - rpy * comb) / dist_sq; dy = (rpx * comb + rpy * leg) / dist_sq; }
+                else { dx = -(rpx * leg + rpy * comb) / dist_sq; dy = -(-rpx * comb + rpy * leg) / dist_sq; }
+                double dot2 = rvx * dx + rvy * dy;
+                ucx = dot2 * dx - rvx; ucy = dot2 * dy - rvy;
+            }
+        } else {
+            double inv_dt = 1.0 / c->dt, wx = rvx - inv_dt * rpx, wy = rvy - inv_dt * rpy;
+            double w_len = sqrt(wx * wx + wy * wy), ux = wx / w_len, uy = wy / w_len, scale = comb * inv_dt - w_len;
+            dx = uy; dy = -ux; ucx = scale * ux; ucy = scale * uy;
+        }
+        out[m].px = h->vx + c->rvo_collab_coeff * ucx; out[m].py = h->vy + c->rvo_collab_coeff * ucy;
+        out[m].dx = dx; out[m].dy = dy;
+        ++m;
+    }
+    return m;
+}
+
+static int lp_on_line(const line_t *ln, int k, double radius, double ox, double oy, int direction_opt, double *x, double *y) {
+    const double px = ln[k].px, py = ln[k].py, dx = ln[k].dx, dy = ln[k].dy;
+    double dot = px * dx + py * dy, disc = dot * dot + radius * radius - (px * px + py * py);
+    if (disc < 0.0) return 0;
+    double root = sqrt(disc), t_lo = -dot - root, t_hi = -dot + root;
+    for (int i = 0; i < k; ++i) {
+        double den = det2(dx, dy, ln[i].dx, ln[i].dy), num = det2(ln[i].dx, ln[i].dy, px - ln[i].px, py - ln[i].py);
+        if (fabs(den) <= RVO_EPSILON) { if (num < 0.0) return 0; continue; }
+        double t = num / den;
+        if (den >= 0.0) t_hi = fmin(t_hi, t); else t_lo = fmax(t_lo, t);
+        if (t_lo > t_hi) return 0;
+    }
+    double t;
+    if (direction_opt) t = (ox * dx + oy * dy > 0.0) ? t_hi : t_lo;
+    else { t = dx * (ox - px) + dy * (oy - py); t = t < t_lo ? t_lo : (t > t_hi ? t_hi : t); }
+    *x = px + t * dx; *y = py + t * dy;
+    return 1;
+}
+
+static int lp_plane(const line_t *ln, int m, double radius, double ox, double oy, int direction_opt, double *x, double *y) {
+    if (direction_opt) { *x = ox * radius; *y = oy * radius; }
+    else if (ox * ox + oy * oy > radius * radius) { double nn = sqrt(ox * ox + oy * oy); *x = ox / nn * radius; *y = oy / nn * radius; }
+    else { *x = ox; *y = oy; }
+    for (int k = 0; k < m; ++k)
+        if (det2(ln[k].dx, ln[k].dy, ln[k].px - *x, ln[k].py - *y) > 0.0) {
+            double nx, ny;
+            if (!lp_on_line(ln, k, radius, ox, oy, direction_opt, &nx, &ny)) return k;
+            *x = nx; *y = ny;
+        }
+    return m;
+}
+
+static void lp_least_penetration(const line_t *ln, int m, int begin, double radius, double *x, double *y) {
+    double distance = 0.0;
+    line_t proj[ORACLE_MAX_AGENTS];
+    for (int k = begin; k < m; ++k) {
+        const double px = ln[k].px, py = ln[k].py, dx = ln[k].dx, dy = ln[k].dy;
+        if (det2(dx, dy, px - *x, py - *y) > distance) {
+            int np = 0;
+            for (int j = 0; j < k; ++j) {
+                double den = det2(dx, dy, ln[j].dx, ln[j].dy), nx, ny;
+                if (fabs(den) <= RVO_EPSILON) {
+                    if (dx * ln[j].dx + dy * ln[j].dy > 0.0) continue;
+                    nx = 0.5 * (px + ln[j].px); ny = 0.5 * (py + ln[j].py);
+                } else {
+                    double t = det2(ln[j].dx, ln[j].dy, px - ln[j].px, py - ln[j].py) / den;
+                    nx = px + t * dx; ny = py + t * dy;
+                }
+                double fx = ln[j].dx - dx, fy = ln[j].dy - dy, fn = sqrt(fx * fx + fy * fy);
+                proj[np].px = nx; proj[np].py = ny; proj[np].dx = fx / fn; proj[np].dy = fy / fn;
+                ++np;
+            }
+            double nx, ny;
+            if (lp_plane(proj, np, radius, -dy, dx, 1, &nx, &ny) >= np) { *x = nx; *y = ny; }
+            distance = det2(dx, dy, px - *x, py - *y);
+        }
+    }
+}
+
+static void rvo_action(const oracle_cfg *c, const agent_t *ag, int n, int hi, double *a0, double *a1) {
+    const agent_t *h = &ag[hi];
+    double gx = h->gx - h->px, gy = h->gy - h->py, gn = sqrt(gx * gx + gy * gy);
+    double scale = gn > 0.0 ? h->pref_speed / gn : 0.0, pvx = scale * gx, pvy = scale * gy;
+    line_t ln[ORACLE_MAX_AGENTS];
+    int m = orca_lines(c, ag, n, hi, ln);
+    double vx, vy;
+    int fail = lp_plane(ln, m, h->pref_speed, pvx, pvy, 0, &vx, &vy);
+    if (fail < m) lp_least_penetration(ln, m, fail, h->pref_speed, &vx, &vy);
+    double speed = sqrt(vx * vx + vy * vy);
+    double delta = speed > 0.0 ? wrap(atan2(vy, vx) - h->heading) : 0.0;
+    if (fabs(delta) > c->rvo_max_delta_heading) { delta = copysign(c->rvo_max_delta_heading, delta); speed = 0.0; }
+    *a0 = speed; *a1 = delta;
+}
+
 static void step_world(const oracle_cfg *c, agent_t *ag, int n, const int32_t *act, const float *cont,
                        double *obs, double *rew, uint8_t *done, uint8_t *game_over) {
     const int N = c->max_agents;
@@ -214,6 +331,7 @@ static void step_world(const oracle_cfg *c, agent_t *ag, int n, const int32_t *a
             if (cont) { a0[i] = cont[2 * i]; a1[i] = cont[2 * i + 1]; }
             else { const double *r = c->actions[act[i]]; a0[i] = ag[i].pref_speed * r[0]; a1[i] = r[1]; }
         } else if (pol == POLICY_NONCOOP) { a0[i] = ag[i].pref_speed; a1[i] = -ag[i].heading_ego; }
+        else if (pol == POLICY_RVO) rvo_action(c, ag, n, i, &a0[i], &a1[i]);
         if (c->actions_fp32) { a0[i] = (double)(float)a0[i]; a1[i] = (double)(float)a1[i]; }
     }
     /* ... then all move (E5) */
@@ -286,50 +404,93 @@ void oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 
 static double u01(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 
+static uint32_t draw_policy(const oracle_gen *g, const uint32_t b[4], int i) {
+    if (i > 0 && u01(b[2]) < g->nonlearning_fraction) {
+        double u = u01(b[3]);
+        if (u < g->static_fraction) return POLICY_STATIC;
+        return u < g->static_fraction + g->rvo_fraction ? POLICY_RVO : POLICY_NONCOOP;
+    }
+    return POLICY_EXTERNAL;
+}
+
+static void place_agent(const oracle_cfg *c, oracle_state *s, int64_t k, double px, double py, float gx, float gy,
+                        float radius, float pref, uint32_t pol) {
+    double tx = (double)gx - px, ty = (double)gy - py;
+    double dxg = px - (double)gx, dyg = py - (double)gy;
+    double straight = (sqrt(dxg * dxg + dyg * dyg) - (c->time_budget_from_goal_edge ? c->near_goal_threshold : 0.0)) / (double)pref;
+    s->px[k] = px; s->py[k] = py; s->heading[k] = atan2(ty, tx);
+    s->t_remaining[k] = fmax(c->max_time_ratio * straight, c->dt);
+    s->gx[k] = gx; s->gy[k] = gy; s->radius[k] = radius; s->pref_speed[k] = pref; s->speed[k] = 0.0f;
+    s->flags[k] = F_PRESENT | (pol == POLICY_EXTERNAL ? F_LEARNING : 0u) | (pol << F_POLICY_SHIFT);
+}
+
 static void generate_world(const oracle_cfg *c, const oracle_gen *g, uint64_t seed, uint32_t gw, uint32_t ep,
                            oracle_state *s, int64_t w) {
     const int N = c->max_agents;
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, ctr[4] = {gw, ep, 0, 0}, r[4], a[4], b[4];
-    if (g->pool_size > 0) {            /* scenario pool: pick the pool entry, which is generator world k, episode 0 */
+    if (g->pool_size > 0) {            /* scenario pool: pick the pool entry, which is generator world k of the pool's epoch */
         /* splitmix64-style finaliser of (seed, gw, ep), reduced to [0, P) by multiply-shift */
         uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gw + 1ull) + 0xC2B2AE3D27D4EB4Full * ((uint64_t)ep + 1ull);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z ^= z >> 31;
         ctr[0] = gw = (uint32_t)(((z >> 32) * (uint64_t)(uint32_t)g->pool_size) >> 32);
-        ctr[1] = ep = 0;
+        ctr[1] = ep = g->pool_epoch;
     }
     oracle_philox4x32(ctr, key, r);
     int span = g->max_agents - g->min_agents + 1;
     int n = g->min_agents + (int)(r[0] % (uint32_t)span);
-    double base = fmax(4.0, 0.7 * n), ring = base * (1.0 + u01(r[1])), phase = u01(r[2]);
-    for (int i = 0; i < N; ++i) {
+    for (int i = n; i < N; ++i) {
         int64_t k = w * N + i;
-        if (i >= n) {
-            s->px[k] = s->py[k] = s->heading[k] = s->t_remaining[k] = 0.0;
-            s->gx[k] = s->gy[k] = s->radius[k] = s->pref_speed[k] = s->speed[k] = 0.0f;
-            s->flags[k] = 0;
-            continue;
+        s->px[k] = s->py[k] = s->heading[k] = s->t_remaining[k] = 0.0;
+        s->gx[k] = s->gy[k] = s->radius[k] = s->pref_speed[k] = s->speed[k] = 0.0f;
+        s->flags[k] = 0;
+    }
+    if (g->mode == 0) {                /* GEN v1: ring, antipodal goals */
+        double base = fmax(4.0, 0.7 * n), ring = base * (1.0 + u01(r[1])), phase = u01(r[2]);
+        for (int i = 0; i < n; ++i) {
+            ctr[2] = 1; ctr[3] = (uint32_t)i; oracle_philox4x32(ctr, key, a);
+            ctr[2] = 2; oracle_philox4x32(ctr, key, b);
+            float radius = (float)(0.2 + 0.6 * u01(a[0]));
+            float pref = (float)(0.5 + 1.5 * u01(a[1]));
+            double turn = phase + (i + (u01(a[2]) - 0.5) * 2.0 * g->angle_jitter) / n;
+            double theta = 2.0 * PI * turn;
+            double px = ring * cos(theta), py = ring * sin(theta);
+            float gx = (float)(-px + (u01(b[0]) - 0.5) * 2.0 * g->goal_jitter);
+            float gy = (float)(-py + (u01(b[1]) - 0.5) * 2.0 * g->goal_jitter);
+            place_agent(c, s, w * N + i, px, py, gx, gy, radius, pref, draw_policy(g, b, i));
         }
+        return;
+    }
+    /* GEN v2: uniform boxes, one agent after the other, rejection sampling against the agents already placed */
+    const double *box = n < g->box_large_from ? g->box_small : g->box_large;
+    double side = box[0] + (box[1] - box[0]) * u01(r[1]);
+    for (int i = 0; i < n; ++i) {
+        uint32_t cc[4];
         ctr[2] = 1; ctr[3] = (uint32_t)i; oracle_philox4x32(ctr, key, a);
         ctr[2] = 2; oracle_philox4x32(ctr, key, b);
         float radius = (float)(0.2 + 0.6 * u01(a[0]));
         float pref = (float)(0.5 + 1.5 * u01(a[1]));
-        double turn = phase + (i + (u01(a[2]) - 0.5) * 2.0 * g->angle_jitter) / n;
-        double theta = 2.0 * PI * turn;
-        double px = ring * cos(theta), py = ring * sin(theta);
-        float gx = (float)(-px + (u01(b[0]) - 0.5) * 2.0 * g->goal_jitter);
-        float gy = (float)(-py + (u01(b[1]) - 0.5) * 2.0 * g->goal_jitter);
-        uint32_t pol = POLICY_EXTERNAL;
-        if (i > 0 && u01(b[2]) < g->nonlearning_fraction)
-            pol = u01(b[3]) < g->static_fraction ? POLICY_STATIC : POLICY_NONCOOP;
-        double tx = (double)gx - px, ty = (double)gy - py;
-        double dxg = px - (double)gx, dyg = py - (double)gy;
-        double straight = (sqrt(dxg * dxg + dyg * dyg) - (c->time_budget_from_goal_edge ? c->near_goal_threshold : 0.0)) / (double)pref;
-        s->px[k] = px; s->py[k] = py; s->heading[k] = atan2(ty, tx);
-        s->t_remaining[k] = fmax(c->max_time_ratio * straight, c->dt);
-        s->gx[k] = gx; s->gy[k] = gy; s->radius[k] = radius; s->pref_speed[k] = pref; s->speed[k] = 0.0f;
-        s->flags[k] = F_PRESENT | (pol == POLICY_EXTERNAL ? F_LEARNING : 0u) | (pol << F_POLICY_SHIFT);
+        double sx, sy;
+        float gx, gy;
+        int attempt = 0;
+        for (;;) {
+            ctr[2] = 3u + (uint32_t)attempt; oracle_philox4x32(ctr, key, cc);
+            sx = side * (2.0 * u01(cc[0]) - 1.0); sy = side * (2.0 * u01(cc[1]) - 1.0);
+            gx = (float)(side * (2.0 * u01(cc[2]) - 1.0)); gy = (float)(side * (2.0 * u01(cc[3]) - 1.0));
+            double tx = (double)gx - sx, ty = (double)gy - sy;
+            int ok = sqrt(tx * tx + ty * ty) >= g->min_trip;
+            for (int j = 0; j < i; ++j) {
+                int64_t kj = w * N + j;
+                double margin = ((double)radius + (double)s->radius[kj]) + c->getting_close_range;
+                double ax = sx - s->px[kj], ay = sy - s->py[kj], bx = (double)gx - (double)s->gx[kj], by = (double)gy - (double)s->gy[kj];
+                if (sqrt(ax * ax + ay * ay) < margin || sqrt(bx * bx + by * by) < margin) ok = 0;
+            }
+            ++attempt;
+            if (ok || attempt >= 100) break;
+            if (attempt % 10 == 0) side = side * 1.01;
+        }
+        place_agent(c, s, w * N + i, sx, sy, gx, gy, radius, pref, draw_policy(g, b, i));
     }
 }
 

@@ -16,6 +16,7 @@ typedef struct oracle_cfg {
     double dt, near_goal_threshold, max_time_ratio, collision_dist, getting_close_range;
     double reward_at_goal, reward_collision, reward_getting_close, reward_time_step;
     double sensing_horizon, close_penalty_slope, max_turn_rate, reward_clip_lo, reward_clip_hi;
+    double rvo_time_horizon, rvo_collab_coeff, rvo_radius_scale, rvo_max_delta_heading;   /* RVO scripted policy */
     int32_t max_agents;        /* N */
     int32_t max_other;         /* M */
     int32_t sort_method;       /* 0 closest_last, 1 closest_first, 2 time_to_impact */
@@ -32,8 +33,12 @@ typedef struct oracle_cfg {
 typedef struct oracle_gen {
     int32_t min_agents, max_agents;
     double nonlearning_fraction, static_fraction, goal_jitter, angle_jitter;
-    int32_t pool_size;   /* > 0: episode ep of world gw is generator world pool_index(seed,gw,ep) (splitmix64 finaliser, multiply-shift), episode 0 */
-    int32_t _pad;
+    int32_t pool_size;   /* > 0: episode ep of world gw is generator world pool_index(seed,gw,ep) (splitmix64 finaliser, multiply-shift) of episode pool_epoch */
+    int32_t mode;        /* 0 GEN v1 (ring), 1 GEN v2 (boxes, rejection sampling) */
+    double rvo_fraction; /* of the scripted agents: P(static) = static_fraction, P(RVO) = rvo_fraction, rest non-cooperative */
+    double box_small[2], box_large[2], min_trip;
+    int32_t box_large_from;
+    uint32_t pool_epoch;
 } oracle_gen;
 
 /* SoA over A = W*N agents, agent a = w*N + i */

@@ -48,10 +48,10 @@ F_WAS_AT_GOAL = 1 << 3      # Agent.was_at_goal_already
 F_WAS_IN_COLL = 1 << 4      # Agent.was_in_collision_already
 F_PRESENT = 1 << 5          # row holds a real agent (worlds may have fewer than N agents)
 F_LEARNING = 1 << 6         # policy is the external (GA3C) learning policy -> obs col 0
-F_POLICY_SHIFT = 8          # bits 8..9: 0 external/learning, 1 static, 2 non-cooperative
+F_POLICY_SHIFT = 8          # bits 8..9: 0 external/learning, 1 static, 2 non-cooperative, 3 RVO (ORCA)
 F_DONE_MASK = F_AT_GOAL | F_RAN_OUT | F_IN_COLL
 
-POLICY_EXTERNAL, POLICY_STATIC, POLICY_NONCOOP = 0, 1, 2
+POLICY_EXTERNAL, POLICY_STATIC, POLICY_NONCOOP, POLICY_RVO = 0, 1, 2, 3
 SORT_CLOSEST_LAST, SORT_CLOSEST_FIRST, SORT_TIME_TO_IMPACT = 0, 1, 2
 DYN_UNICYCLE, DYN_UNICYCLE_MAX_TURN, DYN_HOLONOMIC = 0, 1, 2
 
@@ -97,6 +97,11 @@ class OracleConfig:
     evaluate_mode: bool = False          # EVALUATE_MODE: the episode ends when EVERY agent is done
     time_budget_from_goal_edge: bool = True   # U11: budget = ratio*(dist - NEAR_GOAL_THRESHOLD)/pref (upstream agent.py as
                                          # recalled) vs SURVEY App. A's ratio*dist/pref (False)
+    # --- RVO scripted policy (run-ws/config.yaml:231-239: RVO_TIME_HORIZON 5.0, RVO_COLLAB_COEFF 0.5) -----------
+    rvo_time_horizon: float = 5.0
+    rvo_collab_coeff: float = 0.5        # share of the avoidance effort the RVO agent takes (0.5 = reciprocal)
+    rvo_radius_scale: float = 1.05       # the policy inflates every radius by 5 % (upstream RVOPolicy as recalled)
+    rvo_max_delta_heading: float = math.pi / 6   # larger turns: stop and turn in place
     # min/max of the env's list of possible reward values; rewards are clipped into it
     reward_clip_lo: float = -0.25
     reward_clip_hi: float = 1.0
@@ -247,6 +252,161 @@ def time_to_impact(host: Agent, other: Agent) -> float:
     return (b - math.sqrt(disc)) / a
 
 
+# ----------------------------------------------------------------------------------------------
+# RVO scripted policy: Optimal Reciprocal Collision Avoidance, van den Berg et al.,
+# "Reciprocal n-body collision avoidance" (ISRR 2009) -- the algorithm of the RVO2 library the upstream RVOPolicy
+# drives through its Python binding (absent here, like the whole env package: PARITY UNPINNED).  Restated in float64
+# from the paper: one half-plane ("ORCA line") per neighbour, then the 2-D linear programme of its section 5.2
+# (closest admissible velocity to the preferred one inside the max-speed disc), and, when the half-planes admit no
+# velocity, the programme that minimises the worst penetration.  Neighbours are visited in agent-index order
+# (RVO2 visits them nearest first; the optimum does not depend on the order, rounding does).
+# ----------------------------------------------------------------------------------------------
+RVO_EPSILON = 1e-5
+
+
+def _det(ax: float, ay: float, bx: float, by: float) -> float:
+    return ax * by - ay * bx
+
+
+def orca_lines(hi: int, agents: List["Agent"], cfg: "OracleConfig") -> List[Tuple[float, float, float, float]]:
+    """One line (point_x, point_y, dir_x, dir_y) per OTHER agent: velocities to the left of the line are admissible."""
+    host = agents[hi]
+    inv_h = 1.0 / cfg.rvo_time_horizon
+    lines = []
+    for j, other in enumerate(agents):
+        if j == hi:
+            continue
+        rpx, rpy = other.pos[0] - host.pos[0], other.pos[1] - host.pos[1]
+        rvx, rvy = host.vel[0] - other.vel[0], host.vel[1] - other.vel[1]
+        dist_sq = rpx * rpx + rpy * rpy
+        comb = cfg.rvo_radius_scale * host.radius + cfg.rvo_radius_scale * other.radius
+        comb_sq = comb * comb
+        if dist_sq > comb_sq:                              # not touching: velocity obstacle truncated at the horizon
+            wx, wy = rvx - inv_h * rpx, rvy - inv_h * rpy
+            w_sq = wx * wx + wy * wy
+            dot1 = wx * rpx + wy * rpy
+            if dot1 < 0.0 and dot1 * dot1 > comb_sq * w_sq:   # closest point is on the cut-off circle
+                w_len = math.sqrt(w_sq)
+                ux, uy = wx / w_len, wy / w_len
+                dx, dy = uy, -ux
+                scale = comb * inv_h - w_len
+                ucx, ucy = scale * ux, scale * uy
+            else:                                           # ... on one of the two legs
+                leg = math.sqrt(dist_sq - comb_sq)
+                if _det(rpx, rpy, wx, wy) > 0.0:
+                    dx, dy = (rpx * leg - rpy * comb) / dist_sq, (rpx * comb + rpy * leg) / dist_sq
+                else:
+                    dx, dy = -(rpx * leg + rpy * comb) / dist_sq, -(-rpx * comb + rpy * leg) / dist_sq
+                dot2 = rvx * dx + rvy * dy
+                ucx, ucy = dot2 * dx - rvx, dot2 * dy - rvy
+        else:                                               # already overlapping: get out within one time step
+            inv_dt = 1.0 / cfg.dt
+            wx, wy = rvx - inv_dt * rpx, rvy - inv_dt * rpy
+            w_len = math.sqrt(wx * wx + wy * wy)
+            ux, uy = wx / w_len, wy / w_len
+            dx, dy = uy, -ux
+            scale = comb * inv_dt - w_len
+            ucx, ucy = scale * ux, scale * uy
+        lines.append((host.vel[0] + cfg.rvo_collab_coeff * ucx, host.vel[1] + cfg.rvo_collab_coeff * ucy, dx, dy))
+    return lines
+
+
+def _lp_on_line(lines, k: int, radius: float, ox: float, oy: float, direction_opt: bool):
+    """Optimise along line k inside the disc and the half-planes 0..k-1.  -> (ok, x, y)"""
+    px, py, dx, dy = lines[k]
+    dot = px * dx + py * dy
+    disc = dot * dot + radius * radius - (px * px + py * py)
+    if disc < 0.0:
+        return False, 0.0, 0.0
+    root = math.sqrt(disc)
+    t_lo, t_hi = -dot - root, -dot + root
+    for i in range(k):
+        qx, qy, ex, ey = lines[i]
+        den = _det(dx, dy, ex, ey)
+        num = _det(ex, ey, px - qx, py - qy)
+        if abs(den) <= RVO_EPSILON:                        # parallel lines
+            if num < 0.0:
+                return False, 0.0, 0.0
+            continue
+        t = num / den
+        if den >= 0.0:
+            t_hi = min(t_hi, t)
+        else:
+            t_lo = max(t_lo, t)
+        if t_lo > t_hi:
+            return False, 0.0, 0.0
+    if direction_opt:
+        t = t_hi if ox * dx + oy * dy > 0.0 else t_lo
+    else:
+        t = dx * (ox - px) + dy * (oy - py)
+        t = t_lo if t < t_lo else (t_hi if t > t_hi else t)
+    return True, px + t * dx, py + t * dy
+
+
+def _lp_plane(lines, radius: float, ox: float, oy: float, direction_opt: bool):
+    """-> (index of the first line that cannot be satisfied, or len(lines); x; y)"""
+    if direction_opt:
+        x, y = ox * radius, oy * radius
+    elif ox * ox + oy * oy > radius * radius:
+        n = math.sqrt(ox * ox + oy * oy)
+        x, y = ox / n * radius, oy / n * radius
+    else:
+        x, y = ox, oy
+    for k, (px, py, dx, dy) in enumerate(lines):
+        if _det(dx, dy, px - x, py - y) > 0.0:             # current optimum violates half-plane k
+            ok, nx, ny = _lp_on_line(lines, k, radius, ox, oy, direction_opt)
+            if not ok:
+                return k, x, y
+            x, y = nx, ny
+    return len(lines), x, y
+
+
+def _lp_least_penetration(lines, begin: int, radius: float, x: float, y: float):
+    distance = 0.0
+    for k in range(begin, len(lines)):
+        px, py, dx, dy = lines[k]
+        if _det(dx, dy, px - x, py - y) > distance:
+            proj = []
+            for j in range(k):
+                qx, qy, ex, ey = lines[j]
+                den = _det(dx, dy, ex, ey)
+                if abs(den) <= RVO_EPSILON:
+                    if dx * ex + dy * ey > 0.0:             # same direction: line j adds nothing
+                        continue
+                    nx, ny = 0.5 * (px + qx), 0.5 * (py + qy)
+                else:
+                    t = _det(ex, ey, px - qx, py - qy) / den
+                    nx, ny = px + t * dx, py + t * dy
+                fx, fy = ex - dx, ey - dy
+                fn = math.sqrt(fx * fx + fy * fy)
+                proj.append((nx, ny, fx / fn, fy / fn))
+            fail, nx, ny = _lp_plane(proj, radius, -dy, dx, True)
+            if fail >= len(proj):
+                x, y = nx, ny
+            distance = _det(dx, dy, px - x, py - y)
+    return x, y
+
+
+def rvo_action(hi: int, agents: List["Agent"], cfg: "OracleConfig") -> np.ndarray:
+    """[speed, delta_heading] of an RVO agent: the ORCA velocity for one DT, turned into the unicycle action the env
+    integrates; a turn beyond rvo_max_delta_heading is clipped and taken standing still."""
+    host = agents[hi]
+    gx, gy = host.goal[0] - host.pos[0], host.goal[1] - host.pos[1]
+    gn = math.sqrt(gx * gx + gy * gy)
+    scale = host.pref_speed / gn if gn > 0.0 else 0.0
+    pvx, pvy = scale * gx, scale * gy
+    lines = orca_lines(hi, agents, cfg)
+    fail, vx, vy = _lp_plane(lines, host.pref_speed, pvx, pvy, False)
+    if fail < len(lines):
+        vx, vy = _lp_least_penetration(lines, fail, host.pref_speed, vx, vy)
+    speed = math.sqrt(vx * vx + vy * vy)
+    delta = wrap(math.atan2(vy, vx) - host.heading) if speed > 0.0 else 0.0
+    if abs(delta) > cfg.rvo_max_delta_heading:
+        delta = math.copysign(cfg.rvo_max_delta_heading, delta)
+        speed = 0.0
+    return np.array([speed, delta])
+
+
 class World:
     """One simulated world = what one reference ``CollisionAvoidanceEnv`` instance holds."""
 
@@ -263,6 +423,8 @@ class World:
     def _policy_action(self, agent: Agent) -> np.ndarray:
         if agent.policy == POLICY_STATIC:
             return np.array([0.0, 0.0])
+        if agent.policy == POLICY_RVO:
+            return rvo_action(self.agents.index(agent), self.agents, self.cfg)
         # non-cooperative: full preferred speed straight at the goal
         return np.array([agent.pref_speed, -agent.heading_ego])
 
@@ -416,10 +578,20 @@ class GenConfig:
     min_agents: int = 4
     max_agents: int = 4
     nonlearning_fraction: float = 0.0     # P(agent i>0 runs a scripted policy)
-    static_fraction: float = 0.5          # of those, P(static) (else non-cooperative)
-    goal_jitter: float = 0.5              # half-width (m) of the uniform jitter on the antipodal goal
-    angle_jitter: float = 0.25            # fraction of the angular slot
+    static_fraction: float = 0.5          # of those, P(static)
+    goal_jitter: float = 0.5              # GEN v1: half-width (m) of the uniform jitter on the antipodal goal
+    angle_jitter: float = 0.25            # GEN v1: fraction of the angular slot
     pool_size: int = 0                    # > 0: scenario pool (episode ep of world gw = pool entry pool_index(seed, gw, ep, P))
+    mode: int = 0                         # 0 = GEN v1 (ring, antipodal goals), 1 = GEN v2 (uniform boxes, rejection sampling)
+    rvo_fraction: float = 0.0             # of the scripted agents, P(RVO); the rest (1 - static - rvo) are non-cooperative
+    box_small: Tuple[float, float] = (4.0, 5.0)    # GEN v2: half side of the box ~ U(lo, hi) for worlds of < box_large_from agents
+    box_large: Tuple[float, float] = (6.0, 8.0)    # ... and for the larger worlds (keeps the density roughly constant)
+    box_large_from: int = 5
+    min_trip: float = 1.0                 # GEN v2: an agent's goal is at least this far from its start
+    pool_epoch: int = 0                   # the pool holds generator worlds 0..P-1 of THIS episode index (refreshable)
+
+
+GEN_V2_MAX_ATTEMPTS = 100
 
 
 def pool_index(seed: int, world_id: int, episode: int, pool_size: int) -> int:
@@ -432,35 +604,75 @@ def pool_index(seed: int, world_id: int, episode: int, pool_size: int) -> int:
     return ((z >> 32) * pool_size) >> 32
 
 
+def _draw_policy(b, i: int, gen: GenConfig) -> int:
+    if i > 0 and _u01(b[2]) < gen.nonlearning_fraction:
+        u = _u01(b[3])
+        if u < gen.static_fraction:
+            return POLICY_STATIC
+        return POLICY_RVO if u < gen.static_fraction + gen.rvo_fraction else POLICY_NONCOOP
+    return POLICY_EXTERNAL
+
+
 def generate_world(seed: int, world_id: int, episode: int, cfg: OracleConfig, gen: GenConfig) -> World:
-    """GEN v1: n agents on a circle, goals roughly antipodal (every pair must negotiate the
-    centre).  radius~U(0.2,0.8), pref_speed~U(0.5,2.0) stored as float32 values; start
-    positions stay float64; heading points at the goal; time budget as in ``Agent``."""
+    """GEN v1 (mode 0): n agents on a circle, goals roughly antipodal (every pair must negotiate the centre).
+    GEN v2 (mode 1): starts and goals uniform in a box whose size grows with the agent count, placed one agent after the
+    other by rejection sampling against the agents already placed (starts and goals at least the two radii +
+    GETTING_CLOSE_RANGE apart, trips of at least min_trip) -- the shape of upstream's random test-case generator as
+    recalled (its np.random stream is unknowable, so this is its own counter-based specification).
+    Both: radius~U(0.2,0.8), pref_speed~U(0.5,2.0) stored as float32 values, goals float32, starts float64; heading points
+    at the goal; time budget as in ``Agent``."""
     k0, k1 = seed & _MASK32, (seed >> 32) & _MASK32
-    if gen.pool_size > 0:      # pool entry k is generator world k, episode 0
+    if gen.pool_size > 0:      # pool entry k is generator world k of the pool's epoch
         world_id = pool_index(seed, world_id, episode, gen.pool_size)
-        episode = 0
-    w = philox4x32(world_id & _MASK32, episode & _MASK32, 0, 0, k0, k1)
+        episode = gen.pool_epoch
+    wid, ep = world_id & _MASK32, episode & _MASK32
+    w = philox4x32(wid, ep, 0, 0, k0, k1)
     span = gen.max_agents - gen.min_agents + 1
     n = gen.min_agents + (w[0] % span)
-    base = max(4.0, 0.7 * n)
-    ring = base * (1.0 + _u01(w[1]))
-    phase = _u01(w[2])
     agents = []
+    if gen.mode == 0:
+        base = max(4.0, 0.7 * n)
+        ring = base * (1.0 + _u01(w[1]))
+        phase = _u01(w[2])
+        for i in range(n):
+            a = philox4x32(wid, ep, 1, i, k0, k1)
+            b = philox4x32(wid, ep, 2, i, k0, k1)
+            radius = float(np.float32(0.2 + 0.6 * _u01(a[0])))
+            pref_speed = float(np.float32(0.5 + 1.5 * _u01(a[1])))
+            turn = phase + (i + (_u01(a[2]) - 0.5) * 2.0 * gen.angle_jitter) / n
+            theta = 2.0 * math.pi * turn
+            px, py = ring * math.cos(theta), ring * math.sin(theta)
+            gx = float(np.float32(-px + (_u01(b[0]) - 0.5) * 2.0 * gen.goal_jitter))
+            gy = float(np.float32(-py + (_u01(b[1]) - 0.5) * 2.0 * gen.goal_jitter))
+            agents.append(Agent(px, py, gx, gy, radius, pref_speed, None, _draw_policy(b, i, gen), cfg))
+        return World(agents, cfg)
+    lo, hi = gen.box_small if n < gen.box_large_from else gen.box_large
+    side = lo + (hi - lo) * _u01(w[1])
     for i in range(n):
-        a = philox4x32(world_id & _MASK32, episode & _MASK32, 1, i, k0, k1)
-        b = philox4x32(world_id & _MASK32, episode & _MASK32, 2, i, k0, k1)
+        a = philox4x32(wid, ep, 1, i, k0, k1)
+        b = philox4x32(wid, ep, 2, i, k0, k1)
         radius = float(np.float32(0.2 + 0.6 * _u01(a[0])))
         pref_speed = float(np.float32(0.5 + 1.5 * _u01(a[1])))
-        turn = phase + (i + (_u01(a[2]) - 0.5) * 2.0 * gen.angle_jitter) / n
-        theta = 2.0 * math.pi * turn
-        px, py = ring * math.cos(theta), ring * math.sin(theta)
-        gx = float(np.float32(-px + (_u01(b[0]) - 0.5) * 2.0 * gen.goal_jitter))
-        gy = float(np.float32(-py + (_u01(b[1]) - 0.5) * 2.0 * gen.goal_jitter))
-        policy = POLICY_EXTERNAL
-        if i > 0 and _u01(b[2]) < gen.nonlearning_fraction:
-            policy = POLICY_STATIC if _u01(b[3]) < gen.static_fraction else POLICY_NONCOOP
-        agents.append(Agent(px, py, gx, gy, radius, pref_speed, None, policy, cfg))
+        attempt = 0
+        while True:
+            c = philox4x32(wid, ep, 3 + attempt, i, k0, k1)
+            sx, sy = side * (2.0 * _u01(c[0]) - 1.0), side * (2.0 * _u01(c[1]) - 1.0)
+            gx = float(np.float32(side * (2.0 * _u01(c[2]) - 1.0)))
+            gy = float(np.float32(side * (2.0 * _u01(c[3]) - 1.0)))
+            tx, ty = gx - sx, gy - sy
+            ok = math.sqrt(tx * tx + ty * ty) >= gen.min_trip
+            for other in agents:
+                margin = (radius + other.radius) + cfg.getting_close_range
+                ax, ay = sx - other.pos[0], sy - other.pos[1]
+                bx, by = gx - other.goal[0], gy - other.goal[1]
+                if math.sqrt(ax * ax + ay * ay) < margin or math.sqrt(bx * bx + by * by) < margin:
+                    ok = False
+            attempt += 1
+            if ok or attempt >= GEN_V2_MAX_ATTEMPTS:
+                break
+            if attempt % 10 == 0:
+                side = side * 1.01                           # a crowded box grows, for this and the later agents
+        agents.append(Agent(sx, sy, gx, gy, radius, pref_speed, None, _draw_policy(b, i, gen), cfg))
     return World(agents, cfg)
 
 

@@ -11,11 +11,11 @@ from oracle import c_oracle as co
 from oracle import cavoid_oracle as po
 
 
-def _cross(N, M, sort, nonl, W=12, steps=100, seed=7, dyn=0):
+def _cross(N, M, sort, nonl, W=12, steps=100, seed=7, dyn=0, mode=0, rvo=0.0):
     pcfg = po.OracleConfig(max_agents=N, max_other_agents_observed=M, sort_method=sort, dynamics=dyn)
-    pgen = po.GenConfig(min_agents=2, max_agents=N, nonlearning_fraction=nonl)
+    pgen = po.GenConfig(min_agents=2, max_agents=N, nonlearning_fraction=nonl, mode=mode, rvo_fraction=rvo)
     ccfg = co.default_cfg(N, M, sort_method=sort, dynamics=dyn)
-    cgen = co.default_gen(2, N, nonl)
+    cgen = co.default_gen(2, N, nonl, mode=mode, rvo_fraction=rvo)
     st = co.State.empty(W, N)
     ep = np.zeros(W, np.uint32)
     co.generate(ccfg, cgen, seed, st, ep)
@@ -52,6 +52,72 @@ def test_python_and_c_statements_agree_bitwise(N, M, sort, nonl):
     st = _cross(N, M, sort, nonl)
     present = st.flags & po.F_PRESENT != 0
     assert (st.flags[present] & po.F_DONE_MASK != 0).mean() > 0.3      # episodes actually terminate
+
+
+@pytest.mark.parametrize("N,M,sort,nonl,mode,rvo", [(4, 3, 0, 0.6, 0, 0.6), (4, 3, 0, 0.0, 1, 0.0), (10, 9, 0, 0.5, 1, 0.5),
+                                                    (6, 3, 1, 0.7, 1, 0.3)])
+def test_python_and_c_agree_on_rvo_agents_and_the_box_generator(N, M, sort, nonl, mode, rvo):
+    """GEN v2 (rejection-sampled boxes) and the ORCA policy: both statements, bit for bit, incl. the infeasible-LP branch."""
+    st = _cross(N, M, sort, nonl, W=10, steps=120, seed=11, mode=mode, rvo=rvo)
+    pol = (st.flags >> po.F_POLICY_SHIFT) & 3
+    if rvo > 0:
+        assert (pol == po.POLICY_RVO).any()
+
+
+def test_rvo_agents_avoid_each_other_and_arrive():
+    """Behavioural known answer: in random box scenarios most RVO agents reach their goals and few collide -- and they
+    collide less often than the same agents running the non-cooperative policy in the SAME scenarios."""
+    cfg = po.OracleConfig()
+    tally = {po.POLICY_RVO: [0, 0, 0], po.POLICY_NONCOOP: [0, 0, 0]}
+    for policy in tally:
+        for wd in range(60):
+            gen = po.GenConfig(min_agents=3, max_agents=4, mode=1, nonlearning_fraction=1.0, static_fraction=0.0,
+                               rvo_fraction=1.0 if policy == po.POLICY_RVO else 0.0)
+            world = po.generate_world(9, wd, 0, cfg, gen)
+            world.agents[0].policy = policy                      # agent 0 too (the generator keeps it a learner)
+            for t in range(400):
+                world.step({})
+                if all(a.is_done for a in world.agents):
+                    break
+            for a in world.agents:
+                tally[policy][0] += a.is_at_goal
+                tally[policy][1] += a.in_collision
+                tally[policy][2] += 1
+    rvo, blind = tally[po.POLICY_RVO], tally[po.POLICY_NONCOOP]
+    assert rvo[0] / rvo[2] > 0.7 and rvo[1] / rvo[2] < 0.1, tally
+    assert rvo[1] < 0.5 * blind[1], tally
+    cfg = po.OracleConfig(max_agents=6, max_other_agents_observed=5)
+    # and the LP falls back to 'least penetration' when the half-planes admit nothing: a host boxed in by 3 approaching agents
+    host = po.Agent(0.0, 0.0, 5.0, 0.0, 0.5, 1.0, None, po.POLICY_RVO, cfg)
+    others = [po.Agent(1.2 * math.cos(a), 1.2 * math.sin(a), -math.cos(a), -math.sin(a), 0.5, 1.0, None, po.POLICY_EXTERNAL, cfg)
+              for a in (0.0, 2.1, 4.2)]
+    for o in others:
+        o.vel[:] = (-1.5 * o.pos[0], -1.5 * o.pos[1])
+    crowd = [host] + others
+    lines = po.orca_lines(0, crowd, cfg)
+    fail, vx, vy = po._lp_plane(lines, 1.0, 1.0, 0.0, False)
+    assert fail < len(lines)                                   # infeasible
+    vx, vy = po._lp_least_penetration(lines, fail, 1.0, vx, vy)
+    assert math.hypot(vx, vy) <= 1.0 + 1e-9
+    act = po.rvo_action(0, crowd, cfg)
+    assert 0.0 <= act[0] <= 1.0 + 1e-9 and abs(act[1]) <= math.pi / 6 + 1e-12
+
+
+def test_box_generator_keeps_its_separations():
+    cfg = po.OracleConfig(max_agents=10, max_other_agents_observed=9)
+    gen = po.GenConfig(min_agents=2, max_agents=10, mode=1)
+    sizes = []
+    for wd in range(300):
+        world = po.generate_world(3, wd, 0, cfg, gen)
+        sizes.append(len(world.agents))
+        for i, a in enumerate(world.agents):
+            assert np.hypot(*(a.goal - a.pos)) >= 1.0
+            lim = 8.0 * 1.01 ** 10
+            assert np.all(np.abs(a.pos) <= lim) and np.all(np.abs(a.goal) <= lim)
+            for b in world.agents[:i]:
+                assert np.hypot(*(a.pos - b.pos)) >= a.radius + b.radius + 0.2
+                assert np.hypot(*(a.goal - b.goal)) >= a.radius + b.radius + 0.2
+    assert min(sizes) == 2 and max(sizes) == 10
 
 
 def test_python_and_c_agree_max_turn_rate():
