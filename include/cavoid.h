@@ -62,7 +62,7 @@ extern "C" {
 #define CAVOID_F_WAS_IN_COLL 0x10u
 #define CAVOID_F_PRESENT 0x20u
 #define CAVOID_F_LEARNING 0x40u
-#define CAVOID_F_POLICY_SHIFT 8 /* bits 8..9: 0 external (learning), 1 static, 2 non-cooperative */
+#define CAVOID_F_POLICY_SHIFT 8 /* bits 8..9: 0 external (learning), 1 static, 2 non-cooperative, 3 RVO (ORCA) */
 #define CAVOID_F_DONE_MASK 0x07u
 
 enum { CAVOID_SORT_CLOSEST_LAST = 0, CAVOID_SORT_CLOSEST_FIRST = 1, CAVOID_SORT_TIME_TO_IMPACT = 2 };
@@ -116,7 +116,24 @@ typedef struct cavoid_cfg {
      * path (cf. the reference env's fixed test-case sets, NUM_TEST_CASES run-ws/config.yaml:136-138).
      * 0 = every episode runs the generator in-kernel with counter (gw, ep).  Default 65536. */
     int32_t gen_pool_size;
-    int32_t _pad2;
+    /* GEN v2 (gen_mode = 1): starts and goals uniform in a box (half side ~ U(gen_box_small) for worlds of fewer than
+     * gen_box_large_from agents, ~ U(gen_box_large) otherwise), agents placed one after the other by rejection sampling
+     * against those already placed (starts and goals at least r_i + r_j + getting_close_range apart, trips of at least
+     * gen_min_trip) -- the shape of upstream's get_testcase_random as recalled (TEST_CASE_FN, run-ws/config.yaml:281-283).
+     * cavoid_reset generates directly; auto-reset steps take GEN v2 scenarios from the pool (gen_pool_size > 0). */
+    int32_t gen_mode;
+    int32_t gen_box_large_from;   /* 5 */
+    uint32_t gen_pool_epoch;      /* the pool holds generator worlds 0..P-1 of THIS episode index (cavoid_pool_refresh) */
+    int32_t rvo_enabled;          /* agents with policy 3 may exist: the step kernels reserve the ORCA scratch (4 KiB of LDS per
+                                     wavefront and neighbour; max_agents <= 15, else CAVOID_EUNSUPPORTED) */
+    double gen_rvo_fraction;      /* of the scripted agents: P(static) = gen_static_fraction, P(RVO) = this, the rest non-cooperative */
+    double gen_box_small[2], gen_box_large[2];   /* (4,5), (6,8) */
+    double gen_min_trip;          /* 1.0 */
+    /* RVO scripted policy: ORCA over the other agents' positions and last velocities */
+    double rvo_time_horizon;      /* RVO_TIME_HORIZON 5.0   (run-ws/config.yaml:237-239) */
+    double rvo_collab_coeff;      /* RVO_COLLAB_COEFF 0.5   (run-ws/config.yaml:234-236) */
+    double rvo_radius_scale;      /* 1.05: the policy inflates every radius by 5 % */
+    double rvo_max_delta_heading; /* pi/6: larger turns are clipped and taken standing still */
 } cavoid_cfg;
 
 typedef struct cavoid_env cavoid_env;
@@ -137,6 +154,10 @@ int32_t cavoid_obs_width(const cavoid_env *env);
 /* seed the generator; episode (device u32 [W]) may be NULL = "before episode 0" for every world */
 int cavoid_seed(cavoid_env *env, uint64_t seed, const uint32_t *episode, void *stream);
 int cavoid_get_episode(cavoid_env *env, uint32_t *episode_out, void *stream);
+/* re-fill the scenario pool with generator worlds 0..P-1 of episode index `epoch` (cavoid_seed fills epoch
+ * cfg.gen_pool_epoch): a long run that wants fresh scenarios without the generator on the step's critical path
+ * refreshes the pool every so often.  No-op without a pool. */
+int cavoid_pool_refresh(cavoid_env *env, uint32_t epoch, void *stream);
 
 /* the agents of a world must be packed: CAVOID_F_PRESENT rows first (indices 0..n-1), absent rows after */
 int cavoid_set_state(cavoid_env *env, const double *state_f64, const float *state_f32, const uint32_t *flags, void *stream);

@@ -38,7 +38,12 @@ class CavoidCfg(C.Structure):
         ("gen_min_agents", C.c_int32), ("gen_max_agents", C.c_int32),
         ("gen_nonlearning_fraction", C.c_double), ("gen_static_fraction", C.c_double),
         ("gen_goal_jitter", C.c_double), ("gen_angle_jitter", C.c_double),
-        ("gen_pool_size", C.c_int32), ("_pad2", C.c_int32),
+        ("gen_pool_size", C.c_int32),
+        ("gen_mode", C.c_int32), ("gen_box_large_from", C.c_int32), ("gen_pool_epoch", C.c_uint32), ("rvo_enabled", C.c_int32),
+        ("gen_rvo_fraction", C.c_double), ("gen_box_small", C.c_double * 2), ("gen_box_large", C.c_double * 2),
+        ("gen_min_trip", C.c_double),
+        ("rvo_time_horizon", C.c_double), ("rvo_collab_coeff", C.c_double), ("rvo_radius_scale", C.c_double),
+        ("rvo_max_delta_heading", C.c_double),
     ]
 
 
@@ -80,6 +85,7 @@ SYMBOLS = [
     ("cavoid_obs_width", C.c_int32, [_P]),
     ("cavoid_seed", C.c_int, [_P, C.c_uint64, _P, _P]),
     ("cavoid_get_episode", C.c_int, [_P, _P, _P]),
+    ("cavoid_pool_refresh", C.c_int, [_P, C.c_uint32, _P]),
     ("cavoid_set_state", C.c_int, [_P, _P, _P, _P, _P]),
     ("cavoid_get_state", C.c_int, [_P, _P, _P, _P, _P]),
     ("cavoid_reset", C.c_int, [_P, _P, _P, _P]),

@@ -60,6 +60,8 @@ def make_cfg(config: Optional[EnvConfig] = None, **overrides) -> _lib.CavoidCfg:
             cfg.dynamics = _DYN[val]
         elif key == "sort_method" and isinstance(val, str):
             cfg.sort_method = _SORT[val]
+        elif key in ("gen_box_small", "gen_box_large"):
+            getattr(cfg, key)[0], getattr(cfg, key)[1] = float(val[0]), float(val[1])
         elif hasattr(cfg, key):
             setattr(cfg, key, val)
         else:
@@ -186,6 +188,11 @@ class BatchedCollisionAvoidanceEnv(object):
         if episode is not None:
             ep = self._want(episode, (self.num_worlds,), torch.int32, "episode")
         _lib.check(self._lib.cavoid_seed(self._h, self._seed, self._ptr(ep), self._stream()), "cavoid_seed")
+
+    def refresh_pool(self, epoch: int) -> None:
+        """Re-fill the scenario pool with the generator's worlds of episode index ``epoch`` (fresh scenarios for a long
+        run without the generator on the step's critical path)."""
+        _lib.check(self._lib.cavoid_pool_refresh(self._h, int(epoch) & 0xFFFFFFFF, self._stream()), "cavoid_pool_refresh")
 
     @property
     def episode(self) -> torch.Tensor:

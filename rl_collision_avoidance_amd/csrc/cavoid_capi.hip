@@ -85,6 +85,18 @@ extern "C" int cavoid_default_cfg(cavoid_cfg *c, int32_t max_agents, int32_t max
     c->gen_goal_jitter = 0.5;
     c->gen_angle_jitter = 0.25;
     c->gen_pool_size = 65536;
+    c->gen_mode = 0;
+    c->gen_box_large_from = 5;
+    c->gen_pool_epoch = 0;
+    c->rvo_enabled = 0;
+    c->gen_rvo_fraction = 0.0;
+    c->gen_box_small[0] = 4.0; c->gen_box_small[1] = 5.0;
+    c->gen_box_large[0] = 6.0; c->gen_box_large[1] = 8.0;
+    c->gen_min_trip = 1.0;
+    c->rvo_time_horizon = 5.0;          /* RVO_TIME_HORIZON  run-ws/config.yaml:237-239 */
+    c->rvo_collab_coeff = 0.5;          /* RVO_COLLAB_COEFF  run-ws/config.yaml:234-236 */
+    c->rvo_radius_scale = 1.05;
+    c->rvo_max_delta_heading = kPi / 6;
     return CAVOID_OK;
 }
 
@@ -97,6 +109,13 @@ static int validate(const cavoid_cfg *c) {
     if (!(c->dt > 0.0)) return CAVOID_EINVAL;
     if (c->gen_min_agents < 1 || c->gen_max_agents > c->max_agents || c->gen_min_agents > c->gen_max_agents) return CAVOID_EINVAL;
     if (c->gen_pool_size < 0 || c->gen_pool_size > (1 << 24)) return CAVOID_EINVAL;
+    if (c->gen_mode < 0 || c->gen_mode > 1) return CAVOID_EINVAL;
+    if (c->gen_mode == 1 && !(c->gen_box_small[0] > 0.0 && c->gen_box_small[1] >= c->gen_box_small[0] &&
+                              c->gen_box_large[0] > 0.0 && c->gen_box_large[1] >= c->gen_box_large[0] && c->gen_min_trip >= 0.0))
+        return CAVOID_EINVAL;
+    if (c->gen_rvo_fraction < 0.0 || c->gen_rvo_fraction > 1.0) return CAVOID_EINVAL;
+    if (c->gen_rvo_fraction > 0.0 && !c->rvo_enabled) return CAVOID_EINVAL;    /* the generator would create agents the step cannot drive */
+    if (c->rvo_enabled && !(c->rvo_time_horizon > 0.0 && c->rvo_radius_scale > 0.0)) return CAVOID_EINVAL;
     return CAVOID_OK;
 }
 
@@ -186,6 +205,13 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.horizon = cfg->sensing_horizon; k.max_turn_rate = cfg->max_turn_rate;
     k.gen_nonlearning = cfg->gen_nonlearning_fraction; k.gen_static = cfg->gen_static_fraction;
     k.gen_goal_jitter = cfg->gen_goal_jitter; k.gen_angle_jitter = cfg->gen_angle_jitter;
+    k.gen_rvo = cfg->gen_rvo_fraction; k.gen_min_trip = cfg->gen_min_trip;
+    k.gen_box_small_lo = cfg->gen_box_small[0]; k.gen_box_small_hi = cfg->gen_box_small[1];
+    k.gen_box_large_lo = cfg->gen_box_large[0]; k.gen_box_large_hi = cfg->gen_box_large[1];
+    k.gen_mode = cfg->gen_mode; k.gen_box_large_from = cfg->gen_box_large_from; k.pool_epoch = cfg->gen_pool_epoch;
+    k.rvo_enabled = cfg->rvo_enabled ? 1 : 0;
+    k.rvo_inv_horizon = cfg->rvo_enabled ? 1.0 / cfg->rvo_time_horizon : 0.0;
+    k.rvo_collab = cfg->rvo_collab_coeff; k.rvo_radius_scale = cfg->rvo_radius_scale; k.rvo_max_dh = cfg->rvo_max_delta_heading;
     k.max_other = cfg->max_other; k.width = 6 + 7 * cfg->max_other;
     k.sort_method = cfg->sort_method; k.dynamics = cfg->dynamics; k.actions_fp32 = cfg->actions_fp32;
     k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
@@ -218,14 +244,19 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     // obs tile (rows of width + 2 floats: the packed record is the widest row): the wavefront's rows in ONE pass when
     // the batch is latency bound or when they fit ~9 KiB; else several passes of a multiple of 4 rows, so that the LDS
     // footprint (and the wavefronts resident per CU) does not scale with N*(1+D)   [N=10: +7 % at saturation]
+    // ORCA scratch: two sets of N-1 lines (4 doubles) per lane, only when RVO agents may exist
+    k.rvo_lds_floats = cfg->rvo_enabled ? 64 * 2 * (N - 1) * 4 * 2 : 0;
     const int row_floats = k.width + 2;
     int tile_rows = (int)(9216 / ((size_t)row_floats * sizeof(float))) & ~3;
     if (tile_rows < 4) tile_rows = 4;
-    const bool one_pass_fits = (size_t)(lds_floats_block() + lds_floats_fixed() + lanes * row_floats + 4) * sizeof(float) <= 65536;
+    const bool one_pass_fits = (size_t)(lds_floats_block() + lds_floats_fixed() + k.rvo_lds_floats + lanes * row_floats + 4) * sizeof(float) <= 65536;
     if (tile_rows > lanes || (e->latency_mode && one_pass_fits)) tile_rows = lanes;
     if (const char *ov = std::getenv("CAVOID_TILE_ROWS")) { int v = std::atoi(ov); if (v >= 1 && v <= lanes) tile_rows = v; }
+    // one wavefront must fit the 64 KiB a workgroup may ask for: with the ORCA scratch of a large N the tile shrinks
+    auto wave_bytes = [&](int rows) { return (size_t)(lds_floats_fixed() + k.rvo_lds_floats + ((rows * row_floats + 3) & ~3)) * sizeof(float); };
+    while (tile_rows > 4 && wave_bytes(tile_rows) + lds_floats_block() * sizeof(float) > 65536) tile_rows -= 4;
     k.tile_rows = tile_rows;
-    const size_t per_wave = (size_t)(lds_floats_fixed() + ((tile_rows * row_floats + 3) & ~3)) * sizeof(float);
+    const size_t per_wave = wave_bytes(tile_rows);
     int wpb = (int)(((size_t)65536 - lds_floats_block() * sizeof(float)) / per_wave);
     if (wpb < 1) { cavoid_destroy(e); return CAVOID_EUNSUPPORTED; }
     if (wpb > 4) wpb = 4;
@@ -250,11 +281,13 @@ extern "C" int32_t cavoid_obs_width(const cavoid_env *e) { return e ? e->k.width
 
 template <int MODE>
 static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    if ((MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET) && e->k.rvo_enabled)   // the ORCA instantiations: cavoid_rvo.hip
+        return cavoid_launch_rvo(e, MODE, io, s, ev_start, ev_stop);
     return launch_on<MODE>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
 }
 
 // (re)fill the scenario pool for the current seed: the RESET kernel run over the pool buffer as
-// worlds 0..P-1, episode 0, generator in-kernel
+// worlds 0..P-1 of episode k.pool_epoch, generator (GEN v1 or v2) in-kernel
 static int fill_pool(cavoid_env *e, hipStream_t s) {
     if (e->pool_size <= 0) return CAVOID_OK;
     HIP_TRY(hipMemsetAsync(e->pool_episode, 0xFF, (size_t)e->pool_size * sizeof(uint32_t), s));
@@ -278,6 +311,13 @@ extern "C" int cavoid_seed(cavoid_env *e, uint64_t seed, const uint32_t *episode
     if (episode) HIP_TRY(hipMemcpyAsync(e->st.episode, episode, (size_t)e->W * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     else HIP_TRY(hipMemsetAsync(e->st.episode, 0xFF, (size_t)e->W * sizeof(uint32_t), s));
     return fill_pool(e, s);
+}
+
+extern "C" int cavoid_pool_refresh(cavoid_env *e, uint32_t epoch, void *stream) {
+    if (!e) return CAVOID_EINVAL;
+    e->k.pool_epoch = epoch;
+    e->cfg.gen_pool_epoch = epoch;
+    return fill_pool(e, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cavoid_get_episode(cavoid_env *e, uint32_t *out, void *stream) {
@@ -379,6 +419,7 @@ static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64
                             hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
     if (n_steps < 1 || action_stride < 0) return CAVOID_EINVAL;
+    if (e->cfg.gen_mode == 1 && e->pool_size <= 0) return CAVOID_EINVAL;   // GEN v2 restarts come from the scenario pool
     io.actions = actions;
     io.action_stride = action_stride;
     io.n_steps = n_steps;

@@ -51,12 +51,17 @@ struct KCfg {
     double dt, near_goal_sq, near_goal, budget_offset, max_time_ratio, collision_dist, close_range;
     double r_goal, r_coll, r_close, r_step, close_slope, clip_lo, clip_hi, horizon, max_turn_rate;
     double gen_nonlearning, gen_static, gen_goal_jitter, gen_angle_jitter;
+    double gen_rvo, gen_box_small_lo, gen_box_small_hi, gen_box_large_lo, gen_box_large_hi, gen_min_trip;
+    double rvo_inv_horizon, rvo_collab, rvo_radius_scale, rvo_max_dh;
     int32_t max_other, width, sort_method, dynamics, actions_fp32, timeout_enabled, num_actions;
     int32_t gen_min_agents, gen_max_agents;
+    int32_t gen_mode, gen_box_large_from, rvo_enabled;
+    uint32_t pool_epoch;         // the pool holds generator worlds 0..P-1 of this episode index
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
     int32_t wpw;                 // worlds per wavefront, 1..floor(64/N): small batches spread over more, emptier wavefronts
+    int32_t rvo_lds_floats;      // per-wavefront LDS floats of the ORCA line scratch (0 unless rvo_enabled)
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
@@ -174,18 +179,41 @@ __device__ __forceinline__ void sincos_bounded(double x, double *sn, double *cs)
     *cs = ((q + 1) & 2) ? -c_out : c_out;
 }
 
-// GEN v1 scenario generator (E2; own specification, see oracle/cavoid_oracle.py generate_world)
+// scripted-policy draw shared by both generators (oracle: _draw_policy)
+__device__ __forceinline__ uint32_t draw_policy(const KCfg &c, const U4 &q, int i) {
+    if (i > 0 && u01(q.z) < c.gen_nonlearning) {
+        const double u = u01(q.w);
+        if (u < c.gen_static) return 1u;
+        return u < c.gen_static + c.gen_rvo ? 3u : 2u;
+    }
+    return 0u;
+}
+
+// heading at the goal, time budget, flags of a freshly placed agent (oracle: Agent.__init__ / place_agent)
+__device__ __forceinline__ void finish_agent(const KCfg &c, uint32_t pol, Agent &a) {
+    const double tx = (double)a.gx - a.px, ty = (double)a.gy - a.py;
+    const double dxg = a.px - (double)a.gx, dyg = a.py - (double)a.gy;
+    const double straight = (sqrt(dxg * dxg + dyg * dyg) - c.budget_offset) / (double)a.pref;   // U11 (x - 0.0 is exact)
+    a.heading = atan2(ty, tx);
+    a.t_rem = fmax(c.max_time_ratio * straight, c.dt);
+    a.vx = a.vy = 0.0;
+    a.speed = 0.0f;
+    a.flags = CAVOID_F_PRESENT | (pol == 0u ? CAVOID_F_LEARNING : 0u) | (pol << CAVOID_F_POLICY_SHIFT);
+}
+
+__device__ __forceinline__ void absent_agent(Agent &a) {
+    a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
+    a.gx = a.gy = a.radius = a.pref = a.speed = 0.0f;
+    a.flags = 0u;
+}
+
+// GEN v1 scenario generator (E2; own specification, see oracle/cavoid_oracle.py generate_world): a ring, antipodal goals
 template <int N>
 __device__ __forceinline__ void generate_agent(const KCfg &c, uint32_t gw, uint32_t ep, int i, Agent &a) {
     const U4 r = philox4x32(gw, ep, 0u, 0u, c.seed_lo, c.seed_hi);
     const int span = c.gen_max_agents - c.gen_min_agents + 1;
     const int n = c.gen_min_agents + (int)(r.x % (uint32_t)span);
-    if (i >= n) {
-        a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
-        a.gx = a.gy = a.radius = a.pref = a.speed = 0.0f;
-        a.flags = 0u;
-        return;
-    }
+    if (i >= n) { absent_agent(a); return; }
     const double base = fmax(4.0, 0.7 * n), ring = base * (1.0 + u01(r.y)), phase = u01(r.z);
     const U4 p = philox4x32(gw, ep, 1u, (uint32_t)i, c.seed_lo, c.seed_hi);
     const U4 q = philox4x32(gw, ep, 2u, (uint32_t)i, c.seed_lo, c.seed_hi);
@@ -199,16 +227,58 @@ __device__ __forceinline__ void generate_agent(const KCfg &c, uint32_t gw, uint3
     a.py = ring * sn;
     a.gx = (float)(-a.px + (u01(q.x) - 0.5) * 2.0 * c.gen_goal_jitter);
     a.gy = (float)(-a.py + (u01(q.y) - 0.5) * 2.0 * c.gen_goal_jitter);
-    uint32_t pol = 0u;
-    if (i > 0 && u01(q.z) < c.gen_nonlearning) pol = u01(q.w) < c.gen_static ? 1u : 2u;
-    const double tx = (double)a.gx - a.px, ty = (double)a.gy - a.py;
-    const double dxg = a.px - (double)a.gx, dyg = a.py - (double)a.gy;
-    const double straight = (sqrt(dxg * dxg + dyg * dyg) - c.budget_offset) / (double)a.pref;   // U11 (x - 0.0 is exact)
-    a.heading = atan2(ty, tx);
-    a.t_rem = fmax(c.max_time_ratio * straight, c.dt);
-    a.vx = a.vy = 0.0;
-    a.speed = 0.0f;
-    a.flags = CAVOID_F_PRESENT | (pol == 0u ? CAVOID_F_LEARNING : 0u) | (pol << CAVOID_F_POLICY_SHIFT);
+    finish_agent(c, draw_policy(c, q, i), a);
+}
+
+// GEN v2 (E2; oracle: generate_world, mode 1): uniform boxes, the agents of a world placed ONE AFTER THE OTHER by
+// rejection sampling against those already placed.  Wave-cooperative (MODE_RESET only, every lane of the wavefront
+// calls it): in round k the lanes holding agent k of a `fresh` world draw until accepted, reading the agents 0..k-1 of
+// their world from the LDS staging arrays (starts in lds_px / lds_py, goals in lds_vx / lds_vy, radii in lds_r), then
+// publish their own placement; the (possibly grown) box side travels to the next round by a lane shuffle.
+template <int N>
+__device__ __forceinline__ void generate_world_v2(const KCfg &c, uint32_t gw, uint32_t ep, int i, int base, int lane, bool fresh,
+                                                  double *lds_px, double *lds_py, double *lds_gx, double *lds_gy, float *lds_r,
+                                                  Agent &a) {
+    const U4 r = philox4x32(gw, ep, 0u, 0u, c.seed_lo, c.seed_hi);
+    const int span = c.gen_max_agents - c.gen_min_agents + 1;
+    const int n = c.gen_min_agents + (int)(r.x % (uint32_t)span);
+    const double lo = n < c.gen_box_large_from ? c.gen_box_small_lo : c.gen_box_large_lo;
+    const double hi = n < c.gen_box_large_from ? c.gen_box_small_hi : c.gen_box_large_hi;
+    double side = lo + (hi - lo) * u01(r.y);
+    const U4 p = philox4x32(gw, ep, 1u, (uint32_t)i, c.seed_lo, c.seed_hi);
+    const U4 q = philox4x32(gw, ep, 2u, (uint32_t)i, c.seed_lo, c.seed_hi);
+    const float radius = (float)(0.2 + 0.6 * u01(p.x));
+    const float pref = (float)(0.5 + 1.5 * u01(p.y));
+    if (fresh) absent_agent(a);
+    for (int round = 0; round < N; ++round) {                  // wave-uniform
+        // the box side agent round-1 left behind (a crowded box grows), straight from that lane's register
+        const double side_prev = round > 0 ? __shfl(side, base + round - 1) : side;
+        if (fresh && i == round && i < n) {
+            side = side_prev;
+            double sx = 0.0, sy = 0.0;
+            float gx = 0.f, gy = 0.f;
+            for (int attempt = 0;;) {
+                const U4 d = philox4x32(gw, ep, 3u + (uint32_t)attempt, (uint32_t)i, c.seed_lo, c.seed_hi);
+                sx = side * (2.0 * u01(d.x) - 1.0); sy = side * (2.0 * u01(d.y) - 1.0);
+                gx = (float)(side * (2.0 * u01(d.z) - 1.0)); gy = (float)(side * (2.0 * u01(d.w) - 1.0));
+                const double tx = (double)gx - sx, ty = (double)gy - sy;
+                bool ok = sqrt(tx * tx + ty * ty) >= c.gen_min_trip;
+                for (int j = 0; j < round; ++j) {
+                    const double margin = ((double)radius + (double)lds_r[base + j]) + c.close_range;
+                    const double ax = sx - lds_px[base + j], ay = sy - lds_py[base + j];
+                    const double bx = (double)gx - lds_gx[base + j], by = (double)gy - lds_gy[base + j];
+                    if (sqrt(ax * ax + ay * ay) < margin || sqrt(bx * bx + by * by) < margin) ok = false;
+                }
+                ++attempt;
+                if (ok || attempt >= 100) break;
+                if (attempt % 10 == 0) side = side * 1.01;
+            }
+            a.px = sx; a.py = sy; a.gx = gx; a.gy = gy; a.radius = radius; a.pref = pref;
+            finish_agent(c, draw_policy(c, q, i), a);
+            lds_px[lane] = sx; lds_py[lane] = sy; lds_gx[lane] = (double)gx; lds_gy[lane] = (double)gy; lds_r[lane] = radius;
+        }
+        wave_lds_sync();
+    }
 }
 
 // Ego frame of one host (x axis -> goal).  (tx, ty) is the un-normalised goal direction: the
@@ -654,6 +724,151 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, 
     }
 }
 
+// ---- RVO scripted policy: ORCA, van den Berg et al., "Reciprocal n-body collision avoidance"
+// (ISRR 2009) -- one half-plane per neighbour, the 2-D linear programme of its section 5.2, and the least-penetration
+// programme when the half-planes admit no velocity.  float64, neighbours in agent-index order: the operation sequence of
+// oracle/cavoid_oracle.py (orca_lines, _lp_on_line, _lp_plane, _lp_least_penetration, rvo_action).  The lines live in
+// wave-private LDS (a lane indexes them dynamically): line k of set s of a lane at rvo[((s*(N-1) + k)*64 + lane)*4 ..+3].
+constexpr double kRvoEps = 1e-5;
+__device__ __forceinline__ double det2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
+
+struct Line { double px, py, dx, dy; };
+template <int N>
+struct RvoLines {
+    double *mem; int lane;
+    __device__ __forceinline__ Line get(int set, int k) const {
+        const double *p = mem + ((size_t)(set * (N - 1) + k) * 64 + lane) * 4;
+        return Line{p[0], p[1], p[2], p[3]};
+    }
+    __device__ __forceinline__ void put(int set, int k, const Line &l) const {
+        double *p = mem + ((size_t)(set * (N - 1) + k) * 64 + lane) * 4;
+        p[0] = l.px; p[1] = l.py; p[2] = l.dx; p[3] = l.dy;
+    }
+};
+
+template <int N>
+__device__ __forceinline__ bool lp_on_line(const RvoLines<N> &L, int set, int k, double radius, double ox, double oy, bool direction_opt,
+                                           double &x, double &y) {
+    const Line l = L.get(set, k);
+    const double dot = l.px * l.dx + l.py * l.dy, disc = dot * dot + radius * radius - (l.px * l.px + l.py * l.py);
+    if (disc < 0.0) return false;
+    const double root = sqrt(disc);
+    double t_lo = -dot - root, t_hi = -dot + root;
+    for (int i = 0; i < k; ++i) {
+        const Line o = L.get(set, i);
+        const double den = det2(l.dx, l.dy, o.dx, o.dy), num = det2(o.dx, o.dy, l.px - o.px, l.py - o.py);
+        if (fabs(den) <= kRvoEps) { if (num < 0.0) return false; continue; }
+        const double t = num / den;
+        if (den >= 0.0) t_hi = fmin(t_hi, t); else t_lo = fmax(t_lo, t);
+        if (t_lo > t_hi) return false;
+    }
+    double t;
+    if (direction_opt) t = (ox * l.dx + oy * l.dy > 0.0) ? t_hi : t_lo;
+    else { t = l.dx * (ox - l.px) + l.dy * (oy - l.py); t = t < t_lo ? t_lo : (t > t_hi ? t_hi : t); }
+    x = l.px + t * l.dx; y = l.py + t * l.dy;
+    return true;
+}
+
+template <int N>
+__device__ __forceinline__ int lp_plane(const RvoLines<N> &L, int set, int m, double radius, double ox, double oy, bool direction_opt,
+                                        double &x, double &y) {
+    if (direction_opt) { x = ox * radius; y = oy * radius; }
+    else if (ox * ox + oy * oy > radius * radius) { const double nn = sqrt(ox * ox + oy * oy); x = ox / nn * radius; y = oy / nn * radius; }
+    else { x = ox; y = oy; }
+    for (int k = 0; k < m; ++k) {
+        const Line l = L.get(set, k);
+        if (det2(l.dx, l.dy, l.px - x, l.py - y) > 0.0) {
+            double nx, ny;
+            if (!lp_on_line<N>(L, set, k, radius, ox, oy, direction_opt, nx, ny)) return k;
+            x = nx; y = ny;
+        }
+    }
+    return m;
+}
+
+template <int N>
+__device__ __forceinline__ void lp_least_penetration(const RvoLines<N> &L, int m, int begin, double radius, double &x, double &y) {
+    double distance = 0.0;
+    for (int k = begin; k < m; ++k) {
+        const Line l = L.get(0, k);
+        if (det2(l.dx, l.dy, l.px - x, l.py - y) > distance) {
+            int np = 0;
+            for (int j = 0; j < k; ++j) {
+                const Line o = L.get(0, j);
+                const double den = det2(l.dx, l.dy, o.dx, o.dy);
+                double nx, ny;
+                if (fabs(den) <= kRvoEps) {
+                    if (l.dx * o.dx + l.dy * o.dy > 0.0) continue;
+                    nx = 0.5 * (l.px + o.px); ny = 0.5 * (l.py + o.py);
+                } else {
+                    const double t = det2(o.dx, o.dy, l.px - o.px, l.py - o.py) / den;
+                    nx = l.px + t * l.dx; ny = l.py + t * l.dy;
+                }
+                const double fx = o.dx - l.dx, fy = o.dy - l.dy, fn = sqrt(fx * fx + fy * fy);
+                L.put(1, np, Line{nx, ny, fx / fn, fy / fn});
+                ++np;
+            }
+            double nx, ny;
+            if (lp_plane<N>(L, 1, np, radius, -l.dy, l.dx, true, nx, ny) >= np) { x = nx; y = ny; }
+            distance = det2(l.dx, l.dy, l.px - x, l.py - y);
+        }
+    }
+}
+
+// [speed, delta_heading] of the RVO agent in this lane.  lds_* hold the PRE-move state of the wavefront's agents (positions,
+// last velocities, radii; radius < 0 marks an absent row).  Called by the lanes that hold a running RVO agent only.
+template <int N>
+__device__ __forceinline__ void rvo_action(const KCfg &c, const Agent &a, int i, int base, int lane, const double *lds_px,
+                                           const double *lds_py, const double *lds_vx, const double *lds_vy, const float *lds_r,
+                                           double *rvo_mem, double &a0, double &a1) {
+    const RvoLines<N> L{rvo_mem, lane};
+    const double hvx = lds_vx[lane], hvy = lds_vy[lane];
+    int m = 0;
+    for (int jj = 0; jj < N; ++jj) {
+        const int j = base + jj;
+        const float rjf = lds_r[j];
+        if (jj == i || rjf < 0.0f) continue;
+        const double rpx = lds_px[j] - a.px, rpy = lds_py[j] - a.py, rvx = hvx - lds_vx[j], rvy = hvy - lds_vy[j];
+        const double dist_sq = rpx * rpx + rpy * rpy;
+        const double comb = c.rvo_radius_scale * (double)a.radius + c.rvo_radius_scale * (double)rjf, comb_sq = comb * comb;
+        double dx, dy, ucx, ucy;
+        if (dist_sq > comb_sq) {
+            const double wx = rvx - c.rvo_inv_horizon * rpx, wy = rvy - c.rvo_inv_horizon * rpy;
+            const double w_sq = wx * wx + wy * wy, dot1 = wx * rpx + wy * rpy;
+            if (dot1 < 0.0 && dot1 * dot1 > comb_sq * w_sq) {
+                const double w_len = sqrt(w_sq), ux = wx / w_len, uy = wy / w_len, scale = comb * c.rvo_inv_horizon - w_len;
+                dx = uy; dy = -ux; ucx = scale * ux; ucy = scale * uy;
+            } else {
+                const double leg = sqrt(dist_sq - comb_sq);
+                if (det2(rpx, rpy, wx, wy) > 0.0) { dx = (rpx * leg - rpy * comb) / dist_sq; dy = (rpx * comb + rpy * leg) / dist_sq; }
+                else { dx = -(rpx * leg + rpy * comb) / dist_sq; dy = -(-rpx * comb + rpy * leg) / dist_sq; }
+                const double dot2 = rvx * dx + rvy * dy;
+                ucx = dot2 * dx - rvx; ucy = dot2 * dy - rvy;
+            }
+        } else {
+            const double inv_dt = 1.0 / c.dt, wx = rvx - inv_dt * rpx, wy = rvy - inv_dt * rpy;
+            const double w_len = sqrt(wx * wx + wy * wy), ux = wx / w_len, uy = wy / w_len, scale = comb * inv_dt - w_len;
+            dx = uy; dy = -ux; ucx = scale * ux; ucy = scale * uy;
+        }
+        L.put(0, m, Line{hvx + c.rvo_collab * ucx, hvy + c.rvo_collab * ucy, dx, dy});
+        ++m;
+    }
+    const double gx = (double)a.gx - a.px, gy = (double)a.gy - a.py, gn = sqrt(gx * gx + gy * gy);
+    const double scale = gn > 0.0 ? (double)a.pref / gn : 0.0;
+    double vx, vy;
+    const int fail = lp_plane<N>(L, 0, m, (double)a.pref, scale * gx, scale * gy, false, vx, vy);
+    if (fail < m) lp_least_penetration<N>(L, m, fail, (double)a.pref, vx, vy);
+    double speed = sqrt(vx * vx + vy * vy);
+    double delta = 0.0;
+    if (speed > 0.0) {
+        delta = atan2(vy, vx) - a.heading;
+        while (delta >= kPi) delta -= 2.0 * kPi;
+        while (delta < -kPi) delta += 2.0 * kPi;
+    }
+    if (fabs(delta) > c.rvo_max_dh) { delta = copysign(c.rvo_max_dh, delta); speed = 0.0; }
+    a0 = speed; a1 = delta;
+}
+
 enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESET = 3, MODE_STEP_AUTORESET_PF = 4, MODE_STEP_AUTORESET_N = 5 };
 
 #ifndef CAVOID_OCC_LARGE_N
@@ -671,7 +886,9 @@ enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESE
 // MODE_STEP_AUTORESET_PF the same with the NEXT episode's pool record of every lane held in registers (loaded with the
 //                        state, re-loaded after a restart): latency mode for small batches, where a wavefront is alone on
 //                        its SIMD and a restart must not cost a dependent trip to memory (may use more registers).
-template <int N, int MODE>
+// RVO: the instantiation can drive policy-3 (ORCA) agents.  A separate instantiation because the linear programmes,
+// inlined into the step, cost every other configuration registers (N = 10: +40 VGPRs and scratch) for code it never runs.
+template <int N, int MODE, bool RVO>
 // (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
 //  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
 __global__ void __launch_bounds__(256, (MODE == MODE_STEP_AUTORESET_PF ? 2 : (N <= CAVOID_OCC4_MAX_N ? 4 : CAVOID_OCC_LARGE_N)))
@@ -683,13 +900,14 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int width = c.width, ostride = io.obs ? io.obs_stride : width;
     const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
-    const int per_wave_floats = lds_floats_fixed() + tile_floats;
+    const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
     double *lds_tab = reinterpret_cast<double *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
     double *lds_px = reinterpret_cast<double *>(wbase);
     double *lds_py = lds_px + 64, *lds_vx = lds_py + 64, *lds_vy = lds_vx + 64;
     float *lds_r = reinterpret_cast<float *>(lds_vy + 64);
     float *tile = lds_r + 64;
+    double *rvo_mem = reinterpret_cast<double *>(tile + tile_floats);   // ORCA lines (only with c.rvo_enabled)
 
     const int wpw = c.wpw, lanes_used = wpw * N;          // worlds / lanes this wavefront really owns
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
@@ -728,7 +946,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
         }
         if (!fresh) {
             load_agent(s, a_idx, a);
-            if (!kStepping) a.speed = s.speed[a_idx];
+            if (!kStepping || RVO) a.speed = s.speed[a_idx];   // (RVO agents read the others' last velocities)
         }
         if (kStepping) {
             if (io.cont) { c0 = io.cont[2 * a_idx]; c1 = io.cont[2 * a_idx + 1]; }
@@ -766,7 +984,11 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     const bool present_first = active && (a.flags & CAVOID_F_PRESENT);   // presence changes only at a restart
 
     if (MODE == MODE_RESET) {
-        if (fresh) new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
+        if (io.pool_out) episode = c.pool_epoch;               // pool fill: generator worlds 0..P-1 of the pool's epoch
+        if (c.gen_mode == 1 && c.pool_size == 0)               // GEN v2 needs the whole wavefront (sequential placement)
+            generate_world_v2<N>(c, (uint32_t)(c.world_offset + w), episode, i, base, lane, fresh, lds_px, lds_py, lds_vx, lds_vy,
+                                 lds_r, a);
+        else if (fresh) new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
     }
     if (MODE == MODE_OBSERVE || MODE == MODE_RESET) {
         double sn, cs;
@@ -812,6 +1034,19 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
                 a0 = (double)a.pref;
                 a1 = -e0.heading_ego;
             }
+        }
+        if (RVO && __ballot(present_in && !done_in && pol == 3u) != 0ull) {   // RVO agents in this tile
+            // stage the PRE-move state of every agent: position, last velocity (speed along the heading), radius
+            double sn, cs;
+            sincos_bounded(a.heading, &sn, &cs);
+            lds_px[lane] = a.px; lds_py[lane] = a.py;
+            lds_vx[lane] = present_in ? (double)a.speed * cs : 0.0;
+            lds_vy[lane] = present_in ? (double)a.speed * sn : 0.0;
+            lds_r[lane] = present_in ? a.radius : -1.0f;
+            wave_lds_sync();
+            if (present_in && !done_in && pol == 3u)
+                rvo_action<N>(c, a, i, base, lane, lds_px, lds_py, lds_vx, lds_vy, lds_r, rvo_mem, a0, a1);
+            wave_lds_sync();
         }
         if (c.actions_fp32) { a0 = (double)(float)a0; a1 = (double)(float)a1; }
         // ---- E5 dynamics (computed by every lane, committed only by agents still running) ------------

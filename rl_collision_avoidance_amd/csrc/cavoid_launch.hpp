@@ -31,19 +31,19 @@ struct cavoid_env {
 
 namespace cavoid {
 
-template <int MODE>
+template <int MODE, bool RVO = false>
 static inline int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int grid_x, const KIO &io, hipStream_t s,
                      hipEvent_t ev_start, hipEvent_t ev_stop) {
     const dim3 grid(grid_x), block(64 * e->waves_per_block);
     // dynamic LDS: the action table + per wavefront the staging arrays and an obs tile of this launch's row width
     const int row = io.obs ? io.obs_stride : k.width;
-    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed() + ((k.tile_rows * row + 3) & ~3))) * sizeof(float);
+    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed() + k.rvo_lds_floats + ((k.tile_rows * row + 3) & ~3))) * sizeof(float);
 #define CAVOID_CASE(NN) \
     case NN:                                                                                                            \
         if (ev_start || ev_stop)                                                                                        \
-            hipExtLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, ev_start, ev_stop, 0, k, st, e->pool, io); \
+            hipExtLaunchKernelGGL((env_kernel<NN, MODE, RVO>), grid, block, lds, s, ev_start, ev_stop, 0, k, st, e->pool, io); \
         else /* plain launch: capturable into a hipGraph */                                                             \
-            hipLaunchKernelGGL((env_kernel<NN, MODE>), grid, block, lds, s, k, st, e->pool, io);                         \
+            hipLaunchKernelGGL((env_kernel<NN, MODE, RVO>), grid, block, lds, s, k, st, e->pool, io);                         \
         break;
     switch (e->cfg.max_agents) {
 #ifdef CAVOID_DEV_ONLY_N   /* development builds: instantiate two sizes only (compile time) */
@@ -65,3 +65,5 @@ static inline int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int 
 
 // multi-step auto-reset launch (cavoid_multistep.hip): prefetch != 0 -> MODE_STEP_AUTORESET_PF, else MODE_STEP_AUTORESET_N
 int cavoid_launch_multistep(cavoid_env *e, const cavoid::KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
+// any stepping mode for an env with rvo_enabled (cavoid_rvo.hip: the instantiations that carry the ORCA policy)
+int cavoid_launch_rvo(cavoid_env *e, int mode, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);

@@ -8,6 +8,7 @@
 using namespace cavoid;
 
 int cavoid_launch_multistep(cavoid_env *e, const KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (e->k.rvo_enabled) return cavoid_launch_rvo(e, prefetch ? MODE_STEP_AUTORESET_PF : MODE_STEP_AUTORESET_N, io, s, ev_start, ev_stop);
     if (prefetch) return launch_on<MODE_STEP_AUTORESET_PF>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
     return launch_on<MODE_STEP_AUTORESET_N>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
 }

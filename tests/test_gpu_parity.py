@@ -509,3 +509,86 @@ def test_exact_sort_ties_take_the_generic_rank_path(sort):
         acts = np.full((W, N), 2, np.int32)
         _compare_step(("ties", sort, t), env.step(torch.from_numpy(acts).cuda()), co.step(ocfg, st, acts), env, st)
     env.close()
+
+
+@pytest.mark.parametrize("N,M,mode,nonl,static,rvo,gen_min,sort", [
+    (4, None, 1, 0.6, 0.2, 0.6, 2, 0),       # box scenarios, RVO + static + non-coop + learners
+    (4, None, 0, 0.7, 0.0, 1.0, 4, 1),       # ring scenarios (head-on, crowded centre): ORCA's infeasible branch
+    (10, None, 1, 0.5, 0.2, 0.5, 2, 0),      # configs[3] shape
+    (6, 3, 1, 0.4, 0.3, 0.4, 3, 2),
+    (15, None, 1, 0.3, 0.3, 0.5, 9, 0),      # the largest world the ORCA scratch fits
+])
+def test_rvo_agents_and_box_generator_parity(N, M, mode, nonl, static, rvo, gen_min, sort):
+    """RVO (ORCA) scripted agents and the box-style generator GEN v2, HIP vs the float64 oracle:
+    generated worlds bit-exact (statics) / 1e-12 (float64 state), trajectories to the usual bar."""
+    W, steps, seed = 300, 120, 23
+    ocfg, _ = _oracle(N, M, sort_method=sort)
+    ogen = co.default_gen(gen_min, N, nonl, static, mode=mode, rvo_fraction=rvo)
+    env = _env(W, N, M, seed=seed, sort_method=sort, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl,
+               gen_static_fraction=static, gen_rvo_fraction=rvo, rvo_enabled=1, gen_mode=mode, gen_pool_size=0)
+    obs0 = env.reset().cpu().numpy()
+    st = co.State.empty(W, N)
+    co.generate(ocfg, ogen, seed, st, np.zeros(W, np.uint32))
+    f64, f32, fl = _pull(env)
+    assert np.array_equal(fl, st.flags) and np.array_equal(f32, st.f32)
+    np.testing.assert_allclose(f64, st.f64, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(obs0, co.observe(ocfg, st), rtol=0, atol=OBS_TOL)
+    assert ((st.flags >> 8) & 3 == 3).sum() > 20                   # RVO agents exist
+    _push(env, st)                                                  # continue from the oracle's (1e-16 different) headings
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = _goal_seeking_actions(rng, W, N)
+        out = env.step(torch.from_numpy(acts).cuda())
+        _compare_step(("rvo", N, mode, t), out, co.step(ocfg, st, acts), env, st)
+    rvo_agents = (st.flags >> 8) & 3 == 3
+    assert (st.flags[rvo_agents] & 1).mean() > 0.4                 # most RVO agents arrive
+    env.close()
+
+
+def test_box_generator_through_the_pool_and_refresh():
+    """GEN v2 restarts come from the scenario pool; cavoid_pool_refresh re-fills it with the generator's next epoch."""
+    W, N, seed, pool = 400, 4, 31, 200
+    ocfg, _ = _oracle(N)
+    env = _env(W, N, seed=seed, gen_min_agents=2, gen_mode=1, gen_pool_size=pool, gen_nonlearning_fraction=0.5,
+               gen_rvo_fraction=0.5, rvo_enabled=1)
+    env.reset()
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    for epoch in (0, 7):
+        ogen = co.default_gen(2, N, 0.5, pool_size=pool, mode=1, rvo_fraction=0.5, pool_epoch=epoch)
+        if epoch:
+            env.refresh_pool(epoch)
+            env.seed(seed)                                          # (re-seeding keeps the refreshed epoch)
+            env.refresh_pool(epoch)
+            env.reset()
+            ep[:] = 0
+        co.generate(ocfg, ogen, seed, st, ep)
+        f64, f32, fl = _pull(env)
+        assert np.array_equal(fl, st.flags) and np.array_equal(f32, st.f32), epoch
+        rng = np.random.default_rng(epoch)
+        for t in range(150):
+            acts = _goal_seeking_actions(rng, W, N)
+            out = env.step_autoreset(torch.from_numpy(acts).cuda())
+            _compare_step(("pool", epoch, t), out, co.step_autoreset(ocfg, ogen, seed, st, ep, acts), env, st)
+        assert (ep >= 1).mean() > 0.5
+    # a multi-step launch over the same pool equals single steps
+    twin = _env(W, N, seed=seed, gen_min_agents=2, gen_mode=1, gen_pool_size=pool, gen_nonlearning_fraction=0.5,
+                gen_rvo_fraction=0.5, rvo_enabled=1)
+    twin.reset(); env.seed(seed); env.refresh_pool(0); twin.refresh_pool(0); env.reset()
+    acts = torch.from_numpy(np.random.default_rng(1).integers(0, 11, size=(40, W, N)).astype(np.int32)).cuda()
+    env.step_autoreset_n(acts)
+    for t in range(40):
+        twin.step_autoreset(acts[t])
+    assert torch.equal(env.obs, twin.obs) and torch.equal(env.episode, twin.episode)
+    for x, y in zip(env.get_state(), twin.get_state()):
+        assert torch.equal(x, y)
+    # without a pool GEN v2 cannot restart inside the step, and 16-agent worlds have no room for the ORCA scratch: codes, not crashes
+    from rl_collision_avoidance_amd import _lib
+    with pytest.raises(_lib.CavoidError):
+        _env(8, 16, rvo_enabled=1)
+    bare = _env(8, N, gen_mode=1, gen_pool_size=0)
+    bare.reset()
+    with pytest.raises(_lib.CavoidError):
+        bare.step_autoreset(torch.zeros((8, N), dtype=torch.int32, device="cuda"))
+    for e in (env, twin, bare):
+        e.close()
