@@ -245,6 +245,7 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
     is doubled (MI355X_MICROARCH.md, HBM section).  Returns None when rocprofv3 is not usable here."""
     import csv
     import glob
+    import re
     import shutil
     import subprocess
     import tempfile
@@ -264,9 +265,9 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
             for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        name = row["Kernel_Name"]
-                        if "env_kernel<%d, " % N in name and ("%d, 1>" % N in name or "%d, 4>" % N in name) \
-                                and row["Counter_Name"] == ctr:
+                        # the stepping instantiations: env_kernel<N, MODE in {1 single step, 4 / 5 step loop}, RVO>
+                        hit = re.search(r"env_kernel<%d, (\d+)" % N, row["Kernel_Name"])
+                        if hit and hit.group(1) in ("1", "4", "5") and row["Counter_Name"] == ctr:
                             total += float(row["Counter_Value"])
                             n += 1
             if n == 0:
@@ -394,7 +395,7 @@ def main() -> None:
         bytes_per_launch = algorithmic_bytes_per_agent_step(n_agents - 1) * Wl * n_agents * spl
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "cavoid::env_kernel<%d, MODE_STEP_AUTORESET%s>" % (n_agents, "_PF" if spl > 1 and Wl * n_agents <= 131072 else ""),
+                "traffic": None, "kernel": "cavoid::env_kernel<%d, MODE_STEP_AUTORESET%s, false>" % (n_agents, "" if spl == 1 else ("_PF" if Wl * n_agents <= 131072 else "_N")),
                 "steps_per_launch": spl, "kernel_us": launch_ms * 1e3, "kernel_us_per_step": launch_ms * 1e3 / spl,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(n_agents - 1)}
@@ -477,7 +478,7 @@ def main() -> None:
         # fall back to the committed summary of a PMC run of this command (same kernel and shape), naming it
         try:
             import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_traffic.json")), reverse=True):
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_traffic*.json")), reverse=True):
                 pmc = json.load(open(path))
                 if pmc.get("worlds") == W and pmc.get("agents") == N and "traffic_bytes_per_step" in pmc:
                     roofline["traffic"] = pmc["traffic_bytes_per_step"] * roofline["steps_per_launch"]

@@ -483,9 +483,11 @@ extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actio
 #ifdef CAVOID_TRACE
 // development build only: point the kernels' phase-stamp buffer (u64 [waves][16]) somewhere
 int cavoid_debug_trace_multistep(unsigned long long *dev_ptr);
+int cavoid_debug_trace_rvo(unsigned long long *dev_ptr);
 extern "C" int cavoid_debug_trace(unsigned long long *dev_ptr) {
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dev_ptr, sizeof(dev_ptr)));
-    return cavoid_debug_trace_multistep(dev_ptr);
+    const int rc = cavoid_debug_trace_multistep(dev_ptr);
+    return rc != CAVOID_OK ? rc : cavoid_debug_trace_rvo(dev_ptr);
 }
 #endif
 

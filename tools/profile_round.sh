@@ -1,0 +1,38 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/: kernel-trace --stats of the bench commands (N = 4 and N = 10, default and the driver's
+# K = 20 form, the full loop), PMC traffic, and the sweep.  usage: bash tools/profile_round.sh <tag>   (on the GPU box)
+tag=${1:-r02_a}; out=$PWD/gpurun_out/prof_$tag; mkdir -p $out; repo=$PWD
+export TMPDIR=/tmp
+prof() {   # prof <name> <bench args...>
+  name=$1; shift
+  rm -rf /tmp/rp_$name; mkdir -p /tmp/rp_$name
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_$name -o $name -- python $repo/bench.py "$@" > $out/$name.bench.json 2> $out/$name.err)
+  db=$(find /tmp/rp_$name -name "*.db" | head -1)
+  if [ -n "$db" ]; then python $repo/tools/rocprof_summary.py $db $out/${tag}_${name}.csv "rocprofv3 --kernel-trace --stats -- python bench.py $*" > /dev/null; else echo "no db for $name" >> $out/errors.txt; find /tmp/rp_$name | head >> $out/errors.txt; fi
+}
+prof kernel_trace_stats --no-cpu-baseline --no-full-loop --no-configs3 --no-pmc
+prof kernel_trace_stats_k20 --steps 20 --warmup 5 --no-cpu-baseline --no-full-loop --no-configs3 --no-pmc
+prof kernel_trace_stats_n10 --agents 10 --no-cpu-baseline --no-full-loop --no-pmc
+prof kernel_trace_stats_w1048576 --worlds 1048576 --steps 256 --warmup 64 --no-cpu-baseline --no-full-loop --no-configs3 --no-pmc
+prof kernel_trace_stats_n10_w262144 --agents 10 --worlds 262144 --steps 256 --warmup 64 --no-cpu-baseline --no-full-loop --no-pmc
+prof full_loop_kernel_trace_stats --steps 256 --warmup 64 --no-cpu-baseline --no-configs3 --no-pmc
+# PMC traffic (separate passes per counter, --kernel-trace only beside --pmc)
+for spec in "4 8192" "10 8192" "4 1048576" "10 262144"; do set -- $spec
+  python - <<PY > $out/${tag}_pmc_traffic_n$1_w$2.json 2>> $out/errors.txt
+import json, sys
+sys.path.insert(0, "$repo")
+import bench
+r = bench.measure_traffic($1, $2, 64, 256, timeout_s=400.0)
+M = $1 - 1
+if r is not None:
+    per_step = r["traffic"] / r["steps_per_launch"]
+    r.update({"round": 2, "agents": $1, "worlds": $2, "traffic_bytes_per_step": per_step,
+              "algorithmic_bytes_per_step": bench.algorithmic_bytes_per_agent_step(M) * $1 * $2,
+              "real_bytes_per_step_expected": "action 4 + obs %d + reward 4 + done 1 per agent (state stays in registers)" % (4 * (6 + 7 * M))})
+print(json.dumps(r, indent=1))
+PY
+done
+timeout 1500 python bench.py --sweep --full-loop > $out/${tag}_bench.json 2>> $out/errors.txt
+timeout 900 python bench.py --agents 10 --sweep --no-full-loop > $out/${tag}_bench_n10.json 2>> $out/errors.txt
+ls -la $out; cat $out/errors.txt 2>/dev/null | tail -5
+head -c 1500 $out/${tag}_kernel_trace_stats.csv; head -c 900 $out/${tag}_pmc_traffic_n4_w8192.json
