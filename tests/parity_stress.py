@@ -15,33 +15,46 @@ from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
 from rl_collision_avoidance_amd.config import EnvConfig
 
 
-def run(N, W, steps, seed, nonl, sort):
+def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1):
+    """chunk > 1: the HIP side takes `chunk` steps per launch (the step-loop kernel, packed record); the oracle steps one
+    by one and the outputs are compared at every chunk end."""
     class Cfg(EnvConfig):
         def __init__(self):
             self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
             EnvConfig.__init__(self)
     pool = 4096
     env = BatchedCollisionAvoidanceEnv(W, Cfg(), seed=seed, gen_min_agents=2, gen_nonlearning_fraction=nonl,
-                                       sort_method=sort, gen_pool_size=pool)
+                                       sort_method=sort, gen_pool_size=pool, gen_mode=mode, gen_rvo_fraction=rvo,
+                                       rvo_enabled=1 if rvo > 0 else 0)
     ocfg = co.default_cfg(N, sort_method=sort)
-    ogen = co.default_gen(2, N, nonl, pool_size=pool)
+    ogen = co.default_gen(2, N, nonl, pool_size=pool, mode=mode, rvo_fraction=rvo)
     env.reset()
     st = co.State.empty(W, N)
     ep = np.zeros(W, np.uint32)
     co.generate(ocfg, ogen, seed, st, ep)
     rng = np.random.default_rng(seed)
     worst = {"obs": 0.0, "rew": 0.0, "state": 0.0, "flag_mismatch": 0, "done_mismatch": 0, "episode_mismatch": 0}
-    for t in range(steps):
-        acts = rng.integers(0, 11, size=(W, N)).astype(np.int32)
-        acts[rng.random((W, N)) < 0.75] = 2
-        obs, rew, done, go = env.step_autoreset(torch.from_numpy(acts).cuda())
-        oobs, orew, odone, ogo = co.step_autoreset(ocfg, ogen, seed, st, ep, acts)
-        d = np.abs(obs.cpu().numpy().astype(np.float64) - oobs)
+    packed = env.new_packed()
+    width = env.obs_width
+    for t0 in range(0, steps, chunk):
+        n = min(chunk, steps - t0)
+        acts = rng.integers(0, 11, size=(n, W, N)).astype(np.int32)
+        acts[rng.random((n, W, N)) < 0.75] = 2
+        if chunk == 1:
+            obs, rew, done, go = [x.cpu().numpy() for x in env.step_autoreset(torch.from_numpy(acts[0]).cuda())]
+        else:
+            pk, go = env.step_autoreset_packed(torch.from_numpy(acts).cuda(), packed)
+            pk, go = pk.cpu().numpy(), go.cpu().numpy()
+            obs, rew, done = pk[..., :width], pk[..., width], pk[..., width + 1].astype(np.uint8)
+        for k in range(n):
+            oobs, orew, odone, ogo = co.step_autoreset(ocfg, ogen, seed, st, ep, acts[k])
+        t = t0 + n - 1
+        d = np.abs(obs.astype(np.float64) - oobs)
         d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2 * np.pi))
         worst["obs"] = max(worst["obs"], float(d.max()))
-        worst["rew"] = max(worst["rew"], float(np.abs(rew.cpu().numpy() - orew).max()))
-        worst["done_mismatch"] += int((done.cpu().numpy() != odone).sum() + (go.cpu().numpy() != ogo).sum())
-        if t % 25 == 24 or t == steps - 1:
+        worst["rew"] = max(worst["rew"], float(np.abs(rew - orew).max()))
+        worst["done_mismatch"] += int((done != odone).sum() + (go != ogo).sum())
+        if chunk > 1 or t % 25 == 24 or t == steps - 1:
             f64, f32, fl = env.get_state()
             worst["flag_mismatch"] += int((fl.cpu().numpy().view(np.uint32) != st.flags).sum())
             worst["state"] = max(worst["state"], float(np.abs(f64.cpu().numpy() - st.f64).max()))
@@ -55,7 +68,10 @@ def main():
     t0 = time.time()
     total = {"obs": 0.0, "rew": 0.0, "state": 0.0, "flag_mismatch": 0, "done_mismatch": 0, "episode_mismatch": 0, "agent_steps": 0}
     cases = [(4, 4096, 400, s, 0.0, 0) for s in range(6)] + [(4, 2048, 300, 100 + s, 0.4, 1) for s in range(3)] + \
-            [(10, 1024, 300, 200 + s, 0.3, 0) for s in range(3)] + [(3, 2048, 300, 300, 0.3, 2), (16, 256, 200, 400, 0.1, 0)]
+            [(10, 1024, 300, 200 + s, 0.3, 0) for s in range(3)] + [(3, 2048, 300, 300, 0.3, 2), (16, 256, 200, 400, 0.1, 0)] + \
+            [(4, 4096, 512, 500 + s, 0.0, 0, 0, 0.0, 32) for s in range(3)] + [(10, 1024, 320, 600, 0.3, 0, 0, 0.0, 16)] + \
+            [(4, 2048, 300, 700 + s, 0.6, 0, 1, 0.5, 1) for s in range(2)] + [(10, 512, 256, 800, 0.5, 1, 1, 0.5, 8)]
+    # (round 2: + step-loop launches with the packed record, + GEN v2 scenarios with RVO agents)
     for c in cases:
         r = run(*c)
         for k in ("obs", "rew", "state"):
