@@ -177,15 +177,30 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         fused_us = timed(lambda: pol.act(obs))
         torch_us = timed(lambda: net.predict_p_and_v(obs.contiguous()), 30)
         lens = obs[:, 0].clamp(0, M)
-        # issued MFMA work: 16-wide K chunks x 256 columns; LSTM step 0 needs the input chunk only; a 64-row tile runs as
-        # many LSTM steps as its longest row needs
+        # The inference kernel computes the float32 GEMMs by error-free bf16 splitting (csrc/cavoid_policy_split.hpp): every
+        # float32 product is five bf16 partial products accumulated in float32.  Two figures:
+        #  * f32-equivalent: the float32 work of the graph as the float32-MFMA kernel would issue it (16-wide K chunks x 256
+        #    columns; LSTM step 0 needs the input chunk only; a 64-row tile runs as many LSTM steps as its longest row
+        #    needs), against the float32-MFMA peak the same arithmetic would otherwise be bound by;
+        #  * issued: the bf16 MFMA work really issued (32-wide K chunks x 5 partial products), against the dense bf16 peak.
         steps = lens.view(-1, 64).max(dim=1).values.mean().item() if (W * N) % 64 == 0 else float(M)
         chunks = (1 + 5 * max(steps - 1, 0)) + 5 + 16 + 16 + 1
         flop = W * N * chunks * 16 * 256 * 2
+        split = os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0")
+        chunks32 = (1 + 3 * max(steps - 1, 0)) + 3 + 8 + 8
+        flop_bf16 = W * N * 5 * 32 * 2 * (chunks32 * 256 + 8 * 16)
         env.close()
-        return {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us, "issued_TFLOPs": flop / fused_us * 1e-6,
-                "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3, "bound": "mfma", "dtype": "f32",
-                "kernel": "cavoid::policy_forward_kernel"}
+        out = {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us,
+               "f32_equivalent_TFLOPs": flop / fused_us * 1e-6, "f32_mfma_peak_TFLOPs": 157.3,
+               "f32_equivalent_frac_of_f32_mfma_peak": flop / fused_us * 1e-6 / 157.3}
+        if split:
+            out.update({"issued_TFLOPs": flop_bf16 / fused_us * 1e-6, "peak_TFLOPs": 2500.0, "frac": flop_bf16 / fused_us * 1e-6 / 2500.0,
+                        "bound": "mfma", "dtype": "f32 in/out; bf16 x 5 error-free split products, f32 accumulate",
+                        "kernel": "cavoid::policy_forward_split_kernel"})
+        else:
+            out.update({"issued_TFLOPs": flop / fused_us * 1e-6, "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3,
+                        "bound": "mfma", "dtype": "f32", "kernel": "cavoid::policy_forward_kernel"})
+        return out
     res = {"policy_kernel": policy_kernel(), "actors_only_fused_policy": regime(True, False),
            "full_loop_fused_policy_fused_trainer": regime(True, True, True)}
     if not brief:                                            # the PyTorch comparison legs take most of the time

@@ -18,7 +18,7 @@ HEADERS = {
     "cavoid_multistep.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rvo.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_host.hpp"],
-    "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_host.hpp"],
+    "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_policy_split.hpp", "cavoid_host.hpp"],
     "cavoid_comm_capi.hip": ["cavoid_host.hpp"],
 }
 # per-file extra flags.  The multi-step env kernels run their step loop inside the launch; MachineLICM would hoist every

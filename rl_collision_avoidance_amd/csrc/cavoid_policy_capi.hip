@@ -7,6 +7,9 @@
 #include "cavoid.h"
 #include "cavoid_host.hpp"
 #include "cavoid_policy.hpp"
+#include "cavoid_policy_split.hpp"
+
+#include <cstdlib>
 
 using namespace cavoid;
 
@@ -18,6 +21,8 @@ struct cavoid_policy {
     uint64_t seed = 0;
     void *slab = nullptr;
     f32x4 *frags = nullptr;
+    uint4 *sfrags = nullptr;         // bf16-split weight fragments of the inference kernel (cavoid_policy_split.hpp)
+    bool use_split = true;           // CAVOID_POLICY_F32=1: run inference on the float32-MFMA kernel instead (A/B runs)
     float *bias = nullptr, *avg = nullptr, *std = nullptr;
     int32_t *step_counter = nullptr;
     uint32_t *blocks_done = nullptr, *cu_tickets = nullptr;
@@ -39,12 +44,15 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_frag = carve((size_t)kPackFragsTrain * sizeof(f32x4)), o_bias = carve(kBiasFloats * sizeof(float));
+    const size_t o_sfrag = carve((size_t)kSpPackFrags * sizeof(uint4));
     const size_t o_avg = carve(h->in_size * sizeof(float)), o_std = carve(h->in_size * sizeof(float));
     const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t)), o_tick = carve(kPolCuSlots * sizeof(uint32_t));
     if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return CAVOID_ENOMEM; }
     if (hipMemset(h->slab, 0, off) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP; }
     unsigned char *b = static_cast<unsigned char *>(h->slab);
     h->frags = reinterpret_cast<f32x4 *>(b + o_frag); h->bias = reinterpret_cast<float *>(b + o_bias);
+    h->sfrags = reinterpret_cast<uint4 *>(b + o_sfrag);
+    if (const char *ov = std::getenv("CAVOID_POLICY_F32")) h->use_split = std::atoi(ov) == 0;
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
     h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
@@ -54,7 +62,9 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_lds_bytes(4)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_backward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)policy_lds_bytes(4)) != hipSuccess) {
+                            (int)policy_lds_bytes(4)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_split_lds_bytes()) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP;
     }
     *out = h;
@@ -85,6 +95,11 @@ extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights 
     hipLaunchKernelGGL(policy_pack_kernel, dim3(blocks), dim3(256), 0, s, k, h->frags, h->bias, with_backward);
     h->backward_loaded = with_backward != 0;
     HIP_TRY(hipGetLastError());
+    {   // the inference kernel's copy: every weight split into three bf16 pieces (exact), fragment order
+        constexpr int64_t items = kSpOffHead / 3 + kSpChWide * 64;
+        hipLaunchKernelGGL(policy_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k, h->sfrags);
+        HIP_TRY(hipGetLastError());
+    }
     h->normalize = w->avg != nullptr;
     if (h->normalize) {
         HIP_TRY(hipMemcpyAsync(h->avg, w->avg, h->in_size * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -118,7 +133,12 @@ static int policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_
     const int tile = 16 * h->row_tiles;
     const int64_t blocks = (rows + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
-    hipLaunchKernelGGL((policy_forward_kernel<4, false>), dim3((unsigned)blocks), dim3(256), policy_lds_bytes(4), static_cast<hipStream_t>(stream), a);
+    if (h->use_split) {
+        SplitArgs sa{a, h->sfrags};
+        hipLaunchKernelGGL(policy_forward_split_kernel, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), static_cast<hipStream_t>(stream), sa);
+    } else {
+        hipLaunchKernelGGL((policy_forward_kernel<4, false>), dim3((unsigned)blocks), dim3(256), policy_lds_bytes(4), static_cast<hipStream_t>(stream), a);
+    }
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }

@@ -1,0 +1,471 @@
+// cavoid_policy_split.hpp -- the actors' NetworkVP_rnn inference (predict_p_and_v + select_action, see cavoid_policy.hpp for
+// the graph and its citations) on the bf16 matrix pipe WITHOUT giving up float32 accuracy: error-free splitting.
+//
+//   Every float32 operand is written as a sum of bf16 pieces (8 significant bits each):
+//       weight  w = w1 + w2 + w3   (24 bits: exact)            -- split once, at cavoid_policy_load time
+//       activation a = a1 + a2     (16 bits + rounding: |a - a1 - a2| <= 2^-17 |a|)  -- split in each layer's epilogue
+//   and a product is the sum of the five partial products that matter, accumulated in float32 by the MFMA:
+//       w*a ~= w1*a1 + w1*a2 + w2*a1 + w2*a2 + w3*a1            (dropped: w3*a2 ~ 2^-25)
+//   v_mfma_f32_16x16x32_bf16 runs at 16x the rate of v_mfma_f32_16x16x4_f32 per unit of K, so five of them cost 5/16
+//   of the float32 instruction's time: 3.2x less matrix time.  The result differs from a float32 GEMM by the activation
+//   rounding (relative 4e-6 per element before the sqrt(K) averaging).  Measured against the network in float64
+//   (tests/test_gpu_policy.py::test_both_inference_kernels_against_a_float64_yardstick): |dp| <= 1.3e-6, where the
+//   float32 PyTorch graph loses 1e-7 -- an order above float32 rounding, an order inside the 2e-5 / 2e-4 bar the
+//   float32 kernel is held to.  CAVOID_POLICY_F32=1 keeps inference on the float32-MFMA kernel.
+//
+// Layout.  One workgroup = 64 rows x 4 wavefronts; the GEMMs are computed TRANSPOSED, D[m][n] = sum_k W[k][m] * act[n][k]:
+//   * MFMA operand A = weights (lane: output column m = l%16 of a 16-column tile, k = 8*(l/16) .. +7), operand B =
+//     activations (lane: batch row n = l%16 of a 16-row tile, same k), result lane: row n = l%16, columns m = 4*(l/16)+r:
+//     a lane ends up with FOUR CONSECUTIVE output columns of one row = four consecutive k of the next layer, so the
+//     epilogue packs them and writes 8 bytes per plane (ds_write_b64) -- no 2-byte scatter;
+//   * activations live in LDS as two bf16 planes [64][264] (row stride 528 B: the 16-byte fragment reads of 16 rows hit
+//     16 different bank groups); during the LSTM columns 0..63 hold h and columns 64+8s.. the input slots (s = 0: the 4
+//     host values, s = 1+t: the 7 values of the t-th observed agent), so the "input chunk" of the two 71/68-wide layers is
+//     one predicated 16-byte read by the lanes of k-group 0;
+//   * wavefront w owns output columns 64w..64w+63 of every layer (4 column tiles x 4 row tiles, 64 accumulator
+//     registers); for the LSTM its four column tiles are the i, j, f, o gates of hidden units 16w..16w+15, so the cell
+//     update is per lane and the cell state never leaves registers;
+//   * weights: fragment-ordered copy (policy_pack_split_kernel), [layer][chunk][plane][column tile][lane] x 16 bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cavoid_policy.hpp"
+
+namespace cavoid {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSpStrideB = 528;                 // bytes per LDS row of one plane (264 bf16)
+constexpr int kSpPlaneB = 64 * kSpStrideB;      // 33 792 B
+constexpr int kSpSlotCol = 64;                  // first input-slot column
+constexpr int kSpMaxOthers = 23;                // slots 0..M must fit columns 64..263
+// chunk counts (K = 32 each)
+constexpr int kSpChLstm = 3, kSpChL1 = 3, kSpChWide = 8;
+constexpr int64_t kSpFragPerChunk = 3 * 16 * 64;          // planes x column tiles x lanes
+constexpr int64_t kSpOffLstm = 0;
+constexpr int64_t kSpOffL1 = kSpOffLstm + kSpChLstm * kSpFragPerChunk;
+constexpr int64_t kSpOffL2 = kSpOffL1 + kSpChL1 * kSpFragPerChunk;
+constexpr int64_t kSpOffFc1 = kSpOffL2 + kSpChWide * kSpFragPerChunk;
+constexpr int64_t kSpOffHead = kSpOffFc1 + kSpChWide * kSpFragPerChunk;   // one column tile: 3 x 64 frags per chunk
+constexpr int64_t kSpPackFrags = kSpOffHead + kSpChWide * 3 * 64;
+constexpr size_t policy_split_lds_bytes() { return (size_t)2 * kSpPlaneB + 64 * sizeof(float) + 64 * sizeof(int) + 64; }
+
+// float -> (hi, lo) bf16 with hi = rn(x), lo = rn(x - hi); two values at a time (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+    const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+}
+// float -> three bf16 pieces (exact: 3 x 8 bits cover the 24-bit significand)
+__device__ __forceinline__ void split3(float x, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    uint32_t a, b, c;
+    split2(x, 0.0f, a, b);
+    p1 = a & 0xFFFFu; p2 = b & 0xFFFFu;
+    const float r = (x - __uint_as_float(p1 << 16)) - __uint_as_float(p2 << 16);
+    const bf16x2 h = __builtin_convertvector(f32x2{r, 0.0f}, bf16x2);
+    c = __builtin_bit_cast(uint32_t, h);
+    p3 = c & 0xFFFFu;
+}
+
+// element (k-chunk c, k-group g, element e, packed column col) of a layer, in cavoid_policy.hpp's policy_weight() terms
+__device__ __forceinline__ float split_weight(const PolicyWeights &w, int layer, int c, int g, int e, int col) {
+    if (layer <= 1) {                                       // LSTM / layer1: two chunks of hidden state, then the input slot
+        if (c < 2) return policy_weight(w, layer, 32 * c + 8 * g + e, col);
+        const int n_in = layer == 0 ? kPolOther : kPolHost;
+        return (g == 0 && e < n_in) ? policy_weight(w, layer, kPolHidden + e, col) : 0.0f;
+    }
+    return policy_weight(w, layer, 32 * c + 8 * g + e, col);
+}
+
+__global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one (layer, chunk, column tile, lane): all 3 planes
+    constexpr int64_t kWide = kSpOffHead / 3, kAll = kWide + kSpChWide * 64;
+    if (f >= kAll) return;
+    int layer, c, mt, lane;
+    int64_t base;                                                          // frag index of plane 0
+    if (f >= kWide) {
+        const int64_t r = f - kWide;
+        layer = 4; c = (int)(r >> 6); mt = 0; lane = (int)(r & 63);
+        base = kSpOffHead + (int64_t)c * 3 * 64 + lane;
+    } else {
+        const int64_t per = 16 * 64;                                       // per chunk, per plane
+        const int64_t ch = f / per, r = f - ch * per;                      // global chunk index over the four wide layers
+        mt = (int)(r >> 6); lane = (int)(r & 63);
+        if (ch < kSpChLstm) { layer = 0; c = (int)ch; base = kSpOffLstm; }
+        else if (ch < kSpChLstm + kSpChL1) { layer = 1; c = (int)ch - kSpChLstm; base = kSpOffL1; }
+        else if (ch < kSpChLstm + kSpChL1 + kSpChWide) { layer = 2; c = (int)ch - kSpChLstm - kSpChL1; base = kSpOffL2; }
+        else { layer = 3; c = (int)ch - kSpChLstm - kSpChL1 - kSpChWide; base = kSpOffFc1; }
+        base += (int64_t)c * kSpFragPerChunk + (int64_t)mt * 64 + lane;
+    }
+    const int g = lane >> 4, col = 16 * mt + (lane & 15);
+    uint32_t pl[3][4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        uint32_t a1, a2, a3, b1, b2, b3;
+        split3(split_weight(w, layer, c, g, e, col), a1, a2, a3);
+        split3(split_weight(w, layer, c, g, e + 1, col), b1, b2, b3);
+        pl[0][e >> 1] = a1 | (b1 << 16); pl[1][e >> 1] = a2 | (b2 << 16); pl[2][e >> 1] = a3 | (b3 << 16);
+    }
+    const int64_t plane_stride = layer == 4 ? 64 : 16 * 64;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) frags[base + p * plane_stride] = uint4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+}
+
+struct SplitW { uint4 w[3][4]; };                            // weight fragments of one chunk: plane x column tile
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4 &a, const uint4 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split_load_w1(uint4 (&w)[4], const uint4 *layer, int plane, int wave, int lane, int c) {
+    const uint4 *p = layer + (int64_t)c * kSpFragPerChunk + (int64_t)plane * 16 * 64 + (int64_t)(4 * wave) * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) w[mt] = p[mt * 64];
+}
+__device__ __forceinline__ void split_load_w(SplitW &f, const uint4 *layer, int wave, int lane, int c) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) split_load_w1(f.w[pl], layer, pl, wave, lane, c);
+}
+
+// activation fragments (ONE plane) of the k-range starting at LDS column `col` (32 wide); `slot`: the input chunk --
+// only k-group 0 holds data (one 8-value slot at column `col`), the other groups supply zeros
+__device__ __forceinline__ void split_load_a(uint4 (&a)[4], const unsigned char *planes, int plane, int lane, int col, bool slot) {
+    const int g = lane >> 4;
+    const unsigned char *p = planes + plane * kSpPlaneB + (lane & 15) * kSpStrideB + (col + (slot ? 0 : 8 * g)) * 2;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (!slot || g == 0) v = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
+        a[nt] = v;
+    }
+}
+
+// one partial product for all 16 (column tile, row tile) pairs: consecutive MFMAs never share an accumulator
+__device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4 (&a)[4], f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16(w[mt], a[nt], acc[mt][nt]);
+}
+
+// acc += W(chunks c0..c1-1 of `layer`) x act.  Chunk c reads LDS columns 32c.., except `slot_chunk`, which reads the
+// 8-wide input slot at column `slot_col`.  w must already hold chunk c0's weights (issued before the barrier that
+// publishes the activations).  ONE set of weight registers and ONE set of activation registers: every fragment group is
+// re-loaded for the next chunk right after its last use in this one, ordered so that each load has >= 48 MFMAs (768
+// cycles, L2) resp. >= 16 MFMAs (256 cycles, LDS) to land:
+//     w1*a_lo   w1*a_hi   [w1 <- next]   w2*a_lo   [a_lo <- next]   w2*a_hi   [w2 <- next]   w3*a_hi   [w3, a_hi <- next]
+// 144 live registers (64 accumulators, 48 weight, 32 activation) instead of 240 for a double-buffered pipeline.
+__device__ __forceinline__ void split_gemm(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
+                                           int wave, int lane, SplitW &w, f32x4 (&acc)[4][4]) {
+    uint4 a_hi[4], a_lo[4];
+    auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
+    split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
+    split_load_a(a_hi, planes, 0, lane, col_of(c0), c0 == slot_chunk);
+#pragma unroll 1
+    for (int c = c0; c < c1; ++c) {
+        const int n = c + 1 < c1 ? c + 1 : c;              // (the prefetches of the last chunk are harmless re-reads)
+        __builtin_amdgcn_sched_barrier(0);
+        split_mfma_term(w.w[0], a_lo, acc);
+        split_mfma_term(w.w[0], a_hi, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        split_load_w1(w.w[0], layer, 0, wave, lane, n);
+        split_mfma_term(w.w[1], a_lo, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
+        split_mfma_term(w.w[1], a_hi, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        split_load_w1(w.w[1], layer, 1, wave, lane, n);
+        split_mfma_term(w.w[2], a_hi, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        split_load_w1(w.w[2], layer, 2, wave, lane, n);
+        split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
+__device__ __forceinline__ void split_init_acc(const float *bias, int wave, int lane, f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = b;
+    }
+}
+
+// four consecutive columns of one row -> both planes, 8 bytes each
+__device__ __forceinline__ void split_store4(unsigned char *planes, int row, int col, const f32x4 &z) {
+    uint32_t h0, l0, h1, l1;
+    split2(z[0], z[1], h0, l0);
+    split2(z[2], z[3], h1, l1);
+    unsigned char *p = planes + row * kSpStrideB + col * 2;
+    *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
+    *reinterpret_cast<uint2 *>(p + kSpPlaneB) = uint2{l0, l1};
+}
+
+__device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave, int lane, const f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = fmaxf(acc[mt][nt][r], 0.0f);
+            split_store4(planes, 16 * nt + (lane & 15), 16 * (4 * wave + mt) + 4 * (lane >> 4), z);
+        }
+}
+
+struct SplitArgs {
+    PolicyArgs p;                      // the float32 kernel's arguments (frags / bias: bias is shared, frags unused here)
+    const uint4 *sfrags;               // split weight fragments
+};
+
+__global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const SplitArgs sa) {
+    const PolicyArgs &p = sa.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // plane 1 (hi), plane 2 (lo)
+    float *len_f = reinterpret_cast<float *>(planes + 2 * kSpPlaneB);            // [64] raw num_other_agents
+    int *tile_row = reinterpret_cast<int *>(len_f + 64);                          // [64] global row of each tile row
+    int *wave_max = tile_row + 64;                                                // [4] + ticket
+    int &ticket = wave_max[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t n_rows = p.row_count ? (int64_t)*p.row_count : p.rows;
+    const int rows_here = n_rows - row0 < 64 ? (int)(n_rows - row0 > 0 ? n_rows - row0 : 0) : 64;
+    const int M = p.max_other, A = p.num_actions;
+    const int step = p.actions_out ? *p.step_counter : 0;
+    const bool listed = p.row_index != nullptr;
+    if (listed && rows_here == 0) {                        // uniform over the workgroup: nothing listed for this tile
+        if (p.actions_out) policy_finish(p, step, tid);
+        return;
+    }
+    POLICY_STAMP(0);
+#ifdef CAVOID_TRACE
+    const unsigned long long trace_c0 = clock64();
+    if (tid == 0 && g_pol_trace)
+        g_pol_trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                  ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+    const uint4 *w_lstm = sa.sfrags + kSpOffLstm;
+    SplitW f0;
+    split_load_w(f0, w_lstm, wave, lane, 2);               // first LSTM step: h == 0, only the input chunk contributes
+
+    // ---- input tile: gather + normalise + split into the slot columns ---------------------------------------------
+    if (listed) {
+        if (tid < 64) tile_row[tid] = tid < rows_here ? p.row_index[row0 + tid] : 0;
+        __syncthreads();
+    }
+    {
+        const float *src = listed ? p.x : p.x + row0 * p.stride;
+        if (tid == 0) {                                    // arrival parity on the CU -> static priority (see cavoid_policy.hpp)
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            const uint32_t key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
+            ticket = (int)atomicAdd(p.cu_tickets + key, 1u);
+        }
+        int local_max = 0;
+        if (tid < 64) {
+            const float v = tid < rows_here ? src[(int64_t)(listed ? tile_row[tid] : tid) * p.stride] : 0.0f;
+            len_f[tid] = v;
+            int len = (int)v;
+            len = len < 0 ? 0 : (len > M ? M : len);
+            local_max = len;
+        }
+        // h = 0 (columns 0..63 of both planes)
+        for (int e = tid; e < 2 * 64 * 8; e += 256) {
+            const int pl = e >> 9, r = (e >> 3) & 63, c16 = e & 7;
+            *reinterpret_cast<uint4 *>(planes + pl * kSpPlaneB + r * kSpStrideB + c16 * 16) = uint4{0u, 0u, 0u, 0u};
+        }
+        const int items = 64 * (M + 1);                    // (row, slot): slot 0 = host (4 values), slot s = observed agent s-1 (7)
+        for (int it = tid; it < items; it += 256) {
+            const int r = it & 63, s = it >> 6;
+            const int n_in = s == 0 ? kPolHost : kPolOther, sc0 = s == 0 ? 1 : 1 + kPolHost + kPolOther * (s - 1);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = 0.0f;
+                if (e < n_in && r < rows_here) {
+                    x = src[(int64_t)(listed ? tile_row[r] : r) * p.stride + sc0 + e];
+                    if (p.avg) x = (x - p.avg[sc0 + e]) / p.std[sc0 + e];
+                }
+                v[e] = x;
+            }
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+            unsigned char *d = planes + r * kSpStrideB + (kSpSlotCol + 8 * s) * 2;
+            *reinterpret_cast<uint4 *>(d) = uint4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<uint4 *>(d + kSpPlaneB) = uint4{lo[0], lo[1], lo[2], lo[3]};
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(local_max, d, 64); local_max = o > local_max ? o : local_max; }
+        if (lane == 0) wave_max[wave] = local_max;
+    }
+    __syncthreads();
+    const int steps = wave_max[0];                         // rows 0..63 are all in wavefront 0's threads
+    if (ticket & 1) __builtin_amdgcn_s_setprio(1);
+    POLICY_STAMP(5);
+
+    // this lane's rows (one per row tile) and their sequence lengths
+    float len_r[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) len_r[nt] = len_f[16 * nt + (lane & 15)];
+
+    // ---- LSTM over the observed agents ----------------------------------------------------------------------------
+    f32x4 cell[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) cell[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < steps; ++t) {
+        f32x4 acc[4][4];
+        split_init_acc(p.bias + kBiasLstm, wave, lane, acc);
+        if (t == 1) POLICY_STAMP(8);
+        split_gemm(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc);
+        if (t == 1) POLICY_STAMP(9);
+        split_load_w(f0, w_lstm, wave, lane, 0);           // the next step's first weight fragments
+        __syncthreads();                                   // every wavefront has read h
+        if (t == 1) POLICY_STAMP(10);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            // lane: row 16nt + l%16, hidden units 16w + 4g + r; column tile = gate (i, j, f, o)
+            const bool live = len_r[nt] > (float)t;        // dynamic_rnn: rows past their own length keep (c, h)
+            f32x4 h_new;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gi = fast_sigmoid(acc[0][nt][r]), gj = fast_tanh(acc[1][nt][r]);
+                const float gf = fast_sigmoid(acc[2][nt][r]), go = fast_sigmoid(acc[3][nt][r]);
+                const float c_new = gf * cell[nt][r] + gi * gj;
+                h_new[r] = go * fast_tanh(c_new);
+                cell[nt][r] = live ? c_new : cell[nt][r];
+            }
+            if (live) split_store4(planes, 16 * nt + (lane & 15), 16 * wave + 4 * g, h_new);   // (else h stays as it is)
+        }
+        if (t == 1) POLICY_STAMP(11);
+        __syncthreads();                                   // the new h is in place
+        if (t == 1) POLICY_STAMP(12);
+    }
+    POLICY_STAMP(1);
+    // ---- layer1 on [h | host] -------------------------------------------------------------------------------------
+    {
+        f32x4 acc[4][4];
+        split_load_w(f0, sa.sfrags + kSpOffL1, wave, lane, 0);
+        split_init_acc(p.bias + kBiasL1, wave, lane, acc);
+        split_gemm(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc);
+        split_load_w(f0, sa.sfrags + kSpOffL2, wave, lane, 0);
+        __syncthreads();
+        split_store_relu(planes, wave, lane, acc);
+        __syncthreads();
+    }
+    POLICY_STAMP(2);
+    // ---- layer2, fullyconnected1 ----------------------------------------------------------------------------------
+    {
+        f32x4 acc[4][4];
+        split_init_acc(p.bias + kBiasL2, wave, lane, acc);
+        split_gemm(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
+        split_load_w(f0, sa.sfrags + kSpOffFc1, wave, lane, 0);
+        __syncthreads();
+        split_store_relu(planes, wave, lane, acc);
+        __syncthreads();
+    }
+    uint4 hw[kSpChWide][3];                                // the heads' weight fragments: half in flight across the epilogue
+    const uint4 *hp = sa.sfrags + kSpOffHead + lane;
+    {
+        f32x4 acc[4][4];
+        split_init_acc(p.bias + kBiasFc1, wave, lane, acc);
+        split_gemm(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
+#pragma unroll
+        for (int c = 0; c < kSpChWide / 2; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
+        __syncthreads();
+        split_store_relu(planes, wave, lane, acc);
+        __syncthreads();
+    }
+    POLICY_STAMP(3);
+    // ---- heads: wavefront w does rows 16w..16w+15 x 16 columns (A logits, the value, padding) ---------------------
+    {
+#pragma unroll
+        for (int c = kSpChWide / 2; c < kSpChWide; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
+        f32x4 acc[5];
+        acc[0] = *reinterpret_cast<const f32x4 *>(p.bias + kBiasHead + 4 * g);
+        acc[1] = acc[2] = acc[3] = acc[4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char *arow = planes + (16 * wave + (lane & 15)) * kSpStrideB + 8 * g * 2;
+#pragma unroll
+        for (int c = 0; c < kSpChWide; ++c) {
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(arow + c * 64), a2 = *reinterpret_cast<const uint4 *>(arow + kSpPlaneB + c * 64);
+            acc[4] = mfma_bf16(hw[c][2], a1, acc[4]);
+            acc[3] = mfma_bf16(hw[c][1], a2, acc[3]);
+            acc[2] = mfma_bf16(hw[c][1], a1, acc[2]);
+            acc[1] = mfma_bf16(hw[c][0], a2, acc[1]);
+            acc[0] = mfma_bf16(hw[c][0], a1, acc[0]);
+        }
+        const f32x4 logit = (acc[4] + acc[3]) + (acc[2] + acc[1]) + acc[0];
+        // lane: row 16w + l%16, columns 4g + r.  Reductions over a row's 16 columns = over r in the lane and over the
+        // four lanes l%16 + 16g'.
+        const int trow = 16 * wave + (lane & 15);
+        const bool in_tile = trow < rows_here;
+        const int64_t row = listed ? (in_tile ? (int64_t)tile_row[trow] : p.rows) : row0 + trow;
+        const float scale = 1.0f / (1.0f + p.min_policy * (float)A);
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = (4 * g + r < A) ? fmaxf(m, logit[r]) : m;
+        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float e[4], sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = (4 * g + r < A) ? expf(logit[r] - m) : 0.0f; sum += e[r]; }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        float pj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pj[r] = (4 * g + r < A) ? (e[r] / sum + p.min_policy) * scale : 0.0f;
+        if (row < p.rows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 4 * g + r;
+                if (col < A) p.p_out[row * A + col] = pj[r];
+                else if (col == A) p.v_out[row] = logit[r];
+            }
+        }
+        if (p.actions_out) {                               // wave-uniform
+            int action;
+            if (p.greedy) {                                // np.argmax: first index of the maximum
+                float best = fmaxf(fmaxf(pj[0], pj[1]), fmaxf(pj[2], pj[3]));
+                best = fmaxf(best, __shfl_xor(best, 16, 64)); best = fmaxf(best, __shfl_xor(best, 32, 64));
+                int idx = 99;
+#pragma unroll
+                for (int r = 3; r >= 0; --r) idx = (4 * g + r < A && pj[r] == best) ? 4 * g + r : idx;
+                int o = __shfl_xor(idx, 16, 64); idx = o < idx ? o : idx;
+                o = __shfl_xor(idx, 32, 64); idx = o < idx ? o : idx;
+                action = idx;
+            } else {                                       // inverse CDF: #{c : cdf_c <= u * cdf_{A-1}}
+                const float t_g = (pj[0] + pj[1]) + (pj[2] + pj[3]);
+                float before = 0.0f, total = 0.0f;         // sum of the lower column groups / of all four, in group order
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const float tg = __shfl(t_g, (lane & 15) + 16 * gg, 64);
+                    before += gg < g ? tg : 0.0f;
+                    total += tg;
+                }
+                const uint32_t bits = policy_philox_x((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)step, 0x504F4Cu,
+                                                      p.seed_lo, p.seed_hi);
+                const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+                float cdf = before;
+                int below = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cdf += pj[r]; below += (4 * g + r < A && cdf <= u * total) ? 1 : 0; }
+                below += __shfl_xor(below, 16, 64); below += __shfl_xor(below, 32, 64);
+                action = below < A - 1 ? below : A - 1;
+            }
+            if (row < p.rows && g == 0) p.actions_out[row] = action;
+        }
+    }
+    POLICY_STAMP(4);
+#ifdef CAVOID_TRACE
+    if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
+#endif
+    if (p.actions_out) policy_finish(p, step, tid);
+}
+
+}  // namespace cavoid
