@@ -213,6 +213,18 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     return res
 
 
+def step_kernel_name(N: int, W: int, spl: int) -> str:
+    """Which instantiation cavoid_step_autoreset_n takes (csrc/cavoid_capi.hip, cavoid_launch.hpp)."""
+    if spl == 1:
+        return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET, false>" % N
+    if W * N > 131072:
+        return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET_N, false>" % N
+    tiles = -(-W // (64 // N))
+    if tiles <= 1024 and os.environ.get("CAVOID_PIPELINE", "1") != "0":
+        return "cavoid::env_pipe_kernel<%d, false> (two-wavefront pipeline per tile)" % N
+    return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET_PF, false>" % N
+
+
 def self_launch(args) -> None:
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this script through
     torch.distributed.run on 127.0.0.1 and pass their output through (rank 0 prints the JSON line)."""
@@ -282,7 +294,8 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
                     for row in csv.DictReader(f):
                         # the stepping instantiations: env_kernel<N, MODE in {1 single step, 4 / 5 step loop}, RVO>
                         hit = re.search(r"env_kernel<%d, (\d+)" % N, row["Kernel_Name"])
-                        if hit and hit.group(1) in ("1", "4", "5") and row["Counter_Name"] == ctr:
+                        step = (hit and hit.group(1) in ("1", "4", "5")) or ("env_pipe_kernel<%d," % N) in row["Kernel_Name"]
+                        if step and row["Counter_Name"] == ctr:
                             total += float(row["Counter_Value"])
                             n += 1
             if n == 0:
@@ -410,7 +423,7 @@ def main() -> None:
         bytes_per_launch = algorithmic_bytes_per_agent_step(n_agents - 1) * Wl * n_agents * spl
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "cavoid::env_kernel<%d, MODE_STEP_AUTORESET%s, false>" % (n_agents, "" if spl == 1 else ("_PF" if Wl * n_agents <= 131072 else "_N")),
+                "traffic": None, "kernel": step_kernel_name(n_agents, Wl, spl),
                 "steps_per_launch": spl, "kernel_us": launch_ms * 1e3, "kernel_us_per_step": launch_ms * 1e3 / spl,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(n_agents - 1)}

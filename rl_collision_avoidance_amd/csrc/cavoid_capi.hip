@@ -241,6 +241,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
         e->prefetch_single = e->latency_mode;
     }
     k.prefetch_pool = e->latency_mode;
+    if (const char *ov = std::getenv("CAVOID_PIPELINE")) e->pipeline = std::atoi(ov) != 0;
     // obs tile (rows of width + 2 floats: the packed record is the widest row): the wavefront's rows in ONE pass when
     // the batch is latency bound or when they fit ~9 KiB; else several passes of a multiple of 4 rows, so that the LDS
     // footprint (and the wavefronts resident per CU) does not scale with N*(1+D)   [N=10: +7 % at saturation]

@@ -306,10 +306,10 @@ __device__ __forceinline__ Ego ego_frame_exact(const Agent &a) {
 // flag, a reward branch, a sort key or the state, so the long float64 sqrt/div/atan2 chains are
 // replaced by a Newton-refined v_rsq_f32 seed (relative error ~1e-14) and a float32 atan2
 // (absolute error < 1e-6 rad) -- a third of the dependent latency of the exact form.
-__device__ __forceinline__ Ego ego_frame_obs(const Agent &a) {
+__device__ __forceinline__ Ego ego_from(double tx, double ty, double heading) {
     Ego e;
-    e.tx = (double)a.gx - a.px;
-    e.ty = (double)a.gy - a.py;
+    e.tx = tx;
+    e.ty = ty;
     const double ss = e.tx * e.tx + e.ty * e.ty;
     const bool tiny = !(ss > 1e-16);                                  // dist <= 1e-8: axes stay un-normalised
     double y = (double)__builtin_amdgcn_rsqf((float)ss);              // ~1e-7 relative
@@ -319,12 +319,13 @@ __device__ __forceinline__ Ego ego_frame_obs(const Agent &a) {
     const double inv = tiny ? 1.0 : y;
     e.prll_x = e.tx * inv;
     e.prll_y = e.ty * inv;
-    double h = a.heading - (double)atan2f((float)e.ty, (float)e.tx);
+    double h = heading - (double)atan2f((float)e.ty, (float)e.tx);
     h = h >= kPi ? h - 2.0 * kPi : h;
     h = h < -kPi ? h + 2.0 * kPi : h;
     e.heading_ego = h;
     return e;
 }
+__device__ __forceinline__ Ego ego_frame_obs(const Agent &a) { return ego_from((double)a.gx - a.px, (double)a.gy - a.py, a.heading); }
 
 __device__ __forceinline__ double time_to_impact(double rx, double ry, double vx, double vy, double R) {
     const double cc = rx * rx + ry * ry - R * R;
@@ -1191,6 +1192,252 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
         }
     }
     CAVOID_STAMP(8);
+}
+
+
+// ---- MODE_STEP_AUTORESET_PIPE: the step loop as a two-wavefront pipeline (latency mode: small batches) ----------------
+// At 4 x 8192 there are 512 tiles for 1024 SIMDs and a step is ONE wavefront's dependent chain.  Here a tile is owned by a
+// workgroup of TWO wavefronts on two SIMDs of a CU:
+//   wavefront P (producer): action decode, dynamics, staging, pair pass, rewards, done / game_over, restart -- step t;
+//   wavefront C (consumer): ego frame, neighbour ranking, observation rows, tile flush -- step t-1,
+// handing over through double-buffered LDS (the staged post-move state + one record per lane: goal offset, heading, the
+// sort keys and gaps of the pair pass, flags, reward, done), one workgroup barrier per step.  Same arithmetic, same
+// operation order per value as env_kernel: outputs are bit-identical (tests/test_gpu_packed.py).  The state lives in P's
+// registers for the whole launch; P holds every lane's NEXT pool record like MODE_STEP_AUTORESET_PF.
+template <int N>
+struct PipeRec {                       // per-buffer hand-over record, field-major over the 64 lanes
+    static constexpr int K = Others<N>::K;
+    double tx[64], ty[64], heading[64];
+    float pref[64], radius[64], rew[64], done[64];
+    uint32_t flags[64], valid[64];
+    uint32_t key_hi[K][64], key_lo[K][64];
+    float gap[K][64];
+};
+struct PipeStage { double px[64], py[64], vx[64], vy[64]; float r[64]; };
+
+template <int N>
+__host__ __device__ constexpr size_t pipe_lds_fixed_bytes() {
+    return (size_t)lds_floats_block() * sizeof(float) + 2 * sizeof(PipeStage) + 2 * sizeof(PipeRec<N>);
+}
+
+template <int N, bool RVO>
+__global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *lds_tab = reinterpret_cast<double *>(smem);
+    PipeStage *stage = reinterpret_cast<PipeStage *>(smem + lds_floats_block() * sizeof(float));
+    PipeRec<N> *rec = reinterpret_cast<PipeRec<N> *>(stage + 2);
+    float *tile = reinterpret_cast<float *>(rec + 2);
+    const int width = c.width, ostride = io.obs_stride;
+    const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
+    double *rvo_mem = reinterpret_cast<double *>(tile + tile_floats);
+    const bool producer = (threadIdx.x >> 6) == 0;
+    const int lane0 = threadIdx.x & 63;
+    const int wpw = c.wpw, lanes_used = wpw * N;
+    const int64_t wave = blockIdx.x;                       // one tile per workgroup
+    const int64_t w0 = wave * wpw;
+    const int lw = lane0 / N, i0 = lane0 - lw * N;
+    const int64_t w = w0 + lw;
+    const bool active = lane0 < lanes_used && w < c.num_worlds;
+    const int base0 = lane0 < lanes_used ? lw * N : 0;
+    const int64_t a_idx0 = w * N + i0;
+    const bool packed = io.packed != 0;
+    int64_t worlds_here = c.num_worlds - w0;
+    if (worlds_here > wpw) worlds_here = wpw;
+    if (worlds_here < 0) worlds_here = 0;
+    const int n_steps = io.n_steps;
+
+    // ---- producer state ------------------------------------------------------------------------------------------------
+    Agent a;
+    a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
+    a.gx = a.gy = a.radius = a.pref = a.speed = 0.0f;
+    a.flags = 0u;
+    Agent nxt = a;
+    uint32_t episode = 0u;
+    int act_next = 0;
+    bool restarted_any = false, moved_any = false, present_first = false;
+    const bool prefetch = c.pool_size > 0;
+    if (producer) {
+        double tab_v = 0.0;
+        if (lane0 < 2 * c.num_actions) tab_v = c.action_table[lane0];
+        if (active) {
+            episode = s.episode[w];
+            load_agent(s, a_idx0, a);
+            if (RVO) a.speed = s.speed[a_idx0];
+            act_next = io.actions[a_idx0];
+            if (prefetch) load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i0, nxt);
+        }
+        lds_tab[lane0] = tab_v;
+        present_first = active && (a.flags & CAVOID_F_PRESENT);
+    }
+
+    for (int k = 0; k <= n_steps; ++k) {
+        int lane = lane0, i = i0, base = base0;
+        int64_t a_idx = a_idx0;
+        asm volatile("" : "+v"(lane), "+v"(i), "+v"(base), "+v"(a_idx));   // keep lane-derived values out of loop-invariant registers
+        if (producer) {
+            if (k < n_steps) {
+                const int t = k;
+                PipeStage &st = stage[t & 1];
+                PipeRec<N> &rc = rec[t & 1];
+                const uint32_t flags_in = a.flags;
+                const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
+                const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
+                int act = act_next;
+                if (t + 1 < n_steps && active) act_next = io.actions[(int64_t)(t + 1) * io.action_stride + a_idx];
+                // ---- E4 decode -----------------------------------------------------------------------------------------
+                wave_lds_sync();
+                const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
+                double a0 = 0.0, a1 = 0.0;
+                act = act < 0 ? 0 : (act >= c.num_actions ? c.num_actions - 1 : act);
+                a0 = (double)a.pref * lds_tab[2 * act];
+                a1 = lds_tab[2 * act + 1];
+                if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {   // scripted agents in this tile
+                    if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
+                    if (pol == 2u) {
+                        const Ego e0 = ego_frame_exact(a);
+                        a0 = (double)a.pref;
+                        a1 = -e0.heading_ego;
+                    }
+                }
+                if (RVO && __ballot(present_in && !done_in && pol == 3u) != 0ull) {
+                    double sn, cs;
+                    sincos_bounded(a.heading, &sn, &cs);
+                    st.px[lane] = a.px; st.py[lane] = a.py;
+                    st.vx[lane] = present_in ? (double)a.speed * cs : 0.0;
+                    st.vy[lane] = present_in ? (double)a.speed * sn : 0.0;
+                    st.r[lane] = present_in ? a.radius : -1.0f;
+                    wave_lds_sync();
+                    if (present_in && !done_in && pol == 3u)
+                        rvo_action<N>(c, a, i, base, lane, st.px, st.py, st.vx, st.vy, st.r, rvo_mem, a0, a1);
+                    wave_lds_sync();
+                }
+                if (c.actions_fp32) { a0 = (double)(float)a0; a1 = (double)(float)a1; }
+                // ---- E5 dynamics ---------------------------------------------------------------------------------------
+                const bool moving = present_in && !done_in;
+                moved_any = moved_any || moving;
+                double dh = a1;
+                if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
+                    const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
+                    dh = rate * c.dt;
+                }
+                const double nh = wrap_angle(dh + a.heading);
+                double sn, cs;
+                sincos_bounded(nh, &sn, &cs);
+                const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
+                const double nvx = a0 * cs, nvy = a0 * sn, nsp = a0;
+                a.px = moving ? npx : a.px; a.py = moving ? npy : a.py; a.heading = moving ? nh : a.heading;
+                a.vx = moving ? nvx : 0.0; a.vy = moving ? nvy : 0.0; a.speed = moving ? (float)nsp : 0.0f;
+                if (present_in && done_in) {
+                    if (flags_in & CAVOID_F_AT_GOAL) a.flags |= CAVOID_F_WAS_AT_GOAL;
+                    if (flags_in & CAVOID_F_IN_COLL) a.flags |= CAVOID_F_WAS_IN_COLL;
+                }
+                if (moving) {
+                    const double dx = a.px - (double)a.gx, dy = a.py - (double)a.gy;
+                    if (dx * dx + dy * dy <= c.near_goal_sq) a.flags |= CAVOID_F_AT_GOAL;
+                    a.t_rem -= c.dt;
+                    if (c.timeout_enabled && a.t_rem <= 0.0) a.flags |= CAVOID_F_RAN_OUT;
+                }
+                // ---- stage, E6 pair pass -------------------------------------------------------------------------------
+                bool present = active && (a.flags & CAVOID_F_PRESENT);
+                st.px[lane] = a.px; st.py[lane] = a.py; st.vx[lane] = a.vx; st.vy[lane] = a.vy;
+                st.r[lane] = present ? a.radius : -1.0f;
+                wave_lds_sync();
+                Ego e;                                                  // the pair pass needs the goal offset only
+                e.tx = (double)a.gx - a.px; e.ty = (double)a.gy - a.py;
+                Key key[Others<N>::K];
+                float gapf[Others<N>::K];
+                uint32_t valid;
+                bool hit;
+                double min_gap;
+                pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit, min_gap);
+                // ---- E7 rewards, E8 done -------------------------------------------------------------------------------
+                double r = 0.0;
+                bool done = true;
+                if (present) {
+                    r = c.r_step;
+                    if (a.flags & CAVOID_F_AT_GOAL) { if (!(a.flags & CAVOID_F_WAS_AT_GOAL)) r = c.r_goal; }
+                    else if (!(a.flags & CAVOID_F_WAS_IN_COLL)) {
+                        if (hit) { r = c.r_coll; a.flags |= CAVOID_F_IN_COLL; }
+                        else if (min_gap <= c.close_range) r = c.r_close + c.close_slope * min_gap;
+                    }
+                    r = fmin(fmax(r, c.clip_lo), c.clip_hi);
+                    done = (a.flags & CAVOID_F_DONE_MASK) != 0u;
+                }
+                const unsigned long long running = __ballot(present && ((a.flags & CAVOID_F_LEARNING) || c.evaluate_mode) && !done);
+                const unsigned long long wmask = ((1ull << N) - 1ull) << base;
+                const bool game_over = (running & wmask) == 0ull;
+                const float rew_f = (float)r, done_f = done ? 1.0f : 0.0f;
+                if (active) {
+                    if (!packed) {
+                        io.rew[a_idx] = rew_f;
+                        io.done[a_idx] = done ? 1 : 0;
+                    }
+                    if (i == 0) io.game_over[w] = game_over ? 1 : 0;
+                }
+                const bool restart = active && game_over;
+                if (__ballot(restart) != 0ull) {
+                    wave_lds_sync();
+                    if (restart) {
+                        episode += 1u;
+                        restarted_any = true;
+                        if (prefetch) {
+                            a = nxt;
+                            if (t + 1 < n_steps)
+                                load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
+                        } else generate_agent<N>(c, (uint32_t)(c.world_offset + w), episode, i, a);
+                        present = (a.flags & CAVOID_F_PRESENT) != 0u;
+                        st.px[lane] = a.px; st.py[lane] = a.py; st.vx[lane] = 0.0; st.vy[lane] = 0.0;
+                        st.r[lane] = present ? a.radius : -1.0f;
+                    }
+                    wave_lds_sync();
+                    if (restart) {
+                        e.tx = (double)a.gx - a.px; e.ty = (double)a.gy - a.py;
+                        bool hit2;
+                        double gap2;
+                        pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit2, gap2);
+                    }
+                }
+                // ---- hand over to the consumer ---------------------------------------------------------------------------
+                rc.tx[lane] = e.tx; rc.ty[lane] = e.ty; rc.heading[lane] = a.heading;
+                rc.pref[lane] = a.pref; rc.radius[lane] = a.radius; rc.rew[lane] = rew_f; rc.done[lane] = done_f;
+                rc.flags[lane] = a.flags; rc.valid[lane] = valid;
+#pragma unroll
+                for (int o = 0; o < N - 1; ++o) { rc.key_hi[o][lane] = key[o].hi; rc.key_lo[o][lane] = key[o].lo; rc.gap[o][lane] = gapf[o]; }
+            }
+        } else if (k >= 1) {
+            // ---- consumer: E9 of step k-1 ----------------------------------------------------------------------------------
+            const PipeStage &st = stage[(k - 1) & 1];
+            const PipeRec<N> &rc = rec[(k - 1) & 1];
+            Agent ao;
+            ao.px = st.px[lane]; ao.py = st.py[lane]; ao.vx = st.vx[lane]; ao.vy = st.vy[lane];
+            ao.heading = rc.heading[lane]; ao.t_rem = 0.0;
+            ao.gx = ao.gy = ao.speed = 0.0f;
+            ao.radius = rc.radius[lane]; ao.pref = rc.pref[lane]; ao.flags = rc.flags[lane];
+            const Ego e = ego_from(rc.tx[lane], rc.ty[lane], ao.heading);
+            Key key[Others<N>::K];
+            float gapf[Others<N>::K];
+            key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f;
+#pragma unroll
+            for (int o = 0; o < N - 1; ++o) { key[o].hi = rc.key_hi[o][lane]; key[o].lo = rc.key_lo[o][lane]; gapf[o] = rc.gap[o][lane]; }
+            assemble_obs<N>(c, ao, e, active, lane, i, base, st.px, st.py, st.vx, st.vy, st.r, key, gapf, rc.valid[lane], tile,
+                            io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rc.rew[lane], rc.done[lane], wave);
+        }
+        __syncthreads();                                   // buffer (k & 1) is published, buffer ((k-1) & 1) is free again
+    }
+
+    // ---- state write-back (producer, once per launch) ---------------------------------------------------------------------
+    if (producer) {
+        if (restarted_any) {
+            store_agent(s, a_idx0, a);
+            if (i0 == 0) s.episode[w] = episode;
+        } else if (present_first) {
+            if (moved_any) {
+                s.px[a_idx0] = a.px; s.py[a_idx0] = a.py; s.heading[a_idx0] = a.heading; s.t_rem[a_idx0] = a.t_rem;
+            }
+            s.speed[a_idx0] = a.speed;
+            s.flags[a_idx0] = a.flags;
+        }
+    }
 }
 
 }  // namespace cavoid

@@ -23,6 +23,7 @@ struct cavoid_env {
     double *d_actions = nullptr;
     int waves_per_block = 4;
     int grid = 0;
+    int pipeline = 1;            // latency mode: the step loop as a two-wavefront pipeline per tile (CAVOID_PIPELINE=0: one wavefront)
     int latency_mode = 0;        // small batch: multi-step launches keep the next pool record in registers (MODE_STEP_AUTORESET_PF)
     int prefetch_single = 0;     // ... and single-step launches too (CAVOID_PREFETCH_POOL=1; costs 64 B of reads per agent-step)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -60,6 +61,44 @@ static inline int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int 
     return CAVOID_OK;
 }
 
+
+// The two-wavefront pipelined step loop (env_pipe_kernel): one 128-thread workgroup per tile.  Returns CAVOID_EUNSUPPORTED when
+// its LDS (two staging + two hand-over buffers, the obs tile, the ORCA scratch) does not fit 64 KiB: the caller then takes
+// the single-wavefront loop.
+template <bool RVO>
+static inline int launch_pipe(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const KCfg &k = e->k;
+    const int64_t tiles = (e->W + k.wpw - 1) / k.wpw;
+    // it pays while the chip can hold both wavefronts of every tile at <= 2 per SIMD (1024 SIMDs): measured at N = 4,
+    // 32-step launches: 512 / 1024 tiles 2.50 vs 3.02 / 3.06 us per step, 2048 tiles 5.05 vs 3.75; N = 10, 1366 tiles 9.4 vs 8.2
+    if (tiles > 1024) return CAVOID_EUNSUPPORTED;
+    const int row = io.obs ? io.obs_stride : k.width;
+    const size_t tail = (size_t)(((k.tile_rows * row + 3) & ~3) + k.rvo_lds_floats) * sizeof(float);
+    const dim3 grid((unsigned)tiles), block(128);
+#define CAVOID_PIPE_CASE(NN) \
+    case NN: {                                                                                                          \
+        const size_t lds = pipe_lds_fixed_bytes<NN>() + tail;                                                          \
+        if (lds > 65536) return CAVOID_EUNSUPPORTED;                                                                    \
+        if (ev_start || ev_stop)                                                                                        \
+            hipExtLaunchKernelGGL((env_pipe_kernel<NN, RVO>), grid, block, lds, s, ev_start, ev_stop, 0, k, e->st, e->pool, io); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((env_pipe_kernel<NN, RVO>), grid, block, lds, s, k, e->st, e->pool, io);                  \
+        break;                                                                                                          \
+    }
+    switch (e->cfg.max_agents) {
+#ifdef CAVOID_DEV_ONLY_N
+        CAVOID_PIPE_CASE(4) CAVOID_PIPE_CASE(10)
+#else
+        CAVOID_PIPE_CASE(1) CAVOID_PIPE_CASE(2) CAVOID_PIPE_CASE(3) CAVOID_PIPE_CASE(4) CAVOID_PIPE_CASE(5) CAVOID_PIPE_CASE(6)
+        CAVOID_PIPE_CASE(7) CAVOID_PIPE_CASE(8) CAVOID_PIPE_CASE(9) CAVOID_PIPE_CASE(10) CAVOID_PIPE_CASE(11) CAVOID_PIPE_CASE(12)
+        CAVOID_PIPE_CASE(13) CAVOID_PIPE_CASE(14) CAVOID_PIPE_CASE(15) CAVOID_PIPE_CASE(16)
+#endif
+        default: return CAVOID_EUNSUPPORTED;
+    }
+#undef CAVOID_PIPE_CASE
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}
 
 }  // namespace cavoid
 

@@ -7,6 +7,10 @@
 using namespace cavoid;
 
 int cavoid_launch_rvo(cavoid_env *e, int mode, const KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (mode == MODE_STEP_AUTORESET_PF && e->pipeline) {
+        const int rc = launch_pipe<true>(e, io, s, ev_start, ev_stop);
+        if (rc != CAVOID_EUNSUPPORTED) return rc;
+    }
     switch (mode) {
         case MODE_STEP: return launch_on<MODE_STEP, true>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
         case MODE_STEP_AUTORESET: return launch_on<MODE_STEP_AUTORESET, true>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
