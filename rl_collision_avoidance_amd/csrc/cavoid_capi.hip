@@ -247,6 +247,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     // footprint (and the wavefronts resident per CU) does not scale with N*(1+D)   [N=10: +7 % at saturation]
     // ORCA scratch: two sets of N-1 lines (4 doubles) per lane, only when RVO agents may exist
     k.rvo_lds_floats = cfg->rvo_enabled ? 64 * 2 * (N - 1) * 4 * 2 : 0;
+    k.park_floats = (N >= kParkFromN && !cfg->rvo_enabled) ? 3 * (N - 1) * 64 : 0;      // the tile region also parks the sort keys and gaps
     const int row_floats = k.width + 2;
     int tile_rows = (int)(9216 / ((size_t)row_floats * sizeof(float))) & ~3;
     if (tile_rows < 4) tile_rows = 4;
@@ -254,7 +255,11 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     if (tile_rows > lanes || (e->latency_mode && one_pass_fits)) tile_rows = lanes;
     if (const char *ov = std::getenv("CAVOID_TILE_ROWS")) { int v = std::atoi(ov); if (v >= 1 && v <= lanes) tile_rows = v; }
     // one wavefront must fit the 64 KiB a workgroup may ask for: with the ORCA scratch of a large N the tile shrinks
-    auto wave_bytes = [&](int rows) { return (size_t)(lds_floats_fixed() + k.rvo_lds_floats + ((rows * row_floats + 3) & ~3)) * sizeof(float); };
+    auto wave_bytes = [&](int rows) {
+        int tile = (rows * row_floats + 3) & ~3;
+        if (tile < k.park_floats) tile = k.park_floats;
+        return (size_t)(lds_floats_fixed() + k.rvo_lds_floats + tile) * sizeof(float);
+    };
     while (tile_rows > 4 && wave_bytes(tile_rows) + lds_floats_block() * sizeof(float) > 65536) tile_rows -= 4;
     k.tile_rows = tile_rows;
     const size_t per_wave = wave_bytes(tile_rows);

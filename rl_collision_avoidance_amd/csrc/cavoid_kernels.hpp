@@ -62,6 +62,7 @@ struct KCfg {
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
     int32_t wpw;                 // worlds per wavefront, 1..floor(64/N): small batches spread over more, emptier wavefronts
     int32_t rvo_lds_floats;      // per-wavefront LDS floats of the ORCA line scratch (0 unless rvo_enabled)
+    int32_t park_floats;         // N >= kParkFromN: the obs tile region is at least this large (it parks the sort keys / gaps)
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
@@ -371,18 +372,23 @@ __device__ __forceinline__ int key_bucket(const Key &k) { return (int)(kKeyBias 
 // tie-break inside a bucket) -- not the float64 values (the register budget decides how many wavefronts a
 // SIMD holds, and with it how much memory latency hides).  float32 rounding is monotonic, so two DIFFERENT
 // float32 laterals order exactly as the float64 ones do; equal keys fall back to the exact comparison.
-template <int N>
+// PARK (N >= kParkFromN): the keys and gaps do not stay in 3(N-1) registers from here to the observation rows; they are
+// parked in the wave-private obs-tile region of LDS (idle until the rows are written), field-major [3][N-1][64]:
+// key.hi, key.lo, gap.  The loop is then rolled three neighbours at a time (three square-root chains in flight instead of
+// N-1), which is what lets the N = 10 kernels fit 128 registers.
+constexpr int kParkFromN = 6;
+template <int N, bool PARK = false>
 __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
                                           const double *lds_px, const double *lds_py, const float *lds_r,
                                           Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K],
-                                          uint32_t &valid, bool &hit, double &min_gap) {
+                                          uint32_t &valid, bool &hit, double &min_gap, uint32_t *park = nullptr, int lane = 0) {
+    constexpr int K = Others<N>::K;
     const double ri = (double)a.radius;
     valid = 0u;
     hit = false;
     min_gap = INFINITY;
-    key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f;
-#pragma unroll
-    for (int o = 0; o < N - 1; ++o) {
+    if (!PARK) { key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f; }
+    auto one = [&](int o) {
         const int j = base + other_index(i, o, N);
         const float rjf = lds_r[j];
         const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
@@ -397,9 +403,24 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
         // the observation's gap, host-side association (d - r_host) - r_other; rint(gap*100) is
         // order-isomorphic to round(gap, 2) and integer-valued: exact in int32 (|gap| < 1e7 m)
         const double gap_o = d - ri - (double)rjf;
-        gapf[o] = (float)gap_o;
-        key[o].hi = seen ? kKeyBias - (uint32_t)(int)rint(gap_o * 100.0) : 0x7FFFFFFFu;
-        key[o].lo = seen ? orderable((float)(ry * e.tx - rx * e.ty)) : (uint32_t)o;
+        const uint32_t hi = seen ? kKeyBias - (uint32_t)(int)rint(gap_o * 100.0) : 0x7FFFFFFFu;
+        const uint32_t lo = seen ? orderable((float)(ry * e.tx - rx * e.ty)) : (uint32_t)o;
+        if (PARK) {
+            park[(0 * K + o) * 64 + lane] = hi;
+            park[(1 * K + o) * 64 + lane] = lo;
+            park[(2 * K + o) * 64 + lane] = __float_as_uint((float)gap_o);
+        } else {
+            gapf[o] = (float)gap_o;
+            key[o].hi = hi;
+            key[o].lo = lo;
+        }
+    };
+    if (PARK) {
+#pragma unroll 3
+        for (int o = 0; o < N - 1; ++o) one(o);
+    } else {
+#pragma unroll
+        for (int o = 0; o < N - 1; ++o) one(o);
     }
 }
 
@@ -427,57 +448,43 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
     }
 }
 
-// Ranking by a round-robin tournament in integer arithmetic.  For every unordered pair (p, q), p < q, one bit says
-// "p comes first" (the borrow of the 64-bit difference of their keys); the position of a neighbour in the order is the
-// number of pairs it lost.  No wave masks are produced (a comparison per pair would park 2 x N(N-1)/2 of them in scalar
-// registers) and no branch is taken; `tie` comes back true when two keys were EQUAL (then the caller ranks the exact way).
-template <int NO>
-struct Tournament {
-    static constexpr int kPairs = NO * (NO - 1) / 2;
-    uint32_t t[(kPairs + 31) / 32 > 0 ? (kPairs + 31) / 32 : 1];
-    template <bool ASC_BUCKET, int KK>
-    __device__ __forceinline__ bool play(const Key (&key)[KK]) {
-#pragma unroll
-        for (int w = 0; w < (int)(sizeof(t) / sizeof(t[0])); ++w) t[w] = 0u;
-        uint32_t differ = 0xFFFFFFFFu;
-        int k = 0;
-#pragma unroll
-        for (int p = 0; p < NO; ++p)
-#pragma unroll
-            for (int q = p + 1; q < NO; ++q, ++k) {
-                // near -> far order (closest_first) flips the bucket half of the key; sentinels stay on top
-                const uint64_t kp = ((uint64_t)(ASC_BUCKET ? ((key[p].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[p].hi) : key[p].hi) << 32) | key[p].lo;
-                const uint64_t kq = ((uint64_t)(ASC_BUCKET ? ((key[q].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[q].hi) : key[q].hi) << 32) | key[q].lo;
-                const uint64_t d = kp - kq;                              // both < 2^63: bit 63 of d <=> kp < kq
-                t[k >> 5] |= (uint32_t)(d >> 63) << (k & 31);
-                const uint32_t nz = (uint32_t)d | (uint32_t)(d >> 32);
-                differ = nz < differ ? nz : differ;
-            }
-        return differ == 0u;
-    }
-    // number of neighbours that come before o
-    __device__ __forceinline__ int position(int o) const {
-        int lost = 0, k = 0;
-#pragma unroll
-        for (int p = 0; p < NO; ++p)
-#pragma unroll
-            for (int q = p + 1; q < NO; ++q, ++k) {
-                const uint32_t bit = (t[k >> 5] >> (k & 31)) & 1u;
-                if (q == o) lost += (int)bit;                            // p came first
-                if (p == o) lost += (int)(bit ^ 1u);                     // q came first
-            }
-        return lost;
-    }
-};
-
 // slot numbers of the (up to 15) others of a lane, 4 bits each, in two registers instead of N-1
 struct Slots {
-    uint64_t v;
-    __device__ __forceinline__ void clear() { v = 0ull; }
-    __device__ __forceinline__ void set(int o, int slot) { v |= (uint64_t)(uint32_t)slot << (4 * o); }
-    __device__ __forceinline__ int get(int o) const { return (int)((v >> (4 * o)) & 15ull); }
+    uint32_t lo, hi;                                             // others 0..7, 8..15
+    __device__ __forceinline__ void clear() { lo = 0u; hi = 0u; }
+    __device__ __forceinline__ void bump(int o, uint32_t bit) {  // += bit at field o (one v_lshl_add_u32)
+        if (o < 8) lo += bit << (4 * o); else hi += bit << (4 * (o - 8));
+    }
+    __device__ __forceinline__ void set(int o, int slot) { bump(o, (uint32_t)slot); }
+    __device__ __forceinline__ int get(int o) const { return (int)(((o < 8 ? lo : hi) >> (4 * (o & 7))) & 15u); }
 };
 static_assert(CAVOID_MAX_AGENTS - 1 <= 15, "a slot number must fit 4 bits");
+
+// Ranking by a round-robin tournament in integer arithmetic.  For every unordered pair (p, q), p < q, the borrow of the
+// 64-bit difference of their keys says "p comes first"; the loser's packed counter is bumped, so a neighbour's position in
+// the order = the number of pairs it lost.  No wave masks are produced (a comparison per pair would park 2 x N(N-1)/2 of
+// them in scalar registers), no branch is taken, nine instructions per pair; `tie` comes back true when two keys were EQUAL
+// (then the caller ranks the exact way).
+template <int NO, bool ASC_BUCKET, int KK>
+__device__ __forceinline__ bool tournament(const Key (&key)[KK], Slots &pos) {
+    pos.clear();
+    uint32_t differ = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = 0; p < NO; ++p)
+#pragma unroll
+        for (int q = p + 1; q < NO; ++q) {
+            // near -> far order (closest_first) flips the bucket half of the key; sentinels stay on top
+            const uint64_t kp = ((uint64_t)(ASC_BUCKET ? ((key[p].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[p].hi) : key[p].hi) << 32) | key[p].lo;
+            const uint64_t kq = ((uint64_t)(ASC_BUCKET ? ((key[q].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[q].hi) : key[q].hi) << 32) | key[q].lo;
+            const uint64_t d = kp - kq;                              // both < 2^63: bit 63 of d <=> kp < kq <=> p first
+            const uint32_t p_first = (uint32_t)(d >> 63);
+            pos.bump(q, p_first);                                    // q lost
+            pos.bump(p, p_first ^ 1u);                               // p lost
+            const uint32_t nz = (uint32_t)d | (uint32_t)(d >> 32);
+            differ = nz < differ ? nz : differ;
+        }
+    return differ == 0u;
+}
 
 // the same for a compile-time float count (the common shape: a full wavefront of rows of the default width): every
 // round but the last is unpredicated
@@ -512,13 +519,25 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
 // E9: neighbour ordering by counting ranks, the lane's observation row into the LDS tile, and the
 // coalesced write-out.  The tile holds c.tile_rows rows; wide rows (large N) go out in several passes so
 // that the LDS footprint -- and with it the wavefronts resident per CU -- does not scale with N*(1+D).
-template <int N>
+template <int N, bool PARK = false>
 __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
-                                             const double *lds_vy, const float *lds_r, const Key (&key)[Others<N>::K],
-                                             const float (&gapf)[Others<N>::K], uint32_t valid, float *tile,
+                                             const double *lds_vy, const float *lds_r, const Key (&key_in)[Others<N>::K],
+                                             const float (&gapf_in)[Others<N>::K], uint32_t valid, float *tile,
                                              float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave) {
     constexpr int K = Others<N>::K, NO = N - 1;
+    // PARK: the pair pass left keys and gaps in the tile region (pair_pass); they come back into registers only now
+    Key key[K];
+    float gapf[K];
+#pragma unroll
+    for (int o = 0; o < K; ++o) {
+        if (PARK) {
+            const uint32_t *park = reinterpret_cast<const uint32_t *>(tile);
+            key[o].hi = o < NO ? park[(0 * K + o) * 64 + lane] : 0x7FFFFFFFu;
+            key[o].lo = o < NO ? park[(1 * K + o) * 64 + lane] : 0u;
+            gapf[o] = 0.0f;                                      // (fetched after the ranking, just before the rows are written)
+        } else { key[o] = key_in[o]; gapf[o] = gapf_in[o]; }
+    }
     const int M = c.max_other, width = c.width;
     const bool present = active && (a.flags & CAVOID_F_PRESENT);
     const double ri = (double)a.radius;
@@ -552,13 +571,8 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     uint32_t keep = 0u;
     bool generic = c.sort_method == CAVOID_SORT_TIME_TO_IMPACT;
     if (!generic) {
-        Tournament<NO> tour;                                   // far -> near: larger bucket first, then smaller lateral
-        const bool tie = tour.template play<false>(key);
+        const bool tie = tournament<NO, false>(key, pos);      // far -> near: larger bucket first, then smaller lateral
         generic = __ballot(tie) != 0ull;                        // wave-uniform: redo this tile's ranks the exact way
-        if (!generic) {
-#pragma unroll
-            for (int o = 0; o < NO; ++o) pos.set(o, tour.position(o));
-        }
     }
     if (generic) {
         int gpos[K];
@@ -610,13 +624,9 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
             k2[o].hi = ((keep >> o) & 1u) ? key[o].hi : 0x7FFFFFFFu;
             k2[o].lo = ((keep >> o) & 1u) ? key[o].lo : (uint32_t)o;
         }
-        Tournament<NO> tour;
-        const bool tie = tour.template play<true>(k2);
-        pos.clear();
-        if (__ballot(tie) == 0ull) {
-#pragma unroll
-            for (int o = 0; o < NO; ++o) pos.set(o, tour.position(o));
-        } else {
+        const bool tie = tournament<NO, true>(k2, pos);
+        if (__ballot(tie) != 0ull) {
+            pos.clear();
             int gpos[K];
 #pragma unroll
             for (int o = 0; o < K; ++o) gpos[o] = 0;
@@ -636,6 +646,12 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     }
 
     CAVOID_STAMP(9);                                             // ranks done
+    if (PARK) {                                                  // the gaps come back into registers; then the region is free for the rows
+        const uint32_t *park = reinterpret_cast<const uint32_t *>(tile);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) gapf[o] = __uint_as_float(park[(2 * K + o) * 64 + lane]);
+        wave_lds_sync();
+    }
     const int rpp = c.tile_rows;                                 // rows per pass
     for (int p0 = 0; p0 < rows_active; p0 += rpp) {
     if (active && lane >= p0 && lane < p0 + rpp) {
@@ -900,7 +916,9 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int width = c.width, ostride = io.obs ? io.obs_stride : width;
-    const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
+    constexpr bool kPark = N >= kParkFromN && !RVO;          // (the RVO instantiations need their LDS for the ORCA lines)
+    const int tile_need = (c.tile_rows * ostride + 3) & ~3;
+    const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
     const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
     double *lds_tab = reinterpret_cast<double *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
@@ -1097,7 +1115,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     uint32_t valid;
     bool hit;
     double min_gap;
-    pair_pass<N>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap);
+    pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, reinterpret_cast<uint32_t *>(tile), lane);
 
     CAVOID_STAMP(4);                                        // ego frame + pair pass done
     float rew_f = 0.0f, done_f = (present && (a.flags & CAVOID_F_DONE_MASK) == 0u) ? 0.0f : 1.0f;   // reset / observe, packed
@@ -1149,7 +1167,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
                     e = ego_frame_obs(a);
                     bool hit2;
                     double gap2;
-                    pair_pass<N>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit2, gap2);
+                    pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit2, gap2, reinterpret_cast<uint32_t *>(tile), lane);
                 }
             }
         }
@@ -1159,7 +1177,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     // ---- E9 observation: once per step, after the restart decision -----------------------------------
     if (io.obs) {
         CAVOID_STAMP(6);
-        assemble_obs<N>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, key, gapf, valid, tile,
+        assemble_obs<N, kPark>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, key, gapf, valid, tile,
                         io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave);
     }
     CAVOID_STAMP(7);                                        // tile flushed
@@ -1228,7 +1246,8 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
     PipeRec<N> *rec = reinterpret_cast<PipeRec<N> *>(stage + 2);
     float *tile = reinterpret_cast<float *>(rec + 2);
     const int width = c.width, ostride = io.obs_stride;
-    const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
+    const int tile_need = (c.tile_rows * ostride + 3) & ~3;
+    const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
     double *rvo_mem = reinterpret_cast<double *>(tile + tile_floats);
     const bool producer = (threadIdx.x >> 6) == 0;
     const int lane0 = threadIdx.x & 63;

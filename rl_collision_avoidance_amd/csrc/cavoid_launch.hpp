@@ -38,7 +38,9 @@ static inline int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int 
     const dim3 grid(grid_x), block(64 * e->waves_per_block);
     // dynamic LDS: the action table + per wavefront the staging arrays and an obs tile of this launch's row width
     const int row = io.obs ? io.obs_stride : k.width;
-    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed() + k.rvo_lds_floats + ((k.tile_rows * row + 3) & ~3))) * sizeof(float);
+    int tile = (k.tile_rows * row + 3) & ~3;
+    if (tile < k.park_floats) tile = k.park_floats;
+    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed() + k.rvo_lds_floats + tile)) * sizeof(float);
 #define CAVOID_CASE(NN) \
     case NN:                                                                                                            \
         if (ev_start || ev_stop)                                                                                        \
@@ -73,7 +75,9 @@ static inline int launch_pipe(cavoid_env *e, const KIO &io, hipStream_t s, hipEv
     // 32-step launches: 512 / 1024 tiles 2.50 vs 3.02 / 3.06 us per step, 2048 tiles 5.05 vs 3.75; N = 10, 1366 tiles 9.4 vs 8.2
     if (tiles > 1024) return CAVOID_EUNSUPPORTED;
     const int row = io.obs ? io.obs_stride : k.width;
-    const size_t tail = (size_t)(((k.tile_rows * row + 3) & ~3) + k.rvo_lds_floats) * sizeof(float);
+    int tile = (k.tile_rows * row + 3) & ~3;
+    if (tile < k.park_floats) tile = k.park_floats;
+    const size_t tail = (size_t)(tile + k.rvo_lds_floats) * sizeof(float);
     const dim3 grid((unsigned)tiles), block(128);
 #define CAVOID_PIPE_CASE(NN) \
     case NN: {                                                                                                          \
