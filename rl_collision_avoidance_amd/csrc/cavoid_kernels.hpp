@@ -1301,6 +1301,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 const uint32_t flags_in = a.flags;
                 const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
                 const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
+                CAVOID_STAMP(2);
                 int act = act_next;
                 if (t + 1 < n_steps && active) act_next = io.actions[(int64_t)(t + 1) * io.action_stride + a_idx];
                 // ---- E4 decode -----------------------------------------------------------------------------------------
@@ -1356,6 +1357,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                     a.t_rem -= c.dt;
                     if (c.timeout_enabled && a.t_rem <= 0.0) a.flags |= CAVOID_F_RAN_OUT;
                 }
+                CAVOID_STAMP(3);
                 // ---- stage, E6 pair pass -------------------------------------------------------------------------------
                 bool present = active && (a.flags & CAVOID_F_PRESENT);
                 st.px[lane] = a.px; st.py[lane] = a.py; st.vx[lane] = a.vx; st.vy[lane] = a.vy;
@@ -1369,6 +1371,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 bool hit;
                 double min_gap;
                 pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit, min_gap);
+                CAVOID_STAMP(4);
                 // ---- E7 rewards, E8 done -------------------------------------------------------------------------------
                 double r = 0.0;
                 bool done = true;
@@ -1416,17 +1419,20 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                         pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit2, gap2);
                     }
                 }
+                CAVOID_STAMP(5);
                 // ---- hand over to the consumer ---------------------------------------------------------------------------
                 rc.tx[lane] = e.tx; rc.ty[lane] = e.ty; rc.heading[lane] = a.heading;
                 rc.pref[lane] = a.pref; rc.radius[lane] = a.radius; rc.rew[lane] = rew_f; rc.done[lane] = done_f;
                 rc.flags[lane] = a.flags; rc.valid[lane] = valid;
 #pragma unroll
                 for (int o = 0; o < N - 1; ++o) { rc.key_hi[o][lane] = key[o].hi; rc.key_lo[o][lane] = key[o].lo; rc.gap[o][lane] = gapf[o]; }
+                CAVOID_STAMP(8);
             }
         } else if (k >= 1) {
             // ---- consumer: E9 of step k-1 ----------------------------------------------------------------------------------
             const PipeStage &st = stage[(k - 1) & 1];
             const PipeRec<N> &rc = rec[(k - 1) & 1];
+            CAVOID_STAMP(6);
             Agent ao;
             ao.px = st.px[lane]; ao.py = st.py[lane]; ao.vx = st.vx[lane]; ao.vy = st.vy[lane];
             ao.heading = rc.heading[lane]; ao.t_rem = 0.0;
@@ -1440,8 +1446,10 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
             for (int o = 0; o < N - 1; ++o) { key[o].hi = rc.key_hi[o][lane]; key[o].lo = rc.key_lo[o][lane]; gapf[o] = rc.gap[o][lane]; }
             assemble_obs<N>(c, ao, e, active, lane, i, base, st.px, st.py, st.vx, st.vy, st.r, key, gapf, rc.valid[lane], tile,
                             io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rc.rew[lane], rc.done[lane], wave);
+            CAVOID_STAMP(7);
         }
-        __syncthreads();                                   // buffer (k & 1) is published, buffer ((k-1) & 1) is free again
+        __syncthreads();
+        if (producer) CAVOID_STAMP(1); else CAVOID_STAMP(0);                                   // buffer (k & 1) is published, buffer ((k-1) & 1) is free again
     }
 
     // ---- state write-back (producer, once per launch) ---------------------------------------------------------------------

@@ -55,6 +55,11 @@ def main():
         print("rep %d: launch span (first wave start -> last wave end) = %d clk; per-wave total median %d max %d"
               % (rep, t[:, 8].max() - t0, np.median(t[:, 8] - t[:, 0]), (t[:, 8] - t[:, 0]).max()))
         print("   wave start spread: %d clk" % (t[:, 0].max() - t0))
+        if K > 1 and (t[:, 1] > 0).all():      # the two-wavefront pipeline: producer stamps 2,3,4,5,8,1 / consumer 6,9,10,7,0
+            for a, b, nm in ((2, 3, "P decode+dynamics"), (3, 4, "P stage+pairs"), (4, 5, "P rewards/restart"), (5, 8, "P hand-over"),
+                             (8, 1, "P wait at barrier"), (6, 9, "C ego+ranking"), (9, 10, "C rows"), (10, 7, "C flush"), (7, 0, "C wait at barrier")):
+                d = t[:, b] - t[:, a]
+                print("   [pipe] %-20s median %6d  p90 %6d" % (nm, np.median(d), np.percentile(d, 90)))
         for a, b in ((6, 9), (9, 10), (10, 7)):
             d = t[:, b] - t[:, a]
             print("   [obs] %d -> %d median %6d  p90 %6d" % (a, b, np.median(d), np.percentile(d, 90)))
