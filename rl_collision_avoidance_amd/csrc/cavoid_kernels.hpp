@@ -916,7 +916,10 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int width = c.width, ostride = io.obs ? io.obs_stride : width;
-    constexpr bool kPark = N >= kParkFromN && !RVO;          // (the RVO instantiations need their LDS for the ORCA lines)
+    // parking pays where occupancy is the limit -- one step per launch (N = 10: 216 -> 162 VGPRs, 3 wavefronts/SIMD, saturated
+    // 272 -> 235 us); the step-loop instantiations stay at 2 wavefronts/SIMD either way and lose ILP to the rolled pair loop
+    // (204 -> 212 us), and the RVO instantiations need their LDS for the ORCA lines
+    constexpr bool kPark = N >= kParkFromN && !RVO && MODE != MODE_STEP_AUTORESET_PF && MODE != MODE_STEP_AUTORESET_N;
     const int tile_need = (c.tile_rows * ostride + 3) & ~3;
     const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
     const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
