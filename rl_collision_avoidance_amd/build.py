@@ -11,12 +11,13 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
 SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_multistep.hip"), os.path.join(CSRC, "cavoid_rvo.hip"),
-           os.path.join(CSRC, "cavoid_rollout_capi.hip"),
+           os.path.join(CSRC, "cavoid_relay.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
            os.path.join(CSRC, "cavoid_policy_capi.hip"), os.path.join(CSRC, "cavoid_comm_capi.hip")]
 HEADERS = {
     "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_multistep.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rvo.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
+    "cavoid_relay.hip": ["cavoid_kernels.hpp", "cavoid_relay.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_host.hpp"],
     "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_policy_split.hpp", "cavoid_host.hpp"],
     "cavoid_comm_capi.hip": ["cavoid_host.hpp"],
@@ -24,7 +25,8 @@ HEADERS = {
 # per-file extra flags.  The multi-step env kernels run their step loop inside the launch; MachineLICM would hoist every
 # constant materialisation of the body (float64 polynomial coefficients, config scalars) out of that loop into
 # registers live across it: 128 VGPRs + 276 B/lane of scratch instead of 128 VGPRs + 12 B (N = 4).
-EXTRA_FLAGS = {"cavoid_multistep.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_rvo.hip": ["-mllvm", "-disable-machine-licm"]}
+EXTRA_FLAGS = {"cavoid_multistep.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_rvo.hip": ["-mllvm", "-disable-machine-licm"],
+               "cavoid_relay.hip": ["-mllvm", "-disable-machine-licm"]}
 STAMP_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so.stamp")
 DEPS = SOURCES + [os.path.join(CSRC, h) for hs in HEADERS.values() for h in hs] + [os.path.join(ROOT, "include", "cavoid.h")]
 OBJ_DIR = os.path.join(PKG_DIR, "build")

@@ -241,7 +241,11 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
         e->prefetch_single = e->latency_mode;
     }
     k.prefetch_pool = e->latency_mode;
-    if (const char *ov = std::getenv("CAVOID_PIPELINE")) e->pipeline = std::atoi(ov) != 0;
+    if (const char *ov = std::getenv("CAVOID_PIPELINE")) e->pipeline = std::atoi(ov);
+    if (const char *ov = std::getenv("CAVOID_RELAY_CONSUMERS")) {
+        const int v = std::atoi(ov);
+        if (v >= 1 && v <= cavoid::kRelayMaxConsumers) e->relay_consumers = v;
+    }
     // obs tile (rows of width + 2 floats: the packed record is the widest row): the wavefront's rows in ONE pass when
     // the batch is latency bound or when they fit ~9 KiB; else several passes of a multiple of 4 rows, so that the LDS
     // footprint (and the wavefronts resident per CU) does not scale with N*(1+D)   [N=10: +7 % at saturation]
@@ -490,10 +494,13 @@ extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actio
 // development build only: point the kernels' phase-stamp buffer (u64 [waves][16]) somewhere
 int cavoid_debug_trace_multistep(unsigned long long *dev_ptr);
 int cavoid_debug_trace_rvo(unsigned long long *dev_ptr);
+int cavoid_debug_trace_relay(unsigned long long *dev_ptr);
 extern "C" int cavoid_debug_trace(unsigned long long *dev_ptr) {
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dev_ptr, sizeof(dev_ptr)));
     const int rc = cavoid_debug_trace_multistep(dev_ptr);
-    return rc != CAVOID_OK ? rc : cavoid_debug_trace_rvo(dev_ptr);
+    if (rc != CAVOID_OK) return rc;
+    const int rc2 = cavoid_debug_trace_rvo(dev_ptr);
+    return rc2 != CAVOID_OK ? rc2 : cavoid_debug_trace_relay(dev_ptr);
 }
 #endif
 

@@ -45,6 +45,7 @@ __device__ unsigned long long *g_trace = nullptr;
 #endif
 
 constexpr double kPi = 3.14159265358979323846;
+constexpr int kRelayMaxConsumers = 4;   // observation wavefronts per tile of env_relay_kernel (cavoid_relay.hpp)
 
 // kernel-argument POD (by value).  The action table lives in device memory (per-lane index).
 struct KCfg {
@@ -564,12 +565,16 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
 // E9: neighbour ordering by counting ranks, the lane's observation row into the LDS tile, and the
 // coalesced write-out.  The tile holds c.tile_rows rows; wide rows (large N) go out in several passes so
 // that the LDS footprint -- and with it the wavefronts resident per CU -- does not scale with N*(1+D).
-template <int N, bool PARK = false, bool LEAN = PARK>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// PreFlush: called once, right before the first global store of the tile (env_relay_kernel orders the last step's rows behind
+// the rows of the steps before it, which other wavefronts write)
+template <int N, bool PARK = false, bool LEAN = PARK, class PreFlush = NoHook>
 __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
                                              const double *lds_vy, const float *lds_r, const Key (&key_in)[Others<N>::K],
                                              const float (&gapf_in)[Others<N>::K], uint32_t valid, float *tile,
-                                             float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave) {
+                                             float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave,
+                                             PreFlush pre_flush = PreFlush()) {
     constexpr int K = Others<N>::K, NO = N - 1;
     // PARK: the pair pass left keys and gaps in the tile region (pair_pass); they come back into registers only now
     Key key[K];
@@ -744,6 +749,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     }
     wave_lds_sync();
     CAVOID_STAMP(10);                                            // rows in the LDS tile
+    if (p0 == 0) pre_flush();
     const int rows_here = rows_active - p0 < rpp ? rows_active - p0 : rpp;
     {
         constexpr int kRows = (64 / N) * N, kW = 6 + 7 * (N - 1);   // a full wavefront, the default row widths

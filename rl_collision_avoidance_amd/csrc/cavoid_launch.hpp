@@ -23,7 +23,9 @@ struct cavoid_env {
     double *d_actions = nullptr;
     int waves_per_block = 4;
     int grid = 0;
-    int pipeline = 1;            // latency mode: the step loop as a two-wavefront pipeline per tile (CAVOID_PIPELINE=0: one wavefront)
+    int pipeline = 2;            // latency mode, multi-step launches: 2 = env_relay_kernel (roles on 5-7 wavefronts per tile), 1 = env_pipe_kernel
+                                 // (two wavefronts per tile), 0 = one wavefront per tile (CAVOID_PIPELINE)
+    int relay_consumers = 3;     // observation wavefronts per tile of env_relay_kernel (CAVOID_RELAY_CONSUMERS, 1..4)
     int latency_mode = 0;        // small batch: multi-step launches keep the next pool record in registers (MODE_STEP_AUTORESET_PF)
     int prefetch_single = 0;     // ... and single-step launches too (CAVOID_PREFETCH_POOL=1; costs 64 B of reads per agent-step)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -106,6 +108,8 @@ static inline int launch_pipe(cavoid_env *e, const KIO &io, hipStream_t s, hipEv
 
 }  // namespace cavoid
 
+// env_relay_kernel (cavoid_relay.hip): CAVOID_EUNSUPPORTED when the batch is too large for it or its LDS does not fit
+int cavoid_launch_relay(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-step auto-reset launch (cavoid_multistep.hip): prefetch != 0 -> MODE_STEP_AUTORESET_PF, else MODE_STEP_AUTORESET_N
 int cavoid_launch_multistep(cavoid_env *e, const cavoid::KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // any stepping mode for an env with rvo_enabled (cavoid_rvo.hip: the instantiations that carry the ORCA policy)

@@ -9,7 +9,11 @@ using namespace cavoid;
 
 int cavoid_launch_multistep(cavoid_env *e, const KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (e->k.rvo_enabled) return cavoid_launch_rvo(e, prefetch ? MODE_STEP_AUTORESET_PF : MODE_STEP_AUTORESET_N, io, s, ev_start, ev_stop);
-    if (prefetch && e->pipeline) {                          // small batch: two wavefronts per tile, pipelined (env_pipe_kernel)
+    if (prefetch && e->pipeline >= 2) {                     // small batch: the step cut into roles on several wavefronts (env_relay_kernel)
+        const int rc = cavoid_launch_relay(e, io, s, ev_start, ev_stop);
+        if (rc != CAVOID_EUNSUPPORTED) return rc;
+    }
+    if (prefetch && e->pipeline) {                          // two wavefronts per tile, pipelined (env_pipe_kernel)
         const int rc = launch_pipe<false>(e, io, s, ev_start, ev_stop);
         if (rc != CAVOID_EUNSUPPORTED) return rc;
     }

@@ -1,0 +1,489 @@
+// cavoid_relay.hpp -- env_relay_kernel<N>: the in-launch step loop for SMALL batches, one workgroup per tile, the step cut
+// into roles that run on different wavefronts (different SIMDs of one CU) and relay through LDS.
+//
+// Why: at 4 agents x 8192 worlds there are 512 tiles for 1024 SIMDs, so the time of a step is the LENGTH OF ONE
+// DEPENDENT CHAIN (action -> sincos -> position -> LDS -> sqrt -> gap -> flags -> ballot -> restart -> next action ...), not
+// issue or memory bandwidth.  env_pipe_kernel took the observation off that chain (two wavefronts per tile); this kernel
+// also takes the DYNAMICS off it.  The only true recurrence of the step is
+//      positions(t) -> pair pass -> new collisions / game over (t) -> which agents move, which worlds restart at t+1,
+// everything else of step t+1 -- decode, heading, sincos, position, goal test, time budget -- does not need the pair pass
+// of step t unless an agent collided or the world restarted at t.  So:
+//
+//   D  (state owner)   holds the tile's state in registers for the whole launch.  While P works on step t it computes the
+//                      successor T_c = advance(T(t), action(t+1)) as if nothing happened at t.  When P's verdict arrives it
+//                      only SELECTS: agent done (incl. a collision found at t) -> frozen copy; else T_c -- and posts the next
+//                      tentative state BEFORE it writes step t's final state for the consumers.  A restart (a wave-uniform
+//                      branch, about every third step of a 16-world tile) advances the next pool record on the spot.
+//   P  (pair pass)     distances, collision test, nearest gap, reward, done, game_over of step t from the staged tentative
+//                      state; verdict back to D -- D-commit + P is the loop-carried chain -- and only then the sort keys and
+//                      gaps of the same pass for the consumers.
+//   C0..C{NC-1}        observation of step t (ego frame, ranking, rows, coalesced flush) from the FINAL state of step t,
+//                      steps dealt round-robin: each consumer has NC step times per step.  After a restart in the tile the
+//                      consumer redoes the pair pass on the new positions (P's keys are of the world that ended).
+//   L  (loader)        everything that touches memory inside the loop and is not an output: the action block (a 64-step
+//                      byte ring in LDS, filled ahead of D) and the next scenario-pool record of every restarted lane.
+//
+// Same arithmetic per value, in the same operation order, as env_kernel: outputs and state are bit-identical
+// (tests/test_gpu_packed.py, test_gpu_parity.py run through this kernel by default).  Synchronisation: sequence counters in
+// LDS, polled (s_sleep); an LDS write of a wavefront is visible to the workgroup in issue order, so "data, then counter" on
+// the writer and "counter, then data" on the reader is enough -- no workgroup barrier and no vmcnt drain inside the loop.
+#pragma once
+#include "cavoid_kernels.hpp"
+
+namespace cavoid {
+
+constexpr int kRelayRing = 4;            // depth of the final-state ring (steps in flight between D and the consumers)
+constexpr int kRelayActRing = 64;        // action ring: steps
+constexpr int kRelayActAhead = 48;       // the loader runs at most this many steps ahead of D
+constexpr int kRelayEvq = 8;             // restart-event queue D -> L
+
+struct RelaySeq {                        // sequence counters (each written by exactly one wavefront)
+    int stage;                           // D: tentative state of steps < stage is in `tent`
+    int res;                             // P: verdicts of steps < res are in `res`
+    int fin;                             // D: final state of steps < fin is in the ring
+    int keys;                            // P: sort keys / gaps of steps < keys are in the key ring
+    int act;                             // L: actions of steps < act are in the ring
+    int ev;                              // D: restart events posted
+    int nxt;                             // L: restart events served (pool records of the restarted lanes re-armed)
+    int cons[kRelayMaxConsumers];        // C: steps < cons[c] of consumer c's share are flushed (ring slots free)
+    int cfin[kRelayMaxConsumers];        // C: all of the consumer's stores have completed
+    int pad[1];
+};
+struct RelayTent { double px[64], py[64]; float r[64], gx[64], gy[64]; uint32_t flags[64]; };
+struct RelayRes { uint32_t flags[64], ctl[64]; float rew[64]; };             // ctl: bit 0 done, bit 1 the lane's world restarts
+struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], gy[64], radius[64], pref[64]; uint32_t flags[64]; };
+struct RelayFin {
+    double px[64], py[64], vx[64], vy[64], heading[64];
+    float r[64], gx[64], gy[64], pref[64], rew[64], done[64];
+    uint32_t flags[64], ctl[64];
+};
+template <int N>
+struct RelayKeys {
+    static constexpr int K = Others<N>::K;
+    uint32_t key_hi[K][64], key_lo[K][64];
+    float gap[K][64];
+    uint32_t valid[64];
+};
+
+template <int N>
+__host__ __device__ constexpr size_t relay_lds_fixed_bytes() {
+    return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + sizeof(RelayTent) + sizeof(RelayRes) +
+           sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long) + kRelayRing * (sizeof(RelayFin) + sizeof(RelayKeys<N>));
+}
+
+// development build: lane 0 of a role stamps the shader clock of step n_steps/2 into g_trace[tile*32 + k] (tools/trace_relay.py)
+#ifdef CAVOID_TRACE
+#define RELAY_STAMP(k)                                                                                         \
+    do {                                                                                                       \
+        if (lane0 == 0 && g_trace && t == (n_steps >> 1)) g_trace[wave * 32 + (k)] = (unsigned long long)clock64(); \
+    } while (0)
+#else
+#define RELAY_STAMP(k) do { } while (0)
+#endif
+
+// the counters are read and written through explicit LDS (address space 3) volatile pointers: ds_read_b32 / ds_write_b32, not
+// the flat system-coherent accesses a generic volatile pointer compiles to
+typedef __attribute__((address_space(3))) volatile int relay_lds_int;
+__device__ __forceinline__ int relay_peek(const int *p) { return __builtin_amdgcn_readfirstlane(*(relay_lds_int *)p); }
+__device__ __forceinline__ void relay_wait(const int *p, int v) {
+    while (relay_peek(p) < v) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+// the two waits of the loop-carried chain (D for P's verdict, P for D's next state) poll without sleeping
+__device__ __forceinline__ void relay_spin(const int *p, int v) {
+    while (relay_peek(p) < v) { }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void relay_post(int *p, int v) {
+    asm volatile("" ::: "memory");        // the data writes are issued before the counter (LDS keeps a wavefront's order)
+    *(relay_lds_int *)p = v;
+    asm volatile("" ::: "memory");
+}
+
+// One agent's step up to (not including) the pair pass: E4 decode, scripted policies 1 / 2, E5 unicycle dynamics, goal test,
+// time budget -- env_kernel's statements, value for value.
+__device__ __forceinline__ Agent relay_advance(const KCfg &c, const Agent &in, int act, bool active, const double *lds_tab, bool &moving) {
+    Agent a = in;
+    const uint32_t flags_in = a.flags;
+    const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
+    const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
+    const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
+    double a0 = (double)a.pref * lds_tab[2 * act];
+    double a1 = lds_tab[2 * act + 1];
+    if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {
+        if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
+        if (pol == 2u) {
+            const Ego e0 = ego_frame_exact(a);
+            a0 = (double)a.pref;
+            a1 = -e0.heading_ego;
+        }
+    }
+    if (c.actions_fp32) { a0 = (double)(float)a0; a1 = (double)(float)a1; }
+    moving = present_in && !done_in;
+    double dh = a1;
+    if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
+        const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
+        dh = rate * c.dt;
+    }
+    const double nh = wrap_angle(dh + a.heading);
+    double sn, cs;
+    sincos_bounded(nh, &sn, &cs);
+    const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
+    const double nvx = a0 * cs, nvy = a0 * sn, nsp = a0;
+    a.px = moving ? npx : a.px; a.py = moving ? npy : a.py; a.heading = moving ? nh : a.heading;
+    a.vx = moving ? nvx : 0.0; a.vy = moving ? nvy : 0.0; a.speed = moving ? (float)nsp : 0.0f;
+    if (present_in && done_in) {
+        if (flags_in & CAVOID_F_AT_GOAL) a.flags |= CAVOID_F_WAS_AT_GOAL;
+        if (flags_in & CAVOID_F_IN_COLL) a.flags |= CAVOID_F_WAS_IN_COLL;
+    }
+    if (moving) {
+        const double dx = a.px - (double)a.gx, dy = a.py - (double)a.gy;
+        if (dx * dx + dy * dy <= c.near_goal_sq) a.flags |= CAVOID_F_AT_GOAL;
+        a.t_rem -= c.dt;
+        if (c.timeout_enabled && a.t_rem <= 0.0) a.flags |= CAVOID_F_RAN_OUT;
+    }
+    return a;
+}
+
+__device__ __forceinline__ void relay_read_nxt(const RelayNxt &nb, int lane, Agent &nxt) {
+    nxt.px = nb.px[lane]; nxt.py = nb.py[lane]; nxt.heading = nb.heading[lane]; nxt.t_rem = nb.t_rem[lane];
+    nxt.gx = nb.gx[lane]; nxt.gy = nb.gy[lane]; nxt.radius = nb.radius[lane]; nxt.pref = nb.pref[lane];
+    nxt.flags = nb.flags[lane];
+    nxt.vx = nxt.vy = 0.0;
+    nxt.speed = 0.0f;
+}
+
+template <int N>
+__global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sp = smem;
+    double *lds_tab = reinterpret_cast<double *>(sp); sp += lds_floats_block() * sizeof(float);
+    RelaySeq *seq = reinterpret_cast<RelaySeq *>(sp); sp += sizeof(RelaySeq);
+    unsigned long long *evq = reinterpret_cast<unsigned long long *>(sp); sp += kRelayEvq * sizeof(unsigned long long);
+    RelayTent *tent = reinterpret_cast<RelayTent *>(sp); sp += sizeof(RelayTent);
+    RelayNxt *nbuf = reinterpret_cast<RelayNxt *>(sp); sp += sizeof(RelayNxt);
+    RelayFin *ring = reinterpret_cast<RelayFin *>(sp); sp += kRelayRing * sizeof(RelayFin);
+    RelayKeys<N> *kring = reinterpret_cast<RelayKeys<N> *>(sp); sp += kRelayRing * sizeof(RelayKeys<N>);
+    RelayRes *res = reinterpret_cast<RelayRes *>(sp); sp += sizeof(RelayRes);
+    unsigned char *actring = sp; sp += kRelayActRing * 64;
+    float *tiles = reinterpret_cast<float *>(sp);
+
+    const int role = threadIdx.x >> 6;                     // 0 D, 1 P, 2 .. 1+NC consumers, 2+NC L (consecutive wavefronts land on different SIMDs)
+    const int NC = (blockDim.x >> 6) - 3;
+    const int lane0 = threadIdx.x & 63;
+    const int ostride = io.obs_stride;
+    const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
+    const int wpw = c.wpw, lanes_used = wpw * N;
+    const int64_t wave = blockIdx.x;                       // one tile per workgroup
+    const int64_t w0 = wave * wpw;
+    const int lw = lane0 / N, i0 = lane0 - lw * N;
+    const int64_t w = w0 + lw;
+    const bool active = lane0 < lanes_used && w < c.num_worlds;
+    const int base0 = lane0 < lanes_used ? lw * N : 0;
+    const int64_t a_idx0 = w * N + i0;
+    const bool packed = io.packed != 0;
+    int64_t worlds_here = c.num_worlds - w0;
+    if (worlds_here > wpw) worlds_here = wpw;
+    if (worlds_here < 0) worlds_here = 0;
+    const int n_steps = io.n_steps;
+
+    if (role == 0 && lane0 < (int)(sizeof(RelaySeq) / sizeof(int))) reinterpret_cast<int *>(seq)[lane0] = 0;
+
+    if (role == 0) {
+        // ================================================ D: state owner =====================================================
+        __builtin_amdgcn_s_setprio(3);
+        KCfg cd = c;                                        // this role's constants, pinned in scalar registers (see P)
+        asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.max_turn_rate), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
+                     "+s"(cd.timeout_enabled));
+        Agent a;
+        a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
+        a.gx = a.gy = a.radius = a.pref = a.speed = 0.0f;
+        a.flags = 0u;
+        uint32_t episode = 0u;
+        double tab_v = 0.0;
+        if (lane0 < 2 * c.num_actions) tab_v = c.action_table[lane0];
+        if (active) {
+            episode = s.episode[w];
+            load_agent(s, a_idx0, a);
+        }
+        lds_tab[lane0] = tab_v;
+        const bool present_first = active && (a.flags & CAVOID_F_PRESENT);
+        bool restarted_any = false, moved_any = false;
+        __syncthreads();                                   // table, counters, the loader's first records and actions
+        int events = 0;
+        bool T_moving;
+        Agent T = relay_advance(cd, a, (int)actring[lane0], active, lds_tab, T_moving);   // step 0 is not speculative
+        {
+            const bool present = active && (T.flags & CAVOID_F_PRESENT);
+            tent->px[lane0] = T.px; tent->py[lane0] = T.py; tent->r[lane0] = present ? T.radius : -1.0f;
+            tent->gx[lane0] = T.gx; tent->gy[lane0] = T.gy; tent->flags[lane0] = T.flags;
+            relay_post(&seq->stage, 1);
+        }
+        Agent S = a;
+        for (int t = 0; t < n_steps; ++t) {
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
+            const bool more = t + 1 < n_steps;
+            RELAY_STAMP(0);                                // D: iteration begins (stage t posted)
+            // ---- the successor of step t as if nothing happens at t, while P works on step t --------------------------------
+            Agent Tn = T;
+            bool mn = false;
+            int act1 = 0;
+            if (more) {
+                relay_wait(&seq->act, t + 2);
+                act1 = (int)actring[((t + 1) & (kRelayActRing - 1)) * 64 + lane];
+                Tn = relay_advance(cd, T, act1, active, lds_tab, mn);
+            }
+            // ---- P's verdict on step t -----------------------------------------------------------------------------------
+            RELAY_STAMP(1);                                // D: successor computed
+            relay_spin(&seq->res, t + 1);
+            RELAY_STAMP(2);                                // D: verdict arrived
+            const uint32_t vflags = res->flags[lane], ctl = res->ctl[lane];
+            const float rew_f = res->rew[lane];
+            moved_any = moved_any || T_moving;
+            S = T;
+            S.flags = vflags;
+            const bool restart = (ctl & 2u) != 0u;
+            const unsigned long long rmask = __ballot(restart);
+            if (rmask != 0ull) {                           // some world of the tile starts a new episode
+                relay_wait(&seq->nxt, events);             // every earlier restart's records are re-armed
+                Agent nx;
+                relay_read_nxt(*nbuf, lane, nx);
+                bool mr = false;
+                Agent Tr = nx;
+                if (more) Tr = relay_advance(cd, nx, act1, active, lds_tab, mr);
+                if (restart) { S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr; }
+            }
+            RELAY_STAMP(5);                                // D: verdict read, restart handled
+            // ---- tentative state of step t+1: posted first, it is what P waits for -------------------------------------------
+            if (more) {
+                const bool s_present = active && (S.flags & CAVOID_F_PRESENT);
+                const bool s_done = (S.flags & CAVOID_F_DONE_MASK) != 0u;
+                const bool frozen = s_present && s_done && !restart;   // env_kernel: present_in && done_in
+                uint32_t fflags = S.flags;
+                if (S.flags & CAVOID_F_AT_GOAL) fflags |= CAVOID_F_WAS_AT_GOAL;
+                if (S.flags & CAVOID_F_IN_COLL) fflags |= CAVOID_F_WAS_IN_COLL;
+                T.px = frozen ? S.px : Tn.px; T.py = frozen ? S.py : Tn.py; T.heading = frozen ? S.heading : Tn.heading;
+                T.t_rem = frozen ? S.t_rem : Tn.t_rem;
+                T.vx = frozen ? 0.0 : Tn.vx; T.vy = frozen ? 0.0 : Tn.vy; T.speed = frozen ? 0.0f : Tn.speed;
+                T.gx = Tn.gx; T.gy = Tn.gy; T.radius = Tn.radius; T.pref = Tn.pref;      // (per-episode constants: S's == Tn's)
+                T.flags = frozen ? fflags : Tn.flags;
+                T_moving = frozen ? false : mn;
+                const bool present = active && (T.flags & CAVOID_F_PRESENT);
+                tent->px[lane] = T.px; tent->py[lane] = T.py; tent->r[lane] = present ? T.radius : -1.0f;
+                tent->gx[lane] = T.gx; tent->gy[lane] = T.gy; tent->flags[lane] = T.flags;
+                relay_post(&seq->stage, t + 2);
+            }
+            RELAY_STAMP(3);                                // D: next tentative state posted
+            if (rmask != 0ull) {                           // tell the loader which lanes need their next pool record
+                relay_wait(&seq->nxt, events - (kRelayEvq - 1));
+                if (lane == 0) evq[events & (kRelayEvq - 1)] = rmask;
+                events += 1;
+                relay_post(&seq->ev, events);
+            }
+            // ---- final state of step t -> ring (for the consumers) -------------------------------------------------------
+            if (t >= kRelayRing) relay_wait(&seq->cons[(t - kRelayRing) % NC], t - kRelayRing + 1);
+            {
+                RelayFin &f = ring[t & (kRelayRing - 1)];
+                const bool present = active && (S.flags & CAVOID_F_PRESENT);
+                f.px[lane] = S.px; f.py[lane] = S.py; f.vx[lane] = S.vx; f.vy[lane] = S.vy; f.heading[lane] = S.heading;
+                f.r[lane] = present ? S.radius : -1.0f;
+                f.gx[lane] = S.gx; f.gy[lane] = S.gy; f.pref[lane] = S.pref; f.rew[lane] = rew_f; f.done[lane] = (ctl & 1u) ? 1.0f : 0.0f;
+                f.flags[lane] = S.flags; f.ctl[lane] = ctl;
+                relay_post(&seq->fin, t + 1);
+            }
+            RELAY_STAMP(4);                                // D: final state posted
+        }
+        // ---- state write-back (once per launch) ------------------------------------------------------------------------------
+        if (restarted_any) {
+            store_agent(s, a_idx0, S);
+            if (i0 == 0) s.episode[w] = episode;
+        } else if (present_first) {
+            if (moved_any) {
+                s.px[a_idx0] = S.px; s.py[a_idx0] = S.py; s.heading[a_idx0] = S.heading; s.t_rem[a_idx0] = S.t_rem;
+            }
+            s.speed[a_idx0] = S.speed;
+            s.flags[a_idx0] = S.flags;
+        }
+    } else if (role == 1) {
+        // ================================================ P: pair pass, rewards, done ==========================================
+        __builtin_amdgcn_s_setprio(3);
+        // the constants of this role, pinned in scalar registers for the whole loop (left to itself the compiler re-loads
+        // them from the kernel-argument segment inside the reward branches: seven scalar loads + waits on the loop-carried chain)
+        KCfg cp = c;
+        asm volatile("" : "+s"(cp.r_step), "+s"(cp.r_goal), "+s"(cp.r_coll), "+s"(cp.r_close), "+s"(cp.close_slope), "+s"(cp.close_range),
+                     "+s"(cp.clip_lo), "+s"(cp.clip_hi), "+s"(cp.collision_dist), "+s"(cp.horizon), "+s"(cp.evaluate_mode));
+        __syncthreads();
+        for (int t = 0; t < n_steps; ++t) {
+            int lane = lane0, i = i0, base = base0;
+            int64_t a_idx = a_idx0;
+            asm volatile("" : "+v"(lane), "+v"(i), "+v"(base), "+v"(a_idx));
+            RELAY_STAMP(8);                                // P: waiting for stage t
+            relay_spin(&seq->stage, t + 1);
+            RELAY_STAMP(9);                                // P: stage t arrived
+            Agent a;
+            a.px = tent->px[lane]; a.py = tent->py[lane];
+            a.radius = tent->r[lane];
+            uint32_t flags = tent->flags[lane];
+            const bool present = active && (flags & CAVOID_F_PRESENT);
+            Ego e;
+            e.tx = (double)tent->gx[lane] - a.px; e.ty = (double)tent->gy[lane] - a.py;
+            Key key[Others<N>::K];
+            float gapf[Others<N>::K];
+            uint32_t valid;
+            bool hit;
+            double min_gap;
+            RELAY_STAMP(12);                               // P: own state read
+            pair_pass<N>(cp, a, e, present, i, base, tent->px, tent->py, tent->r, key, gapf, valid, hit, min_gap);
+            RELAY_STAMP(13);                               // P: pair pass done
+            double r = 0.0;
+            bool done = true;
+            if (present) {
+                r = cp.r_step;
+                if (flags & CAVOID_F_AT_GOAL) { if (!(flags & CAVOID_F_WAS_AT_GOAL)) r = cp.r_goal; }
+                else if (!(flags & CAVOID_F_WAS_IN_COLL)) {
+                    if (hit) { r = cp.r_coll; flags |= CAVOID_F_IN_COLL; }
+                    else if (min_gap <= cp.close_range) r = cp.r_close + cp.close_slope * min_gap;
+                }
+                r = fmin(fmax(r, cp.clip_lo), cp.clip_hi);
+                done = (flags & CAVOID_F_DONE_MASK) != 0u;
+            }
+            const unsigned long long running = __ballot(present && ((flags & CAVOID_F_LEARNING) || cp.evaluate_mode) && !done);
+            const unsigned long long wmask = ((1ull << N) - 1ull) << base;
+            const bool game_over = (running & wmask) == 0ull;
+            const float rew_f = (float)r;
+            res->flags[lane] = flags;
+            res->ctl[lane] = (done ? 1u : 0u) | ((active && game_over) ? 2u : 0u);
+            res->rew[lane] = rew_f;
+            relay_post(&seq->res, t + 1);
+            RELAY_STAMP(10);                               // P: verdict posted
+            // ---- off the loop-carried chain: the sort keys and gaps of this pass, the plain outputs -------------------------
+            if (t >= kRelayRing) relay_wait(&seq->cons[(t - kRelayRing) % NC], t - kRelayRing + 1);
+            {
+                RelayKeys<N> &kr = kring[t & (kRelayRing - 1)];
+#pragma unroll
+                for (int o = 0; o < N - 1; ++o) { kr.key_hi[o][lane] = key[o].hi; kr.key_lo[o][lane] = key[o].lo; kr.gap[o][lane] = gapf[o]; }
+                kr.valid[lane] = valid;
+                relay_post(&seq->keys, t + 1);
+            }
+            if (active) {
+                if (!packed) {
+                    io.rew[a_idx] = rew_f;
+                    io.done[a_idx] = done ? 1 : 0;
+                }
+                if (i == 0) io.game_over[w] = game_over ? 1 : 0;
+            }
+            RELAY_STAMP(11);                               // P: keys posted
+        }
+    } else if (role == 2 + NC) {
+        // ================================================ L: actions and pool records ==========================================
+        __builtin_amdgcn_s_setprio(1);
+        uint32_t ep = 0u;
+        {
+            Agent r0;
+            absent_agent(r0);
+            if (active) {
+                ep = s.episode[w];
+                load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), ep + 1u) * N + i0, r0);
+            }
+            RelayNxt &nb = *nbuf;
+            nb.px[lane0] = r0.px; nb.py[lane0] = r0.py; nb.heading[lane0] = r0.heading; nb.t_rem[lane0] = r0.t_rem;
+            nb.gx[lane0] = r0.gx; nb.gy[lane0] = r0.gy; nb.radius[lane0] = r0.radius; nb.pref[lane0] = r0.pref;
+            nb.flags[lane0] = r0.flags;
+        }
+        int loaded = 0;
+        auto load_actions = [&](int upto) {                 // steps [loaded, upto) -> ring, clamped like E4 does
+            for (int sidx = loaded; sidx < upto; ++sidx) {
+                int v = active ? io.actions[(int64_t)sidx * io.action_stride + a_idx0] : 0;
+                v = v < 0 ? 0 : (v >= c.num_actions ? c.num_actions - 1 : v);
+                actring[(sidx & (kRelayActRing - 1)) * 64 + lane0] = (unsigned char)v;
+            }
+            loaded = upto;
+        };
+        load_actions(n_steps < kRelayActAhead ? n_steps : kRelayActAhead);
+        __syncthreads();
+        relay_post(&seq->act, loaded);
+        int served = 0;
+        while (true) {
+            const int ev = relay_peek(&seq->ev), fin = relay_peek(&seq->fin);
+            if (served < ev) {
+                asm volatile("" ::: "memory");
+                const unsigned long long mask = evq[served & (kRelayEvq - 1)];
+                if ((mask >> lane0) & 1ull) {
+                    ep += 1u;
+                    Agent r0;
+                    load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), ep + 1u) * N + i0, r0);
+                    RelayNxt &nb = *nbuf;
+                    nb.px[lane0] = r0.px; nb.py[lane0] = r0.py; nb.heading[lane0] = r0.heading; nb.t_rem[lane0] = r0.t_rem;
+                    nb.gx[lane0] = r0.gx; nb.gy[lane0] = r0.gy; nb.radius[lane0] = r0.radius; nb.pref[lane0] = r0.pref;
+                    nb.flags[lane0] = r0.flags;
+                }
+                served += 1;
+                relay_post(&seq->nxt, served);
+                continue;
+            }
+            if (loaded < n_steps && loaded < fin + kRelayActAhead) {
+                int upto = fin + kRelayActAhead;
+                if (upto > loaded + 8) upto = loaded + 8;
+                if (upto > n_steps) upto = n_steps;
+                load_actions(upto);
+                relay_post(&seq->act, loaded);
+                continue;
+            }
+            if (fin >= n_steps) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    } else {
+        // ================================================ C: observation of every NC-th step ===================================
+        __builtin_amdgcn_s_setprio(0);
+        const int cid = role - 2;
+        float *tile = tiles + (size_t)cid * tile_floats;
+        __syncthreads();
+        for (int t = cid; t < n_steps; t += NC) {
+            int lane = lane0, i = i0, base = base0;
+            asm volatile("" : "+v"(lane), "+v"(i), "+v"(base));
+            RELAY_STAMP(16);                               // C: waiting for final state t
+            relay_wait(&seq->fin, t + 1);
+            relay_wait(&seq->keys, t + 1);
+            RELAY_STAMP(17);                               // C: arrived
+            const RelayFin &f = ring[t & (kRelayRing - 1)];
+            const RelayKeys<N> &kr = kring[t & (kRelayRing - 1)];
+            Agent ao;
+            ao.px = f.px[lane]; ao.py = f.py[lane]; ao.vx = f.vx[lane]; ao.vy = f.vy[lane];
+            ao.heading = f.heading[lane]; ao.t_rem = 0.0;
+            ao.gx = f.gx[lane]; ao.gy = f.gy[lane]; ao.speed = 0.0f;
+            ao.radius = f.r[lane]; ao.pref = f.pref[lane]; ao.flags = f.flags[lane];
+            const bool present = active && (ao.flags & CAVOID_F_PRESENT);
+            const Ego e = ego_frame_obs(ao);
+            Key key[Others<N>::K];
+            float gapf[Others<N>::K];
+            uint32_t valid;
+            key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f;
+            if (__ballot((f.ctl[lane] & 2u) != 0u) != 0ull) {   // a world of the tile restarted: P's keys are of the world that ended
+                bool hit;
+                double min_gap;
+                pair_pass<N>(c, ao, e, present, i, base, f.px, f.py, f.r, key, gapf, valid, hit, min_gap);
+            } else {
+#pragma unroll
+                for (int o = 0; o < N - 1; ++o) { key[o].hi = kr.key_hi[o][lane]; key[o].lo = kr.key_lo[o][lane]; gapf[o] = kr.gap[o][lane]; }
+                valid = kr.valid[lane];
+            }
+            RELAY_STAMP(18);                               // C: ego frame + keys
+            const bool last = t == n_steps - 1;
+            auto order_last = [&]() {                      // the last step's rows go out after every earlier step's have landed
+                if (last)
+                    for (int o = 0; o < NC; ++o)
+                        if (o != cid) relay_wait(&seq->cfin[o], 1);
+            };
+            assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
+                                         io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, f.rew[lane], f.done[lane], wave,
+                                         order_last);
+            relay_post(&seq->cons[cid], t + 1);
+            RELAY_STAMP(19);                               // C: rows flushed
+        }
+        __builtin_amdgcn_s_waitcnt(0);                     // every store of this consumer has completed
+        relay_post(&seq->cfin[cid], 1);
+    }
+}
+
+}  // namespace cavoid
