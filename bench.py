@@ -220,7 +220,10 @@ def step_kernel_name(N: int, W: int, spl: int) -> str:
     if W * N > 131072:
         return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET_N, false>" % N
     tiles = -(-W // (64 // N))
-    if tiles <= 1024 and os.environ.get("CAVOID_PIPELINE", "1") != "0":
+    pipe = os.environ.get("CAVOID_PIPELINE", "2")
+    if tiles <= 512 and N <= 5 and pipe not in ("0", "1"):
+        return "cavoid::env_relay_kernel<%d> (roles on the wavefronts of one workgroup per tile)" % N
+    if tiles <= 1024 and pipe != "0":
         return "cavoid::env_pipe_kernel<%d, false> (two-wavefront pipeline per tile)" % N
     return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET_PF, false>" % N
 
@@ -294,7 +297,7 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
                     for row in csv.DictReader(f):
                         # the stepping instantiations: env_kernel<N, MODE in {1 single step, 4 / 5 step loop}, RVO>
                         hit = re.search(r"env_kernel<%d, (\d+)" % N, row["Kernel_Name"])
-                        step = (hit and hit.group(1) in ("1", "4", "5")) or ("env_pipe_kernel<%d," % N) in row["Kernel_Name"]
+                        step = (hit and hit.group(1) in ("1", "4", "5")) or ("env_pipe_kernel<%d," % N) in row["Kernel_Name"] or ("env_relay_kernel<%d>" % N) in row["Kernel_Name"]
                         if step and row["Counter_Name"] == ctr:
                             total += float(row["Counter_Value"])
                             n += 1

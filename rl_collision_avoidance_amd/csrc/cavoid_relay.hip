@@ -21,7 +21,8 @@ int cavoid_launch_relay(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t 
         int nc = e->relay_consumers;                                                                                    \
         while (nc > 1 && relay_lds_fixed_bytes<NN>() + (size_t)nc * tile_floats * sizeof(float) > 65536) --nc;         \
         const size_t lds = relay_lds_fixed_bytes<NN>() + (size_t)nc * tile_floats * sizeof(float);                      \
-        if (lds > 65536) return CAVOID_EUNSUPPORTED;                                                                    \
+        /* one observation wavefront cannot keep up with the loop: the two-wavefront pipeline is the better form then */  \
+        if (lds > 65536 || (nc < 2 && e->relay_consumers >= 2)) return CAVOID_EUNSUPPORTED;                             \
         const dim3 block(64 * (3 + nc));                                                                                \
         if (ev_start || ev_stop)                                                                                        \
             hipExtLaunchKernelGGL((env_relay_kernel<NN>), grid, block, lds, s, ev_start, ev_stop, 0, k, e->st, e->pool, io);  \

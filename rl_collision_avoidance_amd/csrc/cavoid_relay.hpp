@@ -12,11 +12,12 @@
 //   D  (state owner)   holds the tile's state in registers for the whole launch.  While P works on step t it computes the
 //                      successor T_c = advance(T(t), action(t+1)) as if nothing happened at t.  When P's verdict arrives it
 //                      only SELECTS: agent done (incl. a collision found at t) -> frozen copy; else T_c -- and posts the next
-//                      tentative state BEFORE it writes step t's final state for the consumers.  A restart (a wave-uniform
-//                      branch, about every third step of a 16-world tile) advances the next pool record on the spot.
+//                      tentative state.  A restart (a wave-uniform branch, about every third step of a 16-world tile) advances
+//                      the next pool record on the spot.
 //   P  (pair pass)     distances, collision test, nearest gap, reward, done, game_over of step t from the staged tentative
-//                      state; verdict back to D -- D-commit + P is the loop-carried chain -- and only then the sort keys and
-//                      gaps of the same pass for the consumers.
+//                      state; verdict back to D -- D-commit + P is the loop-carried chain -- and only then, while D selects, the
+//                      final state of step t (the tentative state + the verdict, or the new pool record after a restart) and
+//                      the sort keys and gaps of the same pass for the consumers.
 //   C0..C{NC-1}        observation of step t (ego frame, ranking, rows, coalesced flush) from the FINAL state of step t,
 //                      steps dealt round-robin: each consumer has NC step times per step.  After a restart in the tile the
 //                      consumer redoes the pair pass on the new positions (P's keys are of the world that ended).
@@ -40,17 +41,18 @@ constexpr int kRelayEvq = 8;             // restart-event queue D -> L
 struct RelaySeq {                        // sequence counters (each written by exactly one wavefront)
     int stage;                           // D: tentative state of steps < stage is in `tent`
     int res;                             // P: verdicts of steps < res are in `res`
-    int fin;                             // D: final state of steps < fin is in the ring
-    int keys;                            // P: sort keys / gaps of steps < keys are in the key ring
+    int fin;                             // P: final state, sort keys and gaps of steps < fin are in the rings
     int act;                             // L: actions of steps < act are in the ring
-    int ev;                              // D: restart events posted
+    int ev;                              // P: restart events posted (it has read the old records of the restarted lanes)
+    int dack;                            // D: restart events taken (it has read the old records too)
     int nxt;                             // L: restart events served (pool records of the restarted lanes re-armed)
     int cons[kRelayMaxConsumers];        // C: steps < cons[c] of consumer c's share are flushed (ring slots free)
     int cfin[kRelayMaxConsumers];        // C: all of the consumer's stores have completed
     int pad[1];
 };
-struct RelayTent { double px[64], py[64]; float r[64], gx[64], gy[64]; uint32_t flags[64]; };
-struct RelayRes { uint32_t flags[64], ctl[64]; float rew[64]; };             // ctl: bit 0 done, bit 1 the lane's world restarts
+static_assert(sizeof(RelaySeq) % 8 == 0, "the event queue behind it holds 64-bit masks");
+struct RelayTent { double px[64], py[64], vx[64], vy[64], heading[64]; float r[64], gx[64], gy[64], pref[64]; uint32_t flags[64]; };
+struct RelayRes { uint32_t flags[64], ctl[64]; };                            // ctl: bit 0 done, bit 1 the lane's world restarts
 struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], gy[64], radius[64], pref[64]; uint32_t flags[64]; };
 struct RelayFin {
     double px[64], py[64], vx[64], vy[64], heading[64];
@@ -215,8 +217,9 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         Agent T = relay_advance(cd, a, (int)actring[lane0], active, lds_tab, T_moving);   // step 0 is not speculative
         {
             const bool present = active && (T.flags & CAVOID_F_PRESENT);
-            tent->px[lane0] = T.px; tent->py[lane0] = T.py; tent->r[lane0] = present ? T.radius : -1.0f;
-            tent->gx[lane0] = T.gx; tent->gy[lane0] = T.gy; tent->flags[lane0] = T.flags;
+            tent->px[lane0] = T.px; tent->py[lane0] = T.py; tent->vx[lane0] = T.vx; tent->vy[lane0] = T.vy; tent->heading[lane0] = T.heading;
+            tent->r[lane0] = present ? T.radius : -1.0f;
+            tent->gx[lane0] = T.gx; tent->gy[lane0] = T.gy; tent->pref[lane0] = T.pref; tent->flags[lane0] = T.flags;
             relay_post(&seq->stage, 1);
         }
         Agent S = a;
@@ -239,7 +242,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             relay_spin(&seq->res, t + 1);
             RELAY_STAMP(2);                                // D: verdict arrived
             const uint32_t vflags = res->flags[lane], ctl = res->ctl[lane];
-            const float rew_f = res->rew[lane];
             moved_any = moved_any || T_moving;
             S = T;
             S.flags = vflags;
@@ -253,6 +255,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 Agent Tr = nx;
                 if (more) Tr = relay_advance(cd, nx, act1, active, lds_tab, mr);
                 if (restart) { S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr; }
+                events += 1;
+                relay_post(&seq->dack, events);            // the loader may re-arm these lanes (once P has read them too)
             }
             RELAY_STAMP(5);                                // D: verdict read, restart handled
             // ---- tentative state of step t+1: posted first, it is what P waits for -------------------------------------------
@@ -270,30 +274,14 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 T.flags = frozen ? fflags : Tn.flags;
                 T_moving = frozen ? false : mn;
                 const bool present = active && (T.flags & CAVOID_F_PRESENT);
-                tent->px[lane] = T.px; tent->py[lane] = T.py; tent->r[lane] = present ? T.radius : -1.0f;
-                tent->gx[lane] = T.gx; tent->gy[lane] = T.gy; tent->flags[lane] = T.flags;
+                tent->px[lane] = T.px; tent->py[lane] = T.py; tent->vx[lane] = T.vx; tent->vy[lane] = T.vy; tent->heading[lane] = T.heading;
+                tent->r[lane] = present ? T.radius : -1.0f;
+                tent->gx[lane] = T.gx; tent->gy[lane] = T.gy; tent->pref[lane] = T.pref; tent->flags[lane] = T.flags;
                 relay_post(&seq->stage, t + 2);
             }
             RELAY_STAMP(3);                                // D: next tentative state posted
-            if (rmask != 0ull) {                           // tell the loader which lanes need their next pool record
-                relay_wait(&seq->nxt, events - (kRelayEvq - 1));
-                if (lane == 0) evq[events & (kRelayEvq - 1)] = rmask;
-                events += 1;
-                relay_post(&seq->ev, events);
-            }
-            // ---- final state of step t -> ring (for the consumers) -------------------------------------------------------
-            if (t >= kRelayRing) relay_wait(&seq->cons[(t - kRelayRing) % NC], t - kRelayRing + 1);
-            {
-                RelayFin &f = ring[t & (kRelayRing - 1)];
-                const bool present = active && (S.flags & CAVOID_F_PRESENT);
-                f.px[lane] = S.px; f.py[lane] = S.py; f.vx[lane] = S.vx; f.vy[lane] = S.vy; f.heading[lane] = S.heading;
-                f.r[lane] = present ? S.radius : -1.0f;
-                f.gx[lane] = S.gx; f.gy[lane] = S.gy; f.pref[lane] = S.pref; f.rew[lane] = rew_f; f.done[lane] = (ctl & 1u) ? 1.0f : 0.0f;
-                f.flags[lane] = S.flags; f.ctl[lane] = ctl;
-                relay_post(&seq->fin, t + 1);
-            }
-            RELAY_STAMP(4);                                // D: final state posted
         }
+        relay_post(&seq->stage, n_steps + 1);               // (the loader may leave: no restart is waiting for a record any more)
         // ---- state write-back (once per launch) ------------------------------------------------------------------------------
         if (restarted_any) {
             store_agent(s, a_idx0, S);
@@ -313,6 +301,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         KCfg cp = c;
         asm volatile("" : "+s"(cp.r_step), "+s"(cp.r_goal), "+s"(cp.r_coll), "+s"(cp.r_close), "+s"(cp.close_slope), "+s"(cp.close_range),
                      "+s"(cp.clip_lo), "+s"(cp.clip_hi), "+s"(cp.collision_dist), "+s"(cp.horizon), "+s"(cp.evaluate_mode));
+        int pevents = 0;
         __syncthreads();
         for (int t = 0; t < n_steps; ++t) {
             int lane = lane0, i = i0, base = base0;
@@ -325,9 +314,12 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             a.px = tent->px[lane]; a.py = tent->py[lane];
             a.radius = tent->r[lane];
             uint32_t flags = tent->flags[lane];
+            // (not needed for the verdict: the rest of the final state, read before D may overwrite `tent` with step t+1)
+            a.vx = tent->vx[lane]; a.vy = tent->vy[lane]; a.heading = tent->heading[lane];
+            a.gx = tent->gx[lane]; a.gy = tent->gy[lane]; a.pref = tent->pref[lane];
             const bool present = active && (flags & CAVOID_F_PRESENT);
             Ego e;
-            e.tx = (double)tent->gx[lane] - a.px; e.ty = (double)tent->gy[lane] - a.py;
+            e.tx = (double)a.gx - a.px; e.ty = (double)a.gy - a.py;
             Key key[Others<N>::K];
             float gapf[Others<N>::K];
             uint32_t valid;
@@ -354,17 +346,38 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const float rew_f = (float)r;
             res->flags[lane] = flags;
             res->ctl[lane] = (done ? 1u : 0u) | ((active && game_over) ? 2u : 0u);
-            res->rew[lane] = rew_f;
             relay_post(&seq->res, t + 1);
             RELAY_STAMP(10);                               // P: verdict posted
-            // ---- off the loop-carried chain: the sort keys and gaps of this pass, the plain outputs -------------------------
+            // ---- off the loop-carried chain: the final state of step t, the sort keys and gaps of this pass, the plain outputs ---
+            const bool restart = active && game_over;
+            float fr = a.radius;                           // (-1 marks an absent row)
+            const unsigned long long prmask = __ballot(restart);
+            if (prmask != 0ull) {                          // the restarted worlds' final state is their next pool record
+                relay_wait(&seq->nxt, pevents);            // every earlier restart's records are re-armed
+                if (restart) {
+                    Agent nx;
+                    relay_read_nxt(*nbuf, lane, nx);
+                    a.px = nx.px; a.py = nx.py; a.vx = 0.0; a.vy = 0.0; a.heading = nx.heading;
+                    a.gx = nx.gx; a.gy = nx.gy; a.pref = nx.pref; flags = nx.flags;
+                    fr = (nx.flags & CAVOID_F_PRESENT) ? nx.radius : -1.0f;
+                }
+                relay_wait(&seq->nxt, pevents - (kRelayEvq - 1));
+                if (lane == 0) evq[pevents & (kRelayEvq - 1)] = prmask;
+                pevents += 1;
+                relay_post(&seq->ev, pevents);
+            }
             if (t >= kRelayRing) relay_wait(&seq->cons[(t - kRelayRing) % NC], t - kRelayRing + 1);
             {
+                RelayFin &f = ring[t & (kRelayRing - 1)];
+                f.px[lane] = a.px; f.py[lane] = a.py; f.vx[lane] = a.vx; f.vy[lane] = a.vy; f.heading[lane] = a.heading;
+                f.r[lane] = fr;
+                f.gx[lane] = a.gx; f.gy[lane] = a.gy; f.pref[lane] = a.pref; f.rew[lane] = rew_f; f.done[lane] = done ? 1.0f : 0.0f;
+                f.flags[lane] = flags; f.ctl[lane] = (done ? 1u : 0u) | (restart ? 2u : 0u);
                 RelayKeys<N> &kr = kring[t & (kRelayRing - 1)];
 #pragma unroll
                 for (int o = 0; o < N - 1; ++o) { kr.key_hi[o][lane] = key[o].hi; kr.key_lo[o][lane] = key[o].lo; kr.gap[o][lane] = gapf[o]; }
                 kr.valid[lane] = valid;
-                relay_post(&seq->keys, t + 1);
+                relay_post(&seq->fin, t + 1);
             }
             if (active) {
                 if (!packed) {
@@ -406,7 +419,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         int served = 0;
         while (true) {
             const int ev = relay_peek(&seq->ev), fin = relay_peek(&seq->fin);
-            if (served < ev) {
+            if (served < ev && served < relay_peek(&seq->dack)) {
                 asm volatile("" ::: "memory");
                 const unsigned long long mask = evq[served & (kRelayEvq - 1)];
                 if ((mask >> lane0) & 1ull) {
@@ -430,7 +443,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 relay_post(&seq->act, loaded);
                 continue;
             }
-            if (fin >= n_steps) break;
+            if (fin >= n_steps && relay_peek(&seq->stage) > n_steps) break;
             __builtin_amdgcn_s_sleep(2);
         }
     } else {
@@ -444,7 +457,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             asm volatile("" : "+v"(lane), "+v"(i), "+v"(base));
             RELAY_STAMP(16);                               // C: waiting for final state t
             relay_wait(&seq->fin, t + 1);
-            relay_wait(&seq->keys, t + 1);
             RELAY_STAMP(17);                               // C: arrived
             const RelayFin &f = ring[t & (kRelayRing - 1)];
             const RelayKeys<N> &kr = kring[t & (kRelayRing - 1)];

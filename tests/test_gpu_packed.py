@@ -3,8 +3,9 @@
 * packed outputs -- the kernel writes one (obs | reward | done) record per agent -- must equal, bit for bit, the plain
   outputs packed by `sharding.pack_step_outputs` (the three-launch torch pack it replaces);
 * multi-step launches (`cavoid_step_autoreset_n`: the world state stays in registers between steps) must equal the same
-  steps launched one by one, in both instantiations (register prefetch of the next pool record / on-demand gather) and
-  for every wavefront geometry (worlds per wavefront);
+  steps launched one by one, in every form of the loop (env_relay_kernel: the step cut into roles on several wavefronts per
+  tile; env_pipe_kernel: two wavefronts per tile; one wavefront per tile with register prefetch of the next pool record /
+  on-demand gather) and for every wavefront geometry (worlds per wavefront);
 * BASELINE configs[2] at full size on ONE GPU: 8 shard envs of 8192 worlds with world_offset = r*8192 against one
   65 536-world env, 50 auto-reset steps, concatenated packed buffers bitwise equal -- the workload and the gather layout
   of the 8-GPU run;
@@ -72,24 +73,33 @@ def test_packed_outputs_equal_plain_outputs(N, M, W, nonl, gen_min):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("N,W,pool,wpw", [
-    (4, 300, 65536, None),     # latency mode: next pool record in registers
-    (4, 300, 0, None),         # in-kernel generator
-    (4, 5000, 500, 16),        # full wavefronts
-    (4, 5000, 500, 1),         # one world per wavefront
-    (10, 257, 300, None),
-    (10, 257, 0, 3),
-    (3, 1000, 7, 5),
-    (16, 130, 64, None),
+@pytest.mark.parametrize("N,W,pool,wpw,pipe", [
+    (4, 300, 65536, None, None),   # latency mode, default form: env_relay_kernel (roles on wavefronts of one workgroup per tile)
+    (4, 300, 65536, None, "1"),    # ... env_pipe_kernel (two wavefronts per tile)
+    (4, 300, 65536, None, "0"),    # ... one wavefront per tile, next pool record in registers
+    (4, 300, 0, None, None),       # in-kernel generator
+    (4, 5000, 500, 16, None),      # full wavefronts
+    (4, 5000, 500, 16, "1"),
+    (4, 5000, 500, 1, None),       # one world per wavefront
+    (10, 257, 300, None, None),
+    (10, 257, 0, 3, None),
+    (3, 1000, 7, 5, None),
+    (3, 1000, 7, 5, "1"),
+    (2, 777, 64, None, None),
+    (5, 333, 100, None, None),
+    (16, 130, 64, None, None),
 ])
-def test_multi_step_launch_equals_single_steps(N, W, pool, wpw, monkeypatch):
+def test_multi_step_launch_equals_single_steps(N, W, pool, wpw, pipe, monkeypatch):
     if wpw is not None:
         monkeypatch.setenv("CAVOID_WPW", str(wpw))
+    if pipe is not None:
+        monkeypatch.setenv("CAVOID_PIPELINE", pipe)
     T = 48
     kw = dict(gen_pool_size=pool, gen_min_agents=max(1, N // 2), gen_nonlearning_fraction=0.2)
     acts = _acts(T, W, N, 5)
     a = _env(W, N, seed=9, **kw)
     monkeypatch.delenv("CAVOID_WPW", raising=False)
+    monkeypatch.delenv("CAVOID_PIPELINE", raising=False)
     b = _env(W, N, seed=9, **kw)                            # default geometry, single steps
     a.reset(); b.reset()
     for lo, n in ((0, 1), (1, 7), (8, 24), (32, 16)):       # chunks of different lengths, incl. n = 1
