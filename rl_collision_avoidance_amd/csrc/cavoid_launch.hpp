@@ -25,7 +25,7 @@ struct cavoid_env {
     int grid = 0;
     int pipeline = 2;            // latency mode, multi-step launches: 2 = env_relay_kernel (roles on 5-7 wavefronts per tile), 1 = env_pipe_kernel
                                  // (two wavefronts per tile), 0 = one wavefront per tile (CAVOID_PIPELINE)
-    int relay_consumers = 2;     // observation wavefronts per tile of env_relay_kernel (CAVOID_RELAY_CONSUMERS, 1..4)
+    int relay_consumers = 3;     // observation wavefronts per tile of env_relay_kernel (CAVOID_RELAY_CONSUMERS, 1..4)
     int latency_mode = 0;        // small batch: multi-step launches keep the next pool record in registers (MODE_STEP_AUTORESET_PF)
     int prefetch_single = 0;     // ... and single-step launches too (CAVOID_PREFETCH_POOL=1; costs 64 B of reads per agent-step)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

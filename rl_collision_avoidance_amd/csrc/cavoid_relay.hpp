@@ -10,17 +10,16 @@
 // of step t unless an agent collided or the world restarted at t.  So:
 //
 //   D  (state owner)   holds the tile's state in registers for the whole launch.  While P works on step t it computes the
-//                      successor T_c = advance(T(t), action(t+1)) as if nothing happened at t.  When P's verdict arrives it
-//                      only SELECTS: agent done (incl. a collision found at t) -> frozen copy; else T_c -- and posts the next
-//                      tentative state.  A restart (a wave-uniform branch, about every third step of a 16-world tile) advances
-//                      the next pool record on the spot.
-//   P  (pair pass)     distances, collision test, nearest gap, reward, done, game_over of step t from the staged tentative
-//                      state; verdict back to D -- D-commit + P is the loop-carried chain -- and only then, while D selects, the
-//                      final state of step t (the tentative state + the verdict, or the new pool record after a restart) and
-//                      the sort keys and gaps of the same pass for the consumers.
-//   C0..C{NC-1}        observation of step t (ego frame, ranking, rows, coalesced flush) from the FINAL state of step t,
-//                      steps dealt round-robin: each consumer has NC step times per step.  After a restart in the tile the
-//                      consumer redoes the pair pass on the new positions (P's keys are of the world that ended).
+//                      successor T_c = advance(T(t), action(t+1)) as if nothing happened at t and POSTS it; then it writes the
+//                      final state of step t-1 for the consumers; then it waits for P's verdict on step t.  Only a surprise
+//                      -- a collision found at t, or a world restarting (a wave-uniform test) -- makes it select (collided
+//                      agent -> frozen copy, restarted world -> the next pool record advanced on the spot) and re-post.
+//   P  (pair pass)     distances, collision test, nearest gap, reward, done, game_over of step t from the posted tentative
+//                      state; verdict to D; plain outputs.  It makes the same surprise test on its own verdict: no surprise ->
+//                      it goes straight on with the successor D posted long ago, and the loop-carried chain is this wavefront
+//                      alone; surprise -> it waits for D's corrected state.
+//   C0..C{NC-1}        observation of step t (ego frame, distances and sort keys, ranking, rows, coalesced flush) from the
+//                      FINAL state of step t, steps dealt round-robin: each consumer has NC step times per step.
 //   L  (loader)        everything that touches memory inside the loop and is not an output: the action block (a 64-step
 //                      byte ring in LDS, filled ahead of D) and the next scenario-pool record of every restarted lane.
 //
@@ -39,20 +38,20 @@ constexpr int kRelayActAhead = 48;       // the loader runs at most this many st
 constexpr int kRelayEvq = 8;             // restart-event queue D -> L
 
 struct RelaySeq {                        // sequence counters (each written by exactly one wavefront)
-    int stage;                           // D: tentative state of steps < stage is in `tent`
+    int spec;                            // D: the SPECULATIVE tentative state of steps < spec is in `tent` (nothing happened at the step before)
+    int stage;                           // D: ... and corrected for the verdict of the step before (collisions, restarts)
     int res;                             // P: verdicts of steps < res are in `res`
-    int fin;                             // P: final state, sort keys and gaps of steps < fin are in the rings
+    int fin;                             // D: the final state of steps < fin is in the ring
     int act;                             // L: actions of steps < act are in the ring
-    int ev;                              // P: restart events posted (it has read the old records of the restarted lanes)
-    int dack;                            // D: restart events taken (it has read the old records too)
+    int ev;                              // D: restart events posted (it has read the old records of the restarted lanes)
     int nxt;                             // L: restart events served (pool records of the restarted lanes re-armed)
     int cons[kRelayMaxConsumers];        // C: steps < cons[c] of consumer c's share are flushed (ring slots free)
     int cfin[kRelayMaxConsumers];        // C: all of the consumer's stores have completed
     int pad[1];
 };
 static_assert(sizeof(RelaySeq) % 8 == 0, "the event queue behind it holds 64-bit masks");
-struct RelayTent { double px[64], py[64], vx[64], vy[64], heading[64]; float r[64], gx[64], gy[64], pref[64]; uint32_t flags[64]; };
-struct RelayRes { uint32_t flags[64], ctl[64]; };                            // ctl: bit 0 done, bit 1 the lane's world restarts
+struct RelayTent { double px[64], py[64]; float r[64]; uint32_t flags[64]; };      // what the pair pass needs of a tentative state
+struct RelayRes { uint32_t flags[64], ctl[64]; float rew[64]; };                            // ctl: bit 0 done, bit 1 the lane's world restarts
 struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], gy[64], radius[64], pref[64]; uint32_t flags[64]; };
 struct RelayFin {
     double px[64], py[64], vx[64], vy[64], heading[64];
@@ -60,17 +59,9 @@ struct RelayFin {
     uint32_t flags[64], ctl[64];
 };
 template <int N>
-struct RelayKeys {
-    static constexpr int K = Others<N>::K;
-    uint32_t key_hi[K][64], key_lo[K][64];
-    float gap[K][64];
-    uint32_t valid[64];
-};
-
-template <int N>
 __host__ __device__ constexpr size_t relay_lds_fixed_bytes() {
-    return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + sizeof(RelayTent) + sizeof(RelayRes) +
-           sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long) + kRelayRing * (sizeof(RelayFin) + sizeof(RelayKeys<N>));
+    return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + 2 * sizeof(RelayTent) + 2 * sizeof(RelayRes) +
+           sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long) + kRelayRing * sizeof(RelayFin);
 }
 
 // development build: lane 0 of a role stamps the shader clock of step n_steps/2 into g_trace[tile*32 + k] (tools/trace_relay.py)
@@ -162,11 +153,10 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     double *lds_tab = reinterpret_cast<double *>(sp); sp += lds_floats_block() * sizeof(float);
     RelaySeq *seq = reinterpret_cast<RelaySeq *>(sp); sp += sizeof(RelaySeq);
     unsigned long long *evq = reinterpret_cast<unsigned long long *>(sp); sp += kRelayEvq * sizeof(unsigned long long);
-    RelayTent *tent = reinterpret_cast<RelayTent *>(sp); sp += sizeof(RelayTent);
+    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += 2 * sizeof(RelayTent);
     RelayNxt *nbuf = reinterpret_cast<RelayNxt *>(sp); sp += sizeof(RelayNxt);
     RelayFin *ring = reinterpret_cast<RelayFin *>(sp); sp += kRelayRing * sizeof(RelayFin);
-    RelayKeys<N> *kring = reinterpret_cast<RelayKeys<N> *>(sp); sp += kRelayRing * sizeof(RelayKeys<N>);
-    RelayRes *res = reinterpret_cast<RelayRes *>(sp); sp += sizeof(RelayRes);
+    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += 2 * sizeof(RelayRes);   // (P may be one step ahead of D's reading)
     unsigned char *actring = sp; sp += kRelayActRing * 64;
     float *tiles = reinterpret_cast<float *>(sp);
 
@@ -215,72 +205,100 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         int events = 0;
         bool T_moving;
         Agent T = relay_advance(cd, a, (int)actring[lane0], active, lds_tab, T_moving);   // step 0 is not speculative
-        {
-            const bool present = active && (T.flags & CAVOID_F_PRESENT);
-            tent->px[lane0] = T.px; tent->py[lane0] = T.py; tent->vx[lane0] = T.vx; tent->vy[lane0] = T.vy; tent->heading[lane0] = T.heading;
-            tent->r[lane0] = present ? T.radius : -1.0f;
-            tent->gx[lane0] = T.gx; tent->gy[lane0] = T.gy; tent->pref[lane0] = T.pref; tent->flags[lane0] = T.flags;
-            relay_post(&seq->stage, 1);
-        }
+        auto stage_out = [&](RelayTent &tn, const Agent &x, int lane) {
+            const bool present = active && (x.flags & CAVOID_F_PRESENT);
+            tn.px[lane] = x.px; tn.py[lane] = x.py; tn.r[lane] = present ? x.radius : -1.0f; tn.flags[lane] = x.flags;
+        };
+        stage_out(tents[0], T, lane0);
+        relay_post(&seq->spec, 1);
+        relay_post(&seq->stage, 1);
         Agent S = a;
+        float rew_prev = 0.0f;
+        uint32_t ctl_prev = 0u;
+        auto fin_out = [&](int tt, int lane) {              // the final state of step tt (S, rew_prev, ctl_prev) -> ring
+            if (tt >= kRelayRing) relay_wait(&seq->cons[(tt - kRelayRing) % NC], tt - kRelayRing + 1);
+            RelayFin &f = ring[tt & (kRelayRing - 1)];
+            const bool present = active && (S.flags & CAVOID_F_PRESENT);
+            f.px[lane] = S.px; f.py[lane] = S.py; f.vx[lane] = S.vx; f.vy[lane] = S.vy; f.heading[lane] = S.heading;
+            f.r[lane] = present ? S.radius : -1.0f;
+            f.gx[lane] = S.gx; f.gy[lane] = S.gy; f.pref[lane] = S.pref; f.rew[lane] = rew_prev; f.done[lane] = (ctl_prev & 1u) ? 1.0f : 0.0f;
+            f.flags[lane] = S.flags; f.ctl[lane] = ctl_prev;
+            relay_post(&seq->fin, tt + 1);
+        };
         for (int t = 0; t < n_steps; ++t) {
             int lane = lane0;
             asm volatile("" : "+v"(lane));
             const bool more = t + 1 < n_steps;
             RELAY_STAMP(0);                                // D: iteration begins (stage t posted)
-            // ---- the successor of step t as if nothing happens at t, while P works on step t --------------------------------
+            // ---- the successor of step t as if nothing happens at t, while P works on step t: posted at once, P takes it as it
+            //      is when its own verdict says so (no new collision, no restart in the tile) ---------------------------------
             Agent Tn = T;
             bool mn = false;
             int act1 = 0;
+            RelayTent &tn = tents[(t + 1) & 1];
             if (more) {
                 relay_wait(&seq->act, t + 2);
                 act1 = (int)actring[((t + 1) & (kRelayActRing - 1)) * 64 + lane];
                 Tn = relay_advance(cd, T, act1, active, lds_tab, mn);
+                stage_out(tn, Tn, lane);
+                relay_post(&seq->spec, t + 2);
             }
+            RELAY_STAMP(1);                                // D: successor computed and posted
+            if (t > 0) fin_out(t - 1, lane);               // (off the chain) step t-1 for the consumers
             // ---- P's verdict on step t -----------------------------------------------------------------------------------
-            RELAY_STAMP(1);                                // D: successor computed
+            RELAY_STAMP(4);                                // D: final state of t-1 posted
             relay_spin(&seq->res, t + 1);
             RELAY_STAMP(2);                                // D: verdict arrived
+            const RelayRes *res = &ress[t & 1];
             const uint32_t vflags = res->flags[lane], ctl = res->ctl[lane];
+            rew_prev = res->rew[lane];
+            ctl_prev = ctl;
             moved_any = moved_any || T_moving;
+            const bool new_coll = (vflags & CAVOID_F_IN_COLL) != 0u && (T.flags & CAVOID_F_IN_COLL) == 0u;
             S = T;
             S.flags = vflags;
             const bool restart = (ctl & 2u) != 0u;
             const unsigned long long rmask = __ballot(restart);
-            if (rmask != 0ull) {                           // some world of the tile starts a new episode
-                relay_wait(&seq->nxt, events);             // every earlier restart's records are re-armed
-                Agent nx;
-                relay_read_nxt(*nbuf, lane, nx);
-                bool mr = false;
-                Agent Tr = nx;
-                if (more) Tr = relay_advance(cd, nx, act1, active, lds_tab, mr);
-                if (restart) { S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr; }
-                events += 1;
-                relay_post(&seq->dack, events);            // the loader may re-arm these lanes (once P has read them too)
+            const bool surprise = __ballot(new_coll || restart) != 0ull;       // the same test P makes on its own verdict
+            if (!surprise) {                               // the posted successor stands: an agent that is done was frozen by
+                T = Tn;                                    // relay_advance itself (its flags were known), nobody else changed
+                T_moving = mn;
+            } else {
+                if (rmask != 0ull) {                       // some world of the tile starts a new episode
+                    relay_wait(&seq->nxt, events);         // every earlier restart's records are re-armed
+                    Agent nx;
+                    relay_read_nxt(*nbuf, lane, nx);
+                    bool mr = false;
+                    Agent Tr = nx;
+                    if (more) Tr = relay_advance(cd, nx, act1, active, lds_tab, mr);
+                    if (restart) { S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr; }
+                }
+                if (more) {
+                    const bool s_present = active && (S.flags & CAVOID_F_PRESENT);
+                    const bool s_done = (S.flags & CAVOID_F_DONE_MASK) != 0u;
+                    const bool frozen = s_present && s_done && !restart;   // env_kernel: present_in && done_in
+                    uint32_t fflags = S.flags;
+                    if (S.flags & CAVOID_F_AT_GOAL) fflags |= CAVOID_F_WAS_AT_GOAL;
+                    if (S.flags & CAVOID_F_IN_COLL) fflags |= CAVOID_F_WAS_IN_COLL;
+                    T.px = frozen ? S.px : Tn.px; T.py = frozen ? S.py : Tn.py; T.heading = frozen ? S.heading : Tn.heading;
+                    T.t_rem = frozen ? S.t_rem : Tn.t_rem;
+                    T.vx = frozen ? 0.0 : Tn.vx; T.vy = frozen ? 0.0 : Tn.vy; T.speed = frozen ? 0.0f : Tn.speed;
+                    T.gx = Tn.gx; T.gy = Tn.gy; T.radius = Tn.radius; T.pref = Tn.pref;      // (per-episode constants: S's == Tn's)
+                    T.flags = frozen ? fflags : Tn.flags;
+                    T_moving = frozen ? false : mn;
+                    stage_out(tn, T, lane);                // the posted successor was wrong for some lane
+                    relay_post(&seq->stage, t + 2);
+                }
+                if (rmask != 0ull) {                       // tell the loader which lanes need their next pool record
+                    relay_wait(&seq->nxt, events - (kRelayEvq - 1));
+                    if (lane == 0) evq[events & (kRelayEvq - 1)] = rmask;
+                    events += 1;
+                    relay_post(&seq->ev, events);
+                }
             }
-            RELAY_STAMP(5);                                // D: verdict read, restart handled
-            // ---- tentative state of step t+1: posted first, it is what P waits for -------------------------------------------
-            if (more) {
-                const bool s_present = active && (S.flags & CAVOID_F_PRESENT);
-                const bool s_done = (S.flags & CAVOID_F_DONE_MASK) != 0u;
-                const bool frozen = s_present && s_done && !restart;   // env_kernel: present_in && done_in
-                uint32_t fflags = S.flags;
-                if (S.flags & CAVOID_F_AT_GOAL) fflags |= CAVOID_F_WAS_AT_GOAL;
-                if (S.flags & CAVOID_F_IN_COLL) fflags |= CAVOID_F_WAS_IN_COLL;
-                T.px = frozen ? S.px : Tn.px; T.py = frozen ? S.py : Tn.py; T.heading = frozen ? S.heading : Tn.heading;
-                T.t_rem = frozen ? S.t_rem : Tn.t_rem;
-                T.vx = frozen ? 0.0 : Tn.vx; T.vy = frozen ? 0.0 : Tn.vy; T.speed = frozen ? 0.0f : Tn.speed;
-                T.gx = Tn.gx; T.gy = Tn.gy; T.radius = Tn.radius; T.pref = Tn.pref;      // (per-episode constants: S's == Tn's)
-                T.flags = frozen ? fflags : Tn.flags;
-                T_moving = frozen ? false : mn;
-                const bool present = active && (T.flags & CAVOID_F_PRESENT);
-                tent->px[lane] = T.px; tent->py[lane] = T.py; tent->vx[lane] = T.vx; tent->vy[lane] = T.vy; tent->heading[lane] = T.heading;
-                tent->r[lane] = present ? T.radius : -1.0f;
-                tent->gx[lane] = T.gx; tent->gy[lane] = T.gy; tent->pref[lane] = T.pref; tent->flags[lane] = T.flags;
-                relay_post(&seq->stage, t + 2);
-            }
-            RELAY_STAMP(3);                                // D: next tentative state posted
+            RELAY_STAMP(3);                                // D: next tentative state final
         }
+        fin_out(n_steps - 1, lane0);
         relay_post(&seq->stage, n_steps + 1);               // (the loader may leave: no restart is waiting for a record any more)
         // ---- state write-back (once per launch) ------------------------------------------------------------------------------
         if (restarted_any) {
@@ -301,32 +319,42 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         KCfg cp = c;
         asm volatile("" : "+s"(cp.r_step), "+s"(cp.r_goal), "+s"(cp.r_coll), "+s"(cp.r_close), "+s"(cp.close_slope), "+s"(cp.close_range),
                      "+s"(cp.clip_lo), "+s"(cp.clip_hi), "+s"(cp.collision_dist), "+s"(cp.horizon), "+s"(cp.evaluate_mode));
-        int pevents = 0;
+        bool prev_surprise = false;
         __syncthreads();
         for (int t = 0; t < n_steps; ++t) {
             int lane = lane0, i = i0, base = base0;
             int64_t a_idx = a_idx0;
             asm volatile("" : "+v"(lane), "+v"(i), "+v"(base), "+v"(a_idx));
             RELAY_STAMP(8);                                // P: waiting for stage t
-            relay_spin(&seq->stage, t + 1);
+            // the speculative successor D posted while this wavefront worked on step t-1 is exact unless the verdict of t-1 found
+            // a new collision or restarted a world: only then wait for D's corrected state
+            if (prev_surprise) relay_spin(&seq->stage, t + 1);
+            else relay_spin(&seq->spec, t + 1);
             RELAY_STAMP(9);                                // P: stage t arrived
+            const RelayTent *tent = &tents[t & 1];
             Agent a;
             a.px = tent->px[lane]; a.py = tent->py[lane];
             a.radius = tent->r[lane];
             uint32_t flags = tent->flags[lane];
-            // (not needed for the verdict: the rest of the final state, read before D may overwrite `tent` with step t+1)
-            a.vx = tent->vx[lane]; a.vy = tent->vy[lane]; a.heading = tent->heading[lane];
-            a.gx = tent->gx[lane]; a.gy = tent->gy[lane]; a.pref = tent->pref[lane];
+            const uint32_t flags_t = flags;
             const bool present = active && (flags & CAVOID_F_PRESENT);
-            Ego e;
-            e.tx = (double)a.gx - a.px; e.ty = (double)a.gy - a.py;
-            Key key[Others<N>::K];
-            float gapf[Others<N>::K];
-            uint32_t valid;
-            bool hit;
-            double min_gap;
+            // ---- distances, collision test, nearest gap (pair_pass without the sort keys: the consumers make those) -------------
+            constexpr int K = Others<N>::K;
+            bool hit = false;
+            double min_gap = INFINITY;
+            const double ri = (double)a.radius;
             RELAY_STAMP(12);                               // P: own state read
-            pair_pass<N>(cp, a, e, present, i, base, tent->px, tent->py, tent->r, key, gapf, valid, hit, min_gap);
+#pragma unroll
+            for (int o = 0; o < N - 1; ++o) {
+                const int j = base + other_index(i, o, N);
+                const float rjf = tent->r[j];
+                const double rx = tent->px[j] - a.px, ry = tent->py[j] - a.py;
+                const double d = sqrt(rx * rx + ry * ry);
+                const bool other = present && (rjf >= 0.0f);
+                const double gap_c = d - (ri + (double)rjf);          // pair_pass: the unordered-pair gap
+                min_gap = other ? fmin(min_gap, gap_c) : min_gap;
+                hit = hit || (other && gap_c <= cp.collision_dist);
+            }
             RELAY_STAMP(13);                               // P: pair pass done
             double r = 0.0;
             bool done = true;
@@ -343,42 +371,16 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const unsigned long long running = __ballot(present && ((flags & CAVOID_F_LEARNING) || cp.evaluate_mode) && !done);
             const unsigned long long wmask = ((1ull << N) - 1ull) << base;
             const bool game_over = (running & wmask) == 0ull;
-            const float rew_f = (float)r;
-            res->flags[lane] = flags;
-            res->ctl[lane] = (done ? 1u : 0u) | ((active && game_over) ? 2u : 0u);
-            relay_post(&seq->res, t + 1);
-            RELAY_STAMP(10);                               // P: verdict posted
-            // ---- off the loop-carried chain: the final state of step t, the sort keys and gaps of this pass, the plain outputs ---
             const bool restart = active && game_over;
-            float fr = a.radius;                           // (-1 marks an absent row)
-            const unsigned long long prmask = __ballot(restart);
-            if (prmask != 0ull) {                          // the restarted worlds' final state is their next pool record
-                relay_wait(&seq->nxt, pevents);            // every earlier restart's records are re-armed
-                if (restart) {
-                    Agent nx;
-                    relay_read_nxt(*nbuf, lane, nx);
-                    a.px = nx.px; a.py = nx.py; a.vx = 0.0; a.vy = 0.0; a.heading = nx.heading;
-                    a.gx = nx.gx; a.gy = nx.gy; a.pref = nx.pref; flags = nx.flags;
-                    fr = (nx.flags & CAVOID_F_PRESENT) ? nx.radius : -1.0f;
-                }
-                relay_wait(&seq->nxt, pevents - (kRelayEvq - 1));
-                if (lane == 0) evq[pevents & (kRelayEvq - 1)] = prmask;
-                pevents += 1;
-                relay_post(&seq->ev, pevents);
-            }
-            if (t >= kRelayRing) relay_wait(&seq->cons[(t - kRelayRing) % NC], t - kRelayRing + 1);
-            {
-                RelayFin &f = ring[t & (kRelayRing - 1)];
-                f.px[lane] = a.px; f.py[lane] = a.py; f.vx[lane] = a.vx; f.vy[lane] = a.vy; f.heading[lane] = a.heading;
-                f.r[lane] = fr;
-                f.gx[lane] = a.gx; f.gy[lane] = a.gy; f.pref[lane] = a.pref; f.rew[lane] = rew_f; f.done[lane] = done ? 1.0f : 0.0f;
-                f.flags[lane] = flags; f.ctl[lane] = (done ? 1u : 0u) | (restart ? 2u : 0u);
-                RelayKeys<N> &kr = kring[t & (kRelayRing - 1)];
-#pragma unroll
-                for (int o = 0; o < N - 1; ++o) { kr.key_hi[o][lane] = key[o].hi; kr.key_lo[o][lane] = key[o].lo; kr.gap[o][lane] = gapf[o]; }
-                kr.valid[lane] = valid;
-                relay_post(&seq->fin, t + 1);
-            }
+            const float rew_f = (float)r;
+            RelayRes *res = &ress[t & 1];
+            res->flags[lane] = flags;
+            res->ctl[lane] = (done ? 1u : 0u) | (restart ? 2u : 0u);
+            res->rew[lane] = rew_f;
+            relay_post(&seq->res, t + 1);
+            const bool new_coll = (flags & CAVOID_F_IN_COLL) != 0u && (flags_t & CAVOID_F_IN_COLL) == 0u;
+            prev_surprise = __ballot(new_coll || restart) != 0ull;
+            RELAY_STAMP(10);                               // P: verdict posted
             if (active) {
                 if (!packed) {
                     io.rew[a_idx] = rew_f;
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 }
                 if (i == 0) io.game_over[w] = game_over ? 1 : 0;
             }
-            RELAY_STAMP(11);                               // P: keys posted
+            RELAY_STAMP(11);                               // P: outputs stored
         }
     } else if (role == 2 + NC) {
         // ================================================ L: actions and pool records ==========================================
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         int served = 0;
         while (true) {
             const int ev = relay_peek(&seq->ev), fin = relay_peek(&seq->fin);
-            if (served < ev && served < relay_peek(&seq->dack)) {
+            if (served < ev) {
                 asm volatile("" ::: "memory");
                 const unsigned long long mask = evq[served & (kRelayEvq - 1)];
                 if ((mask >> lane0) & 1ull) {
@@ -459,7 +461,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             relay_wait(&seq->fin, t + 1);
             RELAY_STAMP(17);                               // C: arrived
             const RelayFin &f = ring[t & (kRelayRing - 1)];
-            const RelayKeys<N> &kr = kring[t & (kRelayRing - 1)];
             Agent ao;
             ao.px = f.px[lane]; ao.py = f.py[lane]; ao.vx = f.vx[lane]; ao.vy = f.vy[lane];
             ao.heading = f.heading[lane]; ao.t_rem = 0.0;
@@ -470,16 +471,9 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             Key key[Others<N>::K];
             float gapf[Others<N>::K];
             uint32_t valid;
-            key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f;
-            if (__ballot((f.ctl[lane] & 2u) != 0u) != 0ull) {   // a world of the tile restarted: P's keys are of the world that ended
-                bool hit;
-                double min_gap;
-                pair_pass<N>(c, ao, e, present, i, base, f.px, f.py, f.r, key, gapf, valid, hit, min_gap);
-            } else {
-#pragma unroll
-                for (int o = 0; o < N - 1; ++o) { key[o].hi = kr.key_hi[o][lane]; key[o].lo = kr.key_lo[o][lane]; gapf[o] = kr.gap[o][lane]; }
-                valid = kr.valid[lane];
-            }
+            bool hit;
+            double min_gap;
+            pair_pass<N>(c, ao, e, present, i, base, f.px, f.py, f.r, key, gapf, valid, hit, min_gap);
             RELAY_STAMP(18);                               // C: ego frame + keys
             const bool last = t == n_steps - 1;
             auto order_last = [&]() {                      // the last step's rows go out after every earlier step's have landed
