@@ -10,16 +10,17 @@
 // of step t unless an agent collided or the world restarted at t.  So:
 //
 //   D  (state owner)   holds the tile's state in registers for the whole launch.  While P works on step t it computes the
-//                      successor T_c = advance(T(t), action(t+1)) as if nothing happened at t and POSTS it; then it writes the
-//                      final state of step t-1 for the consumers; then it waits for P's verdict on step t.  Only a surprise
-//                      -- a collision found at t, or a world restarting (a wave-uniform test) -- makes it select (collided
-//                      agent -> frozen copy, restarted world -> the next pool record advanced on the spot) and re-post.
+//                      successor T_c = advance(T(t), action(t+1)) as if nothing happened at t and POSTS it into ring slot t+1;
+//                      then it waits for P's verdict on step t.  Only a surprise -- a collision found at t, or a world
+//                      restarting (a wave-uniform test) -- makes it select (collided agent -> frozen copy, restarted world ->
+//                      the next pool record, patched into slot t for the consumers and advanced on the spot) and re-post.
 //   P  (pair pass)     distances, collision test, nearest gap, reward, done, game_over of step t from the posted tentative
 //                      state; verdict to D; plain outputs.  It makes the same surprise test on its own verdict: no surprise ->
 //                      it goes straight on with the successor D posted long ago, and the loop-carried chain is this wavefront
 //                      alone; surprise -> it waits for D's corrected state.
-//   C0..C{NC-1}        observation of step t (ego frame, distances and sort keys, ranking, rows, coalesced flush) from the
-//                      FINAL state of step t, steps dealt round-robin: each consumer has NC step times per step.
+//   C0..C{NC-1}        observation of step t (ego frame, distances and sort keys, ranking, rows, coalesced flush) from slot t
+//                      (state + verdict) once D has declared it final, steps dealt round-robin: each consumer has NC step
+//                      times per step.
 //   L  (loader)        everything that touches memory inside the loop and is not an output: the action block (a 64-step
 //                      byte ring in LDS, filled ahead of D) and the next scenario-pool record of every restarted lane.
 //
@@ -32,7 +33,7 @@
 
 namespace cavoid {
 
-constexpr int kRelayRing = 4;            // depth of the final-state ring (steps in flight between D and the consumers)
+constexpr int kRelayRing = 4;            // depth of the state / verdict rings (steps in flight between D, P and the consumers)
 constexpr int kRelayActRing = 64;        // action ring: steps
 constexpr int kRelayActAhead = 48;       // the loader runs at most this many steps ahead of D
 constexpr int kRelayEvq = 8;             // restart-event queue D -> L
@@ -41,7 +42,7 @@ struct RelaySeq {                        // sequence counters (each written by e
     int spec;                            // D: the SPECULATIVE tentative state of steps < spec is in `tent` (nothing happened at the step before)
     int stage;                           // D: ... and corrected for the verdict of the step before (collisions, restarts)
     int res;                             // P: verdicts of steps < res are in `res`
-    int fin;                             // D: the final state of steps < fin is in the ring
+    int fin;                             // D: the state and verdict slots of steps < fin are final (restarted worlds patched in)
     int act;                             // L: actions of steps < act are in the ring
     int ev;                              // D: restart events posted (it has read the old records of the restarted lanes)
     int nxt;                             // L: restart events served (pool records of the restarted lanes re-armed)
@@ -50,18 +51,13 @@ struct RelaySeq {                        // sequence counters (each written by e
     int pad[1];
 };
 static_assert(sizeof(RelaySeq) % 8 == 0, "the event queue behind it holds 64-bit masks");
-struct RelayTent { double px[64], py[64]; float r[64]; uint32_t flags[64]; };      // what the pair pass needs of a tentative state
+struct RelayTent { double px[64], py[64], vx[64], vy[64], heading[64]; float r[64], gx[64], gy[64], pref[64]; uint32_t flags[64]; };
 struct RelayRes { uint32_t flags[64], ctl[64]; float rew[64]; };                            // ctl: bit 0 done, bit 1 the lane's world restarts
 struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], gy[64], radius[64], pref[64]; uint32_t flags[64]; };
-struct RelayFin {
-    double px[64], py[64], vx[64], vy[64], heading[64];
-    float r[64], gx[64], gy[64], pref[64], rew[64], done[64];
-    uint32_t flags[64], ctl[64];
-};
 template <int N>
 __host__ __device__ constexpr size_t relay_lds_fixed_bytes() {
-    return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + 2 * sizeof(RelayTent) + 2 * sizeof(RelayRes) +
-           sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long) + kRelayRing * sizeof(RelayFin);
+    return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + kRelayRing * (sizeof(RelayTent) + sizeof(RelayRes)) +
+           sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long);
 }
 
 // development build: lane 0 of a role stamps the shader clock of step n_steps/2 into g_trace[tile*32 + k] (tools/trace_relay.py)
@@ -153,10 +149,9 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     double *lds_tab = reinterpret_cast<double *>(sp); sp += lds_floats_block() * sizeof(float);
     RelaySeq *seq = reinterpret_cast<RelaySeq *>(sp); sp += sizeof(RelaySeq);
     unsigned long long *evq = reinterpret_cast<unsigned long long *>(sp); sp += kRelayEvq * sizeof(unsigned long long);
-    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += 2 * sizeof(RelayTent);
+    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += kRelayRing * sizeof(RelayTent);   // state of step t in slot t % ring
     RelayNxt *nbuf = reinterpret_cast<RelayNxt *>(sp); sp += sizeof(RelayNxt);
-    RelayFin *ring = reinterpret_cast<RelayFin *>(sp); sp += kRelayRing * sizeof(RelayFin);
-    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += 2 * sizeof(RelayRes);   // (P may be one step ahead of D's reading)
+    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += kRelayRing * sizeof(RelayRes);    // verdict of step t in slot t % ring
     unsigned char *actring = sp; sp += kRelayActRing * 64;
     float *tiles = reinterpret_cast<float *>(sp);
 
@@ -208,23 +203,13 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         auto stage_out = [&](RelayTent &tn, const Agent &x, int lane) {
             const bool present = active && (x.flags & CAVOID_F_PRESENT);
             tn.px[lane] = x.px; tn.py[lane] = x.py; tn.r[lane] = present ? x.radius : -1.0f; tn.flags[lane] = x.flags;
+            tn.vx[lane] = x.vx; tn.vy[lane] = x.vy; tn.heading[lane] = x.heading;
+            tn.gx[lane] = x.gx; tn.gy[lane] = x.gy; tn.pref[lane] = x.pref;
         };
         stage_out(tents[0], T, lane0);
         relay_post(&seq->spec, 1);
         relay_post(&seq->stage, 1);
         Agent S = a;
-        float rew_prev = 0.0f;
-        uint32_t ctl_prev = 0u;
-        auto fin_out = [&](int tt, int lane) {              // the final state of step tt (S, rew_prev, ctl_prev) -> ring
-            if (tt >= kRelayRing) relay_wait(&seq->cons[(tt - kRelayRing) % NC], tt - kRelayRing + 1);
-            RelayFin &f = ring[tt & (kRelayRing - 1)];
-            const bool present = active && (S.flags & CAVOID_F_PRESENT);
-            f.px[lane] = S.px; f.py[lane] = S.py; f.vx[lane] = S.vx; f.vy[lane] = S.vy; f.heading[lane] = S.heading;
-            f.r[lane] = present ? S.radius : -1.0f;
-            f.gx[lane] = S.gx; f.gy[lane] = S.gy; f.pref[lane] = S.pref; f.rew[lane] = rew_prev; f.done[lane] = (ctl_prev & 1u) ? 1.0f : 0.0f;
-            f.flags[lane] = S.flags; f.ctl[lane] = ctl_prev;
-            relay_post(&seq->fin, tt + 1);
-        };
         for (int t = 0; t < n_steps; ++t) {
             int lane = lane0;
             asm volatile("" : "+v"(lane));
@@ -235,24 +220,21 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             Agent Tn = T;
             bool mn = false;
             int act1 = 0;
-            RelayTent &tn = tents[(t + 1) & 1];
+            RelayTent &tn = tents[(t + 1) & (kRelayRing - 1)];
             if (more) {
                 relay_wait(&seq->act, t + 2);
                 act1 = (int)actring[((t + 1) & (kRelayActRing - 1)) * 64 + lane];
                 Tn = relay_advance(cd, T, act1, active, lds_tab, mn);
+                if (t + 1 >= kRelayRing) relay_wait(&seq->cons[(t + 1 - kRelayRing) % NC], t + 2 - kRelayRing);   // slot free
                 stage_out(tn, Tn, lane);
                 relay_post(&seq->spec, t + 2);
             }
             RELAY_STAMP(1);                                // D: successor computed and posted
-            if (t > 0) fin_out(t - 1, lane);               // (off the chain) step t-1 for the consumers
             // ---- P's verdict on step t -----------------------------------------------------------------------------------
-            RELAY_STAMP(4);                                // D: final state of t-1 posted
             relay_spin(&seq->res, t + 1);
             RELAY_STAMP(2);                                // D: verdict arrived
-            const RelayRes *res = &ress[t & 1];
+            RelayRes *res = &ress[t & (kRelayRing - 1)];
             const uint32_t vflags = res->flags[lane], ctl = res->ctl[lane];
-            rew_prev = res->rew[lane];
-            ctl_prev = ctl;
             moved_any = moved_any || T_moving;
             const bool new_coll = (vflags & CAVOID_F_IN_COLL) != 0u && (T.flags & CAVOID_F_IN_COLL) == 0u;
             S = T;
@@ -271,7 +253,11 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     bool mr = false;
                     Agent Tr = nx;
                     if (more) Tr = relay_advance(cd, nx, act1, active, lds_tab, mr);
-                    if (restart) { S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr; }
+                    if (restart) {
+                        S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr;
+                        stage_out(tents[t & (kRelayRing - 1)], nx, lane);       // the consumers see step t's FINAL state: the new episode
+                        res->flags[lane] = nx.flags;
+                    }
                 }
                 if (more) {
                     const bool s_present = active && (S.flags & CAVOID_F_PRESENT);
@@ -296,9 +282,9 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     relay_post(&seq->ev, events);
                 }
             }
+            relay_post(&seq->fin, t + 1);                  // slot t (state + verdict) is final: the consumers may take it
             RELAY_STAMP(3);                                // D: next tentative state final
         }
-        fin_out(n_steps - 1, lane0);
         relay_post(&seq->stage, n_steps + 1);               // (the loader may leave: no restart is waiting for a record any more)
         // ---- state write-back (once per launch) ------------------------------------------------------------------------------
         if (restarted_any) {
@@ -331,7 +317,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             if (prev_surprise) relay_spin(&seq->stage, t + 1);
             else relay_spin(&seq->spec, t + 1);
             RELAY_STAMP(9);                                // P: stage t arrived
-            const RelayTent *tent = &tents[t & 1];
+            const RelayTent *tent = &tents[t & (kRelayRing - 1)];
             Agent a;
             a.px = tent->px[lane]; a.py = tent->py[lane];
             a.radius = tent->r[lane];
@@ -373,7 +359,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const bool game_over = (running & wmask) == 0ull;
             const bool restart = active && game_over;
             const float rew_f = (float)r;
-            RelayRes *res = &ress[t & 1];
+            RelayRes *res = &ress[t & (kRelayRing - 1)];
             res->flags[lane] = flags;
             res->ctl[lane] = (done ? 1u : 0u) | (restart ? 2u : 0u);
             res->rew[lane] = rew_f;
@@ -460,12 +446,14 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             RELAY_STAMP(16);                               // C: waiting for final state t
             relay_wait(&seq->fin, t + 1);
             RELAY_STAMP(17);                               // C: arrived
-            const RelayFin &f = ring[t & (kRelayRing - 1)];
+            const RelayTent &f = tents[t & (kRelayRing - 1)];
+            const RelayRes &v = ress[t & (kRelayRing - 1)];
             Agent ao;
             ao.px = f.px[lane]; ao.py = f.py[lane]; ao.vx = f.vx[lane]; ao.vy = f.vy[lane];
             ao.heading = f.heading[lane]; ao.t_rem = 0.0;
             ao.gx = f.gx[lane]; ao.gy = f.gy[lane]; ao.speed = 0.0f;
-            ao.radius = f.r[lane]; ao.pref = f.pref[lane]; ao.flags = f.flags[lane];
+            ao.radius = f.r[lane]; ao.pref = f.pref[lane]; ao.flags = v.flags[lane];
+            const float rew_c = v.rew[lane], done_c = (v.ctl[lane] & 1u) ? 1.0f : 0.0f;
             const bool present = active && (ao.flags & CAVOID_F_PRESENT);
             const Ego e = ego_frame_obs(ao);
             Key key[Others<N>::K];
@@ -482,7 +470,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                         if (o != cid) relay_wait(&seq->cfin[o], 1);
             };
             assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
-                                         io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, f.rew[lane], f.done[lane], wave,
+                                         io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,
                                          order_last);
             relay_post(&seq->cons[cid], t + 1);
             RELAY_STAMP(19);                               // C: rows flushed

@@ -16,7 +16,7 @@ from rl_collision_avoidance_amd import _lib
 from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
 from rl_collision_avoidance_amd.config import EnvConfig
 
-NAMES = {0: "D iteration begins", 1: "D successor posted", 4: "D final state t-1 posted", 2: "D verdict arrived", 3: "D next state final",
+NAMES = {0: "D iteration begins", 1: "D successor posted", 2: "D verdict arrived", 3: "D slot final",
          8: "P waits for stage", 9: "P stage arrived", 12: "P own state read", 13: "P pair pass done", 10: "P verdict posted", 11: "P outputs stored",
          16: "C waits for final", 17: "C final arrived", 18: "C ego + keys", 19: "C rows flushed"}
 
