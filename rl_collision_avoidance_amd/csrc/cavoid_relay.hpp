@@ -91,14 +91,14 @@ __device__ __forceinline__ void relay_post(int *p, int v) {
 
 // One agent's step up to (not including) the pair pass: E4 decode, scripted policies 1 / 2, E5 unicycle dynamics, goal test,
 // time budget -- env_kernel's statements, value for value.
-__device__ __forceinline__ Agent relay_advance(const KCfg &c, const Agent &in, int act, bool active, const double *lds_tab, bool &moving) {
+__device__ __forceinline__ Agent relay_advance(const KCfg &c, const Agent &in, double tab_speed, double tab_dh, bool active, bool &moving) {
     Agent a = in;
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
     const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
-    double a0 = (double)a.pref * lds_tab[2 * act];
-    double a1 = lds_tab[2 * act + 1];
+    double a0 = (double)a.pref * tab_speed;               // the action's table row, read one step ahead by the caller
+    double a1 = tab_dh;
     if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {
         if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
         if (pol == 2u) {
@@ -199,7 +199,17 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         __syncthreads();                                   // table, counters, the loader's first records and actions
         int events = 0;
         bool T_moving;
-        Agent T = relay_advance(cd, a, (int)actring[lane0], active, lds_tab, T_moving);   // step 0 is not speculative
+        Agent T;
+        {
+            const int act0 = (int)actring[lane0];
+            T = relay_advance(cd, a, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
+        }
+        // the table row of the NEXT step's action is read one iteration ahead (two dependent LDS trips off the chain)
+        double tab_s = 0.0, tab_h = 0.0;
+        if (n_steps > 1) {
+            const int actn = (int)actring[64 + lane0];
+            tab_s = lds_tab[2 * actn]; tab_h = lds_tab[2 * actn + 1];
+        }
         auto stage_out = [&](RelayTent &tn, const Agent &x, int lane) {
             const bool present = active && (x.flags & CAVOID_F_PRESENT);
             tn.px[lane] = x.px; tn.py[lane] = x.py; tn.r[lane] = present ? x.radius : -1.0f; tn.flags[lane] = x.flags;
@@ -209,26 +219,25 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         stage_out(tents[0], T, lane0);
         relay_post(&seq->spec, 1);
         relay_post(&seq->stage, 1);
-        Agent S = a;
-        for (int t = 0; t < n_steps; ++t) {
+        // steps 0 .. n-2: each iteration posts the successor (step t+1) and then settles step t; the last step is settled below
+        for (int t = 0; t + 1 < n_steps; ++t) {
             int lane = lane0;
             asm volatile("" : "+v"(lane));
-            const bool more = t + 1 < n_steps;
             RELAY_STAMP(0);                                // D: iteration begins (stage t posted)
             // ---- the successor of step t as if nothing happens at t, while P works on step t: posted at once, P takes it as it
             //      is when its own verdict says so (no new collision, no restart in the tile) ---------------------------------
-            Agent Tn = T;
-            bool mn = false;
-            int act1 = 0;
             RelayTent &tn = tents[(t + 1) & (kRelayRing - 1)];
-            if (more) {
-                relay_wait(&seq->act, t + 2);
-                act1 = (int)actring[((t + 1) & (kRelayActRing - 1)) * 64 + lane];
-                Tn = relay_advance(cd, T, act1, active, lds_tab, mn);
-                if (t + 1 >= kRelayRing) relay_wait(&seq->cons[(t + 1 - kRelayRing) % NC], t + 2 - kRelayRing);   // slot free
-                stage_out(tn, Tn, lane);
-                relay_post(&seq->spec, t + 2);
+            const double tab_s1 = tab_s, tab_h1 = tab_h;    // action(t+1)'s row
+            int act2 = 0;
+            if (t + 2 < n_steps) {
+                if ((t & 7) == 0) relay_wait(&seq->act, t + 10 < n_steps ? t + 10 : n_steps);   // (the loader runs 48 steps ahead)
+                act2 = (int)actring[((t + 2) & (kRelayActRing - 1)) * 64 + lane];
             }
+            bool mn;
+            Agent Tn = relay_advance(cd, T, tab_s1, tab_h1, active, mn);
+            if (t + 1 >= kRelayRing) relay_wait(&seq->cons[(t + 1 - kRelayRing) % NC], t + 2 - kRelayRing);   // slot free
+            stage_out(tn, Tn, lane);
+            relay_post(&seq->spec, t + 2);
             RELAY_STAMP(1);                                // D: successor computed and posted
             // ---- P's verdict on step t -----------------------------------------------------------------------------------
             relay_spin(&seq->res, t + 1);
@@ -237,44 +246,37 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const uint32_t vflags = res->flags[lane], ctl = res->ctl[lane];
             moved_any = moved_any || T_moving;
             const bool new_coll = (vflags & CAVOID_F_IN_COLL) != 0u && (T.flags & CAVOID_F_IN_COLL) == 0u;
-            S = T;
-            S.flags = vflags;
             const bool restart = (ctl & 2u) != 0u;
             const unsigned long long rmask = __ballot(restart);
             const bool surprise = __ballot(new_coll || restart) != 0ull;       // the same test P makes on its own verdict
-            if (!surprise) {                               // the posted successor stands: an agent that is done was frozen by
-                T = Tn;                                    // relay_advance itself (its flags were known), nobody else changed
-                T_moving = mn;
-            } else {
+            if (surprise) {
+                Agent S = T;                               // the committed state of step t
+                S.flags = vflags;
                 if (rmask != 0ull) {                       // some world of the tile starts a new episode
                     relay_wait(&seq->nxt, events);         // every earlier restart's records are re-armed
                     Agent nx;
                     relay_read_nxt(*nbuf, lane, nx);
-                    bool mr = false;
-                    Agent Tr = nx;
-                    if (more) Tr = relay_advance(cd, nx, act1, active, lds_tab, mr);
+                    bool mr;
+                    const Agent Tr = relay_advance(cd, nx, tab_s1, tab_h1, active, mr);
                     if (restart) {
                         S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr;
                         stage_out(tents[t & (kRelayRing - 1)], nx, lane);       // the consumers see step t's FINAL state: the new episode
                         res->flags[lane] = nx.flags;
                     }
                 }
-                if (more) {
-                    const bool s_present = active && (S.flags & CAVOID_F_PRESENT);
-                    const bool s_done = (S.flags & CAVOID_F_DONE_MASK) != 0u;
-                    const bool frozen = s_present && s_done && !restart;   // env_kernel: present_in && done_in
-                    uint32_t fflags = S.flags;
-                    if (S.flags & CAVOID_F_AT_GOAL) fflags |= CAVOID_F_WAS_AT_GOAL;
-                    if (S.flags & CAVOID_F_IN_COLL) fflags |= CAVOID_F_WAS_IN_COLL;
-                    T.px = frozen ? S.px : Tn.px; T.py = frozen ? S.py : Tn.py; T.heading = frozen ? S.heading : Tn.heading;
-                    T.t_rem = frozen ? S.t_rem : Tn.t_rem;
-                    T.vx = frozen ? 0.0 : Tn.vx; T.vy = frozen ? 0.0 : Tn.vy; T.speed = frozen ? 0.0f : Tn.speed;
-                    T.gx = Tn.gx; T.gy = Tn.gy; T.radius = Tn.radius; T.pref = Tn.pref;      // (per-episode constants: S's == Tn's)
-                    T.flags = frozen ? fflags : Tn.flags;
-                    T_moving = frozen ? false : mn;
-                    stage_out(tn, T, lane);                // the posted successor was wrong for some lane
-                    relay_post(&seq->stage, t + 2);
-                }
+                const bool s_present = active && (S.flags & CAVOID_F_PRESENT);
+                const bool s_done = (S.flags & CAVOID_F_DONE_MASK) != 0u;
+                const bool frozen = s_present && s_done && !restart;   // env_kernel: present_in && done_in
+                uint32_t fflags = S.flags;
+                if (S.flags & CAVOID_F_AT_GOAL) fflags |= CAVOID_F_WAS_AT_GOAL;
+                if (S.flags & CAVOID_F_IN_COLL) fflags |= CAVOID_F_WAS_IN_COLL;
+                Tn.px = frozen ? S.px : Tn.px; Tn.py = frozen ? S.py : Tn.py; Tn.heading = frozen ? S.heading : Tn.heading;
+                Tn.t_rem = frozen ? S.t_rem : Tn.t_rem;
+                Tn.vx = frozen ? 0.0 : Tn.vx; Tn.vy = frozen ? 0.0 : Tn.vy; Tn.speed = frozen ? 0.0f : Tn.speed;
+                Tn.flags = frozen ? fflags : Tn.flags;      // (gx, gy, radius, pref: per-episode constants, S's == Tn's)
+                mn = frozen ? false : mn;
+                stage_out(tn, Tn, lane);                   // the posted successor was wrong for some lane
+                relay_post(&seq->stage, t + 2);
                 if (rmask != 0ull) {                       // tell the loader which lanes need their next pool record
                     relay_wait(&seq->nxt, events - (kRelayEvq - 1));
                     if (lane == 0) evq[events & (kRelayEvq - 1)] = rmask;
@@ -282,8 +284,35 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     relay_post(&seq->ev, events);
                 }
             }
+            // (no surprise: the posted successor stands -- an agent that is done was frozen by relay_advance itself, its flags
+            //  were known; nobody else changed)
+            T = Tn;
+            T_moving = mn;
+            tab_s = lds_tab[2 * act2]; tab_h = lds_tab[2 * act2 + 1];
             relay_post(&seq->fin, t + 1);                  // slot t (state + verdict) is final: the consumers may take it
-            RELAY_STAMP(3);                                // D: next tentative state final
+            RELAY_STAMP(3);                                // D: slot t final
+        }
+        // ---- the last step: nothing to post, only its committed state ---------------------------------------------------------
+        Agent S = T;
+        {
+            const int t = n_steps - 1;
+            relay_spin(&seq->res, t + 1);
+            RelayRes *res = &ress[t & (kRelayRing - 1)];
+            const uint32_t vflags = res->flags[lane0], ctl = res->ctl[lane0];
+            moved_any = moved_any || T_moving;
+            S.flags = vflags;
+            const bool restart = (ctl & 2u) != 0u;
+            if (__ballot(restart) != 0ull) {
+                relay_wait(&seq->nxt, events);
+                Agent nx;
+                relay_read_nxt(*nbuf, lane0, nx);
+                if (restart) {
+                    S = nx; episode += 1u; restarted_any = true;
+                    stage_out(tents[t & (kRelayRing - 1)], nx, lane0);
+                    res->flags[lane0] = nx.flags;
+                }
+            }
+            relay_post(&seq->fin, t + 1);
         }
         relay_post(&seq->stage, n_steps + 1);               // (the loader may leave: no restart is waiting for a record any more)
         // ---- state write-back (once per launch) ------------------------------------------------------------------------------
@@ -309,8 +338,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         __syncthreads();
         for (int t = 0; t < n_steps; ++t) {
             int lane = lane0, i = i0, base = base0;
-            int64_t a_idx = a_idx0;
-            asm volatile("" : "+v"(lane), "+v"(i), "+v"(base), "+v"(a_idx));
+            asm volatile("" : "+v"(lane), "+v"(i), "+v"(base));
             RELAY_STAMP(8);                                // P: waiting for stage t
             // the speculative successor D posted while this wavefront worked on step t-1 is exact unless the verdict of t-1 found
             // a new collision or restarted a world: only then wait for D's corrected state
@@ -366,15 +394,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             relay_post(&seq->res, t + 1);
             const bool new_coll = (flags & CAVOID_F_IN_COLL) != 0u && (flags_t & CAVOID_F_IN_COLL) == 0u;
             prev_surprise = __ballot(new_coll || restart) != 0ull;
-            RELAY_STAMP(10);                               // P: verdict posted
-            if (active) {
-                if (!packed) {
-                    io.rew[a_idx] = rew_f;
-                    io.done[a_idx] = done ? 1 : 0;
-                }
-                if (i == 0) io.game_over[w] = game_over ? 1 : 0;
-            }
-            RELAY_STAMP(11);                               // P: outputs stored
+            RELAY_STAMP(10);                               // P: verdict posted (the plain outputs go out with the consumer's rows)
         }
     } else if (role == 2 + NC) {
         // ================================================ L: actions and pool records ==========================================
@@ -453,7 +473,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             ao.heading = f.heading[lane]; ao.t_rem = 0.0;
             ao.gx = f.gx[lane]; ao.gy = f.gy[lane]; ao.speed = 0.0f;
             ao.radius = f.r[lane]; ao.pref = f.pref[lane]; ao.flags = v.flags[lane];
-            const float rew_c = v.rew[lane], done_c = (v.ctl[lane] & 1u) ? 1.0f : 0.0f;
+            const uint32_t ctl_c = v.ctl[lane];
+            const float rew_c = v.rew[lane], done_c = (ctl_c & 1u) ? 1.0f : 0.0f;
             const bool present = active && (ao.flags & CAVOID_F_PRESENT);
             const Ego e = ego_frame_obs(ao);
             Key key[Others<N>::K];
@@ -472,6 +493,13 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
                                          io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,
                                          order_last);
+            if (active) {                                  // the step's plain outputs (behind order_last, like the rows)
+                if (!packed) {
+                    io.rew[a_idx0] = rew_c;
+                    io.done[a_idx0] = (ctl_c & 1u) ? 1 : 0;
+                }
+                if (i0 == 0) io.game_over[w] = (ctl_c & 2u) ? 1 : 0;
+            }
             relay_post(&seq->cons[cid], t + 1);
             RELAY_STAMP(19);                               // C: rows flushed
         }
