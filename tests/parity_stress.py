@@ -70,8 +70,10 @@ def main():
     cases = [(4, 4096, 400, s, 0.0, 0) for s in range(6)] + [(4, 2048, 300, 100 + s, 0.4, 1) for s in range(3)] + \
             [(10, 1024, 300, 200 + s, 0.3, 0) for s in range(3)] + [(3, 2048, 300, 300, 0.3, 2), (16, 256, 200, 400, 0.1, 0)] + \
             [(4, 4096, 512, 500 + s, 0.0, 0, 0, 0.0, 32) for s in range(3)] + [(10, 1024, 320, 600, 0.3, 0, 0, 0.0, 16)] + \
-            [(4, 2048, 300, 700 + s, 0.6, 0, 1, 0.5, 1) for s in range(2)] + [(10, 512, 256, 800, 0.5, 1, 1, 0.5, 8)]
-    # (round 2: + step-loop launches with the packed record, + GEN v2 scenarios with RVO agents)
+            [(4, 2048, 300, 700 + s, 0.6, 0, 1, 0.5, 1) for s in range(2)] + [(10, 512, 256, 800, 0.5, 1, 1, 0.5, 8)] + \
+            [(4, 8192, 640, 900, 0.3, 0, 0, 0.0, 64), (3, 3000, 300, 901, 0.3, 2, 0, 0.0, 20), (5, 2000, 340, 902, 0.2, 1, 0, 0.0, 17)]
+    # (round 2: + step-loop launches with the packed record, + GEN v2 scenarios with RVO agents; the last three: env_relay_kernel
+    #  with scripted agents in the tile, N = 3 / 4 / 5, 17 ... 64 steps per launch)
     for c in cases:
         r = run(*c)
         for k in ("obs", "rew", "state"):
