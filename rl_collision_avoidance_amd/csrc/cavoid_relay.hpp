@@ -89,9 +89,52 @@ __device__ __forceinline__ void relay_post(int *p, int v) {
     asm volatile("" ::: "memory");
 }
 
+// sincos_bounded (cavoid_kernels.hpp) with its fifteen constants handed in: D pins them in scalar registers once, instead of
+// re-materialising each as two moves per step (the step-loop units are built without MachineLICM).  Same operations, same
+// order: bit-identical.
+struct RelayTrig {
+    double two_over_pi, pio2_hi, pio2_lo, s1, s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
+};
+__device__ __forceinline__ RelayTrig relay_trig_constants() {
+    RelayTrig k;
+    k.two_over_pi = 0.63661977236758134308; k.pio2_hi = 1.57079632673412561417e+00; k.pio2_lo = 6.07710050650619224932e-11;
+    k.s6 = 1.58969099521155010221e-10; k.s5 = -2.50507602534068634195e-08; k.s4 = 2.75573137070700676789e-06;
+    k.s3 = -1.98412698298579493134e-04; k.s2 = 8.33333333332248946124e-03; k.s1 = -1.66666666666666324348e-01;
+    k.c6 = -1.13596475577881948265e-11; k.c5 = 2.08757232129817482790e-09; k.c4 = -2.75573143513906633035e-07;
+    k.c3 = 2.48015872894767294178e-05; k.c2 = -1.38888888888741095749e-03; k.c1 = 4.16666666666666019037e-02;
+    asm volatile("" : "+s"(k.two_over_pi), "+s"(k.pio2_hi), "+s"(k.pio2_lo), "+s"(k.s1), "+s"(k.s2), "+s"(k.s3), "+s"(k.s4), "+s"(k.s5),
+                 "+s"(k.s6), "+s"(k.c1), "+s"(k.c2), "+s"(k.c3), "+s"(k.c4), "+s"(k.c5), "+s"(k.c6));
+    return k;
+}
+__device__ __forceinline__ void relay_sincos(const RelayTrig &q, double x, double *sn, double *cs) {
+    const double k = rint(x * q.two_over_pi);
+    double r = __builtin_fma(-k, q.pio2_hi, x);
+    r = __builtin_fma(-k, q.pio2_lo, r);
+    const double z = r * r;
+    double ps = q.s6;
+    ps = __builtin_fma(ps, z, q.s5);
+    ps = __builtin_fma(ps, z, q.s4);
+    ps = __builtin_fma(ps, z, q.s3);
+    ps = __builtin_fma(ps, z, q.s2);
+    ps = __builtin_fma(ps, z, q.s1);
+    const double s = __builtin_fma(r * z, ps, r);
+    double pc = q.c6;
+    pc = __builtin_fma(pc, z, q.c5);
+    pc = __builtin_fma(pc, z, q.c4);
+    pc = __builtin_fma(pc, z, q.c3);
+    pc = __builtin_fma(pc, z, q.c2);
+    pc = __builtin_fma(pc, z, q.c1);
+    const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    const int qd = (int)k & 3;
+    const double s_out = (qd & 1) ? c : s, c_out = (qd & 1) ? s : c;
+    *sn = (qd & 2) ? -s_out : s_out;
+    *cs = ((qd + 1) & 2) ? -c_out : c_out;
+}
+
 // One agent's step up to (not including) the pair pass: E4 decode, scripted policies 1 / 2, E5 unicycle dynamics, goal test,
 // time budget -- env_kernel's statements, value for value.
-__device__ __forceinline__ Agent relay_advance(const KCfg &c, const Agent &in, double tab_speed, double tab_dh, bool active, bool &moving) {
+__device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &trig, const Agent &in, double tab_speed, double tab_dh, bool active,
+                                               bool &moving) {
     Agent a = in;
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
@@ -116,21 +159,21 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const Agent &in, d
     }
     const double nh = wrap_angle(dh + a.heading);
     double sn, cs;
-    sincos_bounded(nh, &sn, &cs);
+    relay_sincos(trig, nh, &sn, &cs);
     const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
     const double nvx = a0 * cs, nvy = a0 * sn, nsp = a0;
     a.px = moving ? npx : a.px; a.py = moving ? npy : a.py; a.heading = moving ? nh : a.heading;
     a.vx = moving ? nvx : 0.0; a.vy = moving ? nvy : 0.0; a.speed = moving ? (float)nsp : 0.0f;
-    if (present_in && done_in) {
-        if (flags_in & CAVOID_F_AT_GOAL) a.flags |= CAVOID_F_WAS_AT_GOAL;
-        if (flags_in & CAVOID_F_IN_COLL) a.flags |= CAVOID_F_WAS_IN_COLL;
-    }
-    if (moving) {
-        const double dx = a.px - (double)a.gx, dy = a.py - (double)a.gy;
-        if (dx * dx + dy * dy <= c.near_goal_sq) a.flags |= CAVOID_F_AT_GOAL;
-        a.t_rem -= c.dt;
-        if (c.timeout_enabled && a.t_rem <= 0.0) a.flags |= CAVOID_F_RAN_OUT;
-    }
+    // (env_kernel's branches as selects: same values, no divergent control flow on the chain)
+    uint32_t latch = 0u;
+    latch |= (flags_in & CAVOID_F_AT_GOAL) ? CAVOID_F_WAS_AT_GOAL : 0u;
+    latch |= (flags_in & CAVOID_F_IN_COLL) ? CAVOID_F_WAS_IN_COLL : 0u;
+    a.flags |= (present_in && done_in) ? latch : 0u;
+    const double dx = a.px - (double)a.gx, dy = a.py - (double)a.gy;
+    a.flags |= (moving && dx * dx + dy * dy <= c.near_goal_sq) ? CAVOID_F_AT_GOAL : 0u;
+    const double t_next = a.t_rem - c.dt;
+    a.t_rem = moving ? t_next : a.t_rem;
+    a.flags |= (moving && c.timeout_enabled && t_next <= 0.0) ? CAVOID_F_RAN_OUT : 0u;
     return a;
 }
 
@@ -182,6 +225,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         KCfg cd = c;                                        // this role's constants, pinned in scalar registers (see P)
         asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.max_turn_rate), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
                      "+s"(cd.timeout_enabled));
+        const RelayTrig trig = relay_trig_constants();
         Agent a;
         a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
         a.gx = a.gy = a.radius = a.pref = a.speed = 0.0f;
@@ -202,7 +246,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         Agent T;
         {
             const int act0 = (int)actring[lane0];
-            T = relay_advance(cd, a, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
+            T = relay_advance(cd, trig, a, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
         }
         // the table row of the NEXT step's action is read one iteration ahead (two dependent LDS trips off the chain)
         double tab_s = 0.0, tab_h = 0.0;
@@ -219,6 +263,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         stage_out(tents[0], T, lane0);
         relay_post(&seq->spec, 1);
         relay_post(&seq->stage, 1);
+        int cslot = 0;                                      // (t + 1 - ring) mod NC, kept by counting
         // steps 0 .. n-2: each iteration posts the successor (step t+1) and then settles step t; the last step is settled below
         for (int t = 0; t + 1 < n_steps; ++t) {
             int lane = lane0;
@@ -234,8 +279,11 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 act2 = (int)actring[((t + 2) & (kRelayActRing - 1)) * 64 + lane];
             }
             bool mn;
-            Agent Tn = relay_advance(cd, T, tab_s1, tab_h1, active, mn);
-            if (t + 1 >= kRelayRing) relay_wait(&seq->cons[(t + 1 - kRelayRing) % NC], t + 2 - kRelayRing);   // slot free
+            Agent Tn = relay_advance(cd, trig, T, tab_s1, tab_h1, active, mn);
+            if (t + 1 >= kRelayRing) {                      // slot free: the consumer of step t+1-ring is done with it
+                relay_wait(&seq->cons[cslot], t + 2 - kRelayRing);
+                cslot = cslot + 1 == NC ? 0 : cslot + 1;
+            }
             stage_out(tn, Tn, lane);
             relay_post(&seq->spec, t + 2);
             RELAY_STAMP(1);                                // D: successor computed and posted
@@ -257,7 +305,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     Agent nx;
                     relay_read_nxt(*nbuf, lane, nx);
                     bool mr;
-                    const Agent Tr = relay_advance(cd, nx, tab_s1, tab_h1, active, mr);
+                    const Agent Tr = relay_advance(cd, trig, nx, tab_s1, tab_h1, active, mr);
                     if (restart) {
                         S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr;
                         stage_out(tents[t & (kRelayRing - 1)], nx, lane);       // the consumers see step t's FINAL state: the new episode
@@ -370,18 +418,20 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 hit = hit || (other && gap_c <= cp.collision_dist);
             }
             RELAY_STAMP(13);                               // P: pair pass done
-            double r = 0.0;
-            bool done = true;
-            if (present) {
-                r = cp.r_step;
-                if (flags & CAVOID_F_AT_GOAL) { if (!(flags & CAVOID_F_WAS_AT_GOAL)) r = cp.r_goal; }
-                else if (!(flags & CAVOID_F_WAS_IN_COLL)) {
-                    if (hit) { r = cp.r_coll; flags |= CAVOID_F_IN_COLL; }
-                    else if (min_gap <= cp.close_range) r = cp.r_close + cp.close_slope * min_gap;
-                }
-                r = fmin(fmax(r, cp.clip_lo), cp.clip_hi);
-                done = (flags & CAVOID_F_DONE_MASK) != 0u;
-            }
+            // E7 / E8 (env_kernel's branches as selects: same values, no divergent control flow on the chain)
+            const bool at_goal = (flags & CAVOID_F_AT_GOAL) != 0u;
+            const bool may_collide = present && !at_goal && (flags & CAVOID_F_WAS_IN_COLL) == 0u;
+            const bool collides = may_collide && hit;
+            const bool close = may_collide && !hit && min_gap <= cp.close_range;
+            double r = present ? cp.r_step : 0.0;
+            r = (present && at_goal && (flags & CAVOID_F_WAS_AT_GOAL) == 0u) ? cp.r_goal : r;
+            r = collides ? cp.r_coll : r;
+            const double r_near = cp.r_close + cp.close_slope * min_gap;
+            r = close ? r_near : r;
+            flags |= collides ? CAVOID_F_IN_COLL : 0u;
+            const double r_clip = fmin(fmax(r, cp.clip_lo), cp.clip_hi);
+            r = present ? r_clip : r;
+            const bool done = present ? (flags & CAVOID_F_DONE_MASK) != 0u : true;
             const unsigned long long running = __ballot(present && ((flags & CAVOID_F_LEARNING) || cp.evaluate_mode) && !done);
             const unsigned long long wmask = ((1ull << N) - 1ull) << base;
             const bool game_over = (running & wmask) == 0ull;
