@@ -78,6 +78,18 @@ __device__ __forceinline__ void relay_wait(const int *p, int v) {
     while (relay_peek(p) < v) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
+// The observation wavefronts and the loader wait with a bound: a wait that does not end within ~1 s (2^24 polls; a step is
+// microseconds) is a broken hand-over somewhere in the workgroup, and the wavefront traps -- the process gets a launch failure
+// instead of a GPU that never answers again.  (D and P wait unbounded: the bound costs their loops 5 %.)
+constexpr int kRelayPollLimit = 1 << 24;
+__device__ __forceinline__ void relay_wait_bounded(const int *p, int v) {
+    int polls = 0;
+    while (relay_peek(p) < v) {
+        if (++polls > kRelayPollLimit) __builtin_trap();
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
 // the two waits of the loop-carried chain (D for P's verdict, P for D's next state) poll without sleeping
 __device__ __forceinline__ void relay_spin(const int *p, int v) {
     while (relay_peek(p) < v) { }
@@ -474,7 +486,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         load_actions(n_steps < kRelayActAhead ? n_steps : kRelayActAhead);
         __syncthreads();
         relay_post(&seq->act, loaded);
-        int served = 0;
+        int served = 0, idle_polls = 0;
         while (true) {
             const int ev = relay_peek(&seq->ev), fin = relay_peek(&seq->fin);
             if (served < ev) {
@@ -490,6 +502,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     nb.flags[lane0] = r0.flags;
                 }
                 served += 1;
+                idle_polls = 0;
                 relay_post(&seq->nxt, served);
                 continue;
             }
@@ -498,10 +511,12 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 if (upto > loaded + 8) upto = loaded + 8;
                 if (upto > n_steps) upto = n_steps;
                 load_actions(upto);
+                idle_polls = 0;
                 relay_post(&seq->act, loaded);
                 continue;
             }
             if (fin >= n_steps && relay_peek(&seq->stage) > n_steps) break;
+            if (++idle_polls > kRelayPollLimit) __builtin_trap();
             __builtin_amdgcn_s_sleep(2);
         }
     } else {
@@ -514,7 +529,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             int lane = lane0, i = i0, base = base0;
             asm volatile("" : "+v"(lane), "+v"(i), "+v"(base));
             RELAY_STAMP(16);                               // C: waiting for final state t
-            relay_wait(&seq->fin, t + 1);
+            relay_wait_bounded(&seq->fin, t + 1);
             RELAY_STAMP(17);                               // C: arrived
             const RelayTent &f = tents[t & (kRelayRing - 1)];
             const RelayRes &v = ress[t & (kRelayRing - 1)];
@@ -538,7 +553,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             auto order_last = [&]() {                      // the last step's rows go out after every earlier step's have landed
                 if (last)
                     for (int o = 0; o < NC; ++o)
-                        if (o != cid) relay_wait(&seq->cfin[o], 1);
+                        if (o != cid) relay_wait_bounded(&seq->cfin[o], 1);
             };
             assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
                                          io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,

@@ -115,6 +115,36 @@ def test_multi_step_launch_equals_single_steps(N, W, pool, wpw, pipe, monkeypatc
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("N,W,nc", [(4, 1, 1), (4, 17, 2), (4, 1000, 4), (2, 33, 3), (5, 64, 2), (1, 70, 2), (10, 100, 2), (4, 8192, 3)])
+def test_relay_kernel_short_launches_and_consumer_counts(N, W, nc, monkeypatch):
+    """env_relay_kernel's hand-over protocol at its edges: launches shorter than its rings (2 ... 6 steps), every number of
+    observation wavefronts, tiles with one world, scripted (static / non-cooperative) agents in the tile, a time budget that
+    restarts worlds every few steps.  Reference: the same steps one per launch."""
+    monkeypatch.setenv("CAVOID_PIPELINE", "2")
+    monkeypatch.setenv("CAVOID_RELAY_CONSUMERS", str(nc))
+    kw = dict(gen_pool_size=257, gen_min_agents=max(1, N - 2), gen_nonlearning_fraction=0.3 if N > 1 else 0.0)
+    a = _env(W, N, seed=31, **kw)
+    monkeypatch.delenv("CAVOID_PIPELINE", raising=False)
+    monkeypatch.delenv("CAVOID_RELAY_CONSUMERS", raising=False)
+    b = _env(W, N, seed=31, **kw)
+    a.reset(); b.reset()
+    T = 120
+    acts = _acts(T, W, N, 17)
+    lo = 0
+    for n in (2, 3, 4, 5, 6, 2, 9, 33, 3, 53):
+        a.step_autoreset_n(acts[lo:lo + n])
+        for t in range(lo, lo + n):
+            b.step_autoreset(acts[t])
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.rewards, b.rewards), (lo, n)
+        assert torch.equal(a.done, b.done) and torch.equal(a.game_over, b.game_over), (lo, n)
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert torch.equal(x, y), (lo, n)
+        assert torch.equal(a.episode, b.episode)
+        lo += n
+    assert a.episode.max().item() >= 1
+    a.close(); b.close()
+
+
 def test_multi_step_packed_run_against_the_oracle():
     """One direct check of the new launch form against the float64 oracle: 40 steps in one launch, packed record."""
     W, N, T, seed = 512, 4, 40, 21
