@@ -105,6 +105,11 @@ class BatchedCollisionAvoidanceEnv(object):
         self.done = torch.zeros((W, N), dtype=torch.uint8, device=self.device)
         self.game_over = torch.zeros((W,), dtype=torch.uint8, device=self.device)
         self.packed_width = self.obs_width + 2
+        # the hot calls pass these as they are: the output tensors are allocated once and never replaced
+        self._dev_index = dev_index
+        self._p_obs, self._p_rew = C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.rewards.data_ptr())
+        self._p_done, self._p_go = C.c_void_p(self.done.data_ptr()), C.c_void_p(self.game_over.data_ptr())
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # (an int, without a Stream object around it)
         self.seed(seed)
 
     # -- packed outputs: one (obs | reward | done) record per agent, written by the kernel itself ---------------
@@ -164,6 +169,8 @@ class BatchedCollisionAvoidanceEnv(object):
             pass
 
     def _stream(self):
+        if self._raw_stream is not None:
+            return C.c_void_p(self._raw_stream(self._dev_index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @staticmethod
@@ -171,6 +178,8 @@ class BatchedCollisionAvoidanceEnv(object):
         return None if t is None else C.c_void_p(t.data_ptr())
 
     def _want(self, t: torch.Tensor, shape, dtype, name: str) -> torch.Tensor:
+        if t.dtype is dtype and t.shape == shape and t.device == self.device and t.is_contiguous():
+            return t                                       # (the usual case, checked first: this sits on the launch path)
         if t.device != self.device:
             raise ValueError("%s must live on %s (got %s)" % (name, self.device, t.device))
         if t.dtype != dtype:
@@ -276,9 +285,10 @@ class BatchedCollisionAvoidanceEnv(object):
         obs = self.obs if obs_out is None else self._want(obs_out, self.obs.shape, torch.float32, "obs_out")
         if obs_out is not None and obs.data_ptr() != obs_out.data_ptr():
             raise ValueError("obs_out must be a contiguous float32 tensor on the env's device")
-        _lib.check(self._lib.cavoid_step_autoreset(self._h, self._ptr(a), self._ptr(obs), self._ptr(self.rewards),
-                                                   self._ptr(self.done), self._ptr(self.game_over), self._stream()),
-                   "cavoid_step_autoreset")
+        rc = self._lib.cavoid_step_autoreset(self._h, C.c_void_p(a.data_ptr()), self._p_obs if obs_out is None else C.c_void_p(obs.data_ptr()),
+                                             self._p_rew, self._p_done, self._p_go, self._stream())
+        if rc != 0:
+            _lib.check(rc, "cavoid_step_autoreset")
         return obs, self.rewards, self.done, self.game_over
 
     def step_autoreset_n(self, actions: torch.Tensor, n_steps: Optional[int] = None):
@@ -291,9 +301,10 @@ class BatchedCollisionAvoidanceEnv(object):
             raise ValueError("n_steps > number of action slices")
         a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
         stride = self.num_worlds * self.max_agents
-        _lib.check(self._lib.cavoid_step_autoreset_n(self._h, self._ptr(a), stride, n, self._ptr(self.obs),
-                                                     self._ptr(self.rewards), self._ptr(self.done),
-                                                     self._ptr(self.game_over), self._stream()), "cavoid_step_autoreset_n")
+        rc = self._lib.cavoid_step_autoreset_n(self._h, C.c_void_p(a.data_ptr()), stride, n, self._p_obs, self._p_rew, self._p_done,
+                                               self._p_go, self._stream())
+        if rc != 0:
+            _lib.check(rc, "cavoid_step_autoreset_n")
         return self.obs, self.rewards, self.done, self.game_over
 
     # -- measurement -------------------------------------------------------------------------------
