@@ -221,7 +221,7 @@ def step_kernel_name(N: int, W: int, spl: int) -> str:
         return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET_N, false>" % N
     tiles = -(-W // (64 // N))
     pipe = os.environ.get("CAVOID_PIPELINE", "2")
-    if tiles <= 512 and N <= 11 and pipe not in ("0", "1"):
+    if tiles <= 512 and N <= 6 and pipe not in ("0", "1"):
         return "cavoid::env_relay_kernel<%d> (roles on the wavefronts of one workgroup per tile)" % N
     if tiles <= 1024 and pipe != "0":
         return "cavoid::env_pipe_kernel<%d, false> (two-wavefront pipeline per tile)" % N

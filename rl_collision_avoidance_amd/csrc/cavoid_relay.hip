@@ -11,7 +11,11 @@ int cavoid_launch_relay(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t 
     if (k.rvo_enabled || k.pool_size <= 0 || !io.obs || !io.actions || io.cont) return CAVOID_EUNSUPPORTED;
     const int64_t tiles = (e->W + k.wpw - 1) / k.wpw;
     // every tile's workgroup must be resident at once (256 CUs x 2 workgroups): beyond that the tiles run in rounds
+    // (measured with 1024 tiles, N = 4: 3.87 vs 2.50 us per step for the two-wavefront pipeline; 1366 tiles, N = 10: 25 vs 8.3)
     if (tiles > 512) return CAVOID_EUNSUPPORTED;
+    // wide rows make the observation wavefronts the limit (and N >= 9 spills): measured at 512 tiles, us per step, this kernel /
+    // env_pipe_kernel: N = 2 1.42 / 1.97, 3 1.53 / 2.33, 5 1.86 / 2.91, 6 3.11 / 3.29, 8 4.35 / 3.88, 10 8.85 / 4.80
+    if (e->cfg.max_agents > kRelayMaxAgents) return CAVOID_EUNSUPPORTED;
     const int row = io.obs_stride;
     const int tile_floats = (k.tile_rows * row + 3) & ~3;
     if (k.tile_rows < k.wpw * e->cfg.max_agents) return CAVOID_EUNSUPPORTED;   // one pass per step only
@@ -32,11 +36,9 @@ int cavoid_launch_relay(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t 
     }
     switch (e->cfg.max_agents) {
 #ifdef CAVOID_DEV_ONLY_N
-        CAVOID_RELAY_CASE(4) CAVOID_RELAY_CASE(10)
+        CAVOID_RELAY_CASE(4)
 #else
         CAVOID_RELAY_CASE(1) CAVOID_RELAY_CASE(2) CAVOID_RELAY_CASE(3) CAVOID_RELAY_CASE(4) CAVOID_RELAY_CASE(5) CAVOID_RELAY_CASE(6)
-        CAVOID_RELAY_CASE(7) CAVOID_RELAY_CASE(8) CAVOID_RELAY_CASE(9) CAVOID_RELAY_CASE(10) CAVOID_RELAY_CASE(11) CAVOID_RELAY_CASE(12)
-        CAVOID_RELAY_CASE(13) CAVOID_RELAY_CASE(14) CAVOID_RELAY_CASE(15) CAVOID_RELAY_CASE(16)
 #endif
         default: return CAVOID_EUNSUPPORTED;
     }

@@ -33,6 +33,7 @@
 
 namespace cavoid {
 
+constexpr int kRelayMaxAgents = 6;        // instantiated (and faster than the two-wavefront pipeline) up to this many agents per world
 constexpr int kRelayRing = 4;            // depth of the state / verdict rings (steps in flight between D, P and the consumers)
 constexpr int kRelayActRing = 64;        // action ring: steps
 constexpr int kRelayActAhead = 48;       // the loader runs at most this many steps ahead of D
