@@ -112,7 +112,7 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
     from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedA3CTrainer, FusedPolicy
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
-    per_graph = 4                                            # env steps per hipGraph replay (even)
+    per_graph = int(os.environ.get("CAVOID_STEPS_PER_GRAPH", "8"))   # env steps per hipGraph replay (even): one drain (a host sync) per replay
 
     def regime(fused: bool, train: bool, fused_trainer: bool = False):
         env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
