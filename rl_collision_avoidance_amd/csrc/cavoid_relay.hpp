@@ -476,15 +476,24 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             nb.flags[lane0] = r0.flags;
         }
         int loaded = 0;
-        auto load_actions = [&](int upto) {                 // steps [loaded, upto) -> ring, clamped like E4 does
-            for (int sidx = loaded; sidx < upto; ++sidx) {
-                int v = active ? io.actions[(int64_t)sidx * io.action_stride + a_idx0] : 0;
-                v = v < 0 ? 0 : (v >= c.num_actions ? c.num_actions - 1 : v);
-                actring[(sidx & (kRelayActRing - 1)) * 64 + lane0] = (unsigned char)v;
+        const int64_t a_safe = active ? a_idx0 : 0;        // (idle lanes read lane 0's actions: no branch around the loads)
+        auto load_actions = [&](int upto) {                 // steps [loaded, upto) -> ring, clamped like E4 does: the loads of up to
+            while (loaded < upto) {                         // eight steps are in flight together, then the eight bytes are written
+                int v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int sidx = loaded + q < upto ? loaded + q : upto - 1;
+                    v[q] = io.actions[(int64_t)sidx * io.action_stride + a_safe];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    int x = v[q] < 0 ? 0 : (v[q] >= c.num_actions ? c.num_actions - 1 : v[q]);
+                    if (loaded + q < upto) actring[((loaded + q) & (kRelayActRing - 1)) * 64 + lane0] = (unsigned char)x;
+                }
+                loaded = loaded + 8 < upto ? loaded + 8 : upto;
             }
-            loaded = upto;
         };
-        load_actions(n_steps < kRelayActAhead ? n_steps : kRelayActAhead);
+        load_actions(n_steps < 8 ? n_steps : 8);            // enough for D to start; the rest follows while the loop runs
         __syncthreads();
         relay_post(&seq->act, loaded);
         int served = 0, idle_polls = 0;
