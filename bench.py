@@ -522,7 +522,7 @@ def main() -> None:
         # BASELINE configs[3] beside the headline: 10 agents (TrainPhase2 shape, 2..10 agents per world, M = 9) x 8192 worlds
         try:
             e3, a3 = make(8192, 10, gen_min_agents=2)
-            run_steps(e3, a3, 64)
+            run_steps(e3, a3, 256)                          # (past the first, synchronised wave of restarts)
             torch.cuda.synchronize(device)
             t3 = time.perf_counter()
             run_steps(e3, a3, 640)
