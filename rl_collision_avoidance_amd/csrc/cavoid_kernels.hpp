@@ -339,6 +339,24 @@ __device__ __forceinline__ double time_to_impact(double rx, double ry, double vx
     return (bb - sqrt(disc)) / aa;
 }
 
+// sqrt of a squared distance, bit for bit the device library's correctly rounded sqrt(double) for x = 0 and x >= 2^-767
+// (anything a sum of two squares of position differences can be): the library's iteration -- rsq seed, one coupled
+// Goldschmidt step, two residual corrections -- without its rescaling of tiny arguments (a compare, two ldexp and a select
+// per call; the pair pass calls it N-1 times per agent and step).  tests/test_gpu_parity.py holds the flags to the oracle's.
+__device__ __forceinline__ double sqrt_dist2(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;          // +-0 and +inf come back as they are (like the library)
+}
+
 // Others of host i, in ring order: o = 0..N-2  ->  agent j = (i + 1 + o) mod N.  Iterating the N-1
 // OTHERS (instead of all N agents with the host masked out) saves a sqrt and, with the symmetric
 // rank update below, three quarters of the key comparisons.
@@ -393,7 +411,7 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
         const int j = base + other_index(i, o, N);
         const float rjf = lds_r[j];
         const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
-        const double d = sqrt(rx * rx + ry * ry);
+        const double d = sqrt_dist2(rx * rx + ry * ry);
         const bool other = present && (rjf >= 0.0f);
         // unordered-pair gap d - (r_lo + r_hi): the sum is commutative, both ends agree bitwise
         const double gap_c = d - (ri + (double)rjf);

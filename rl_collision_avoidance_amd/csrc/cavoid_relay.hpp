@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 const int j = base + other_index(i, o, N);
                 const float rjf = tent->r[j];
                 const double rx = tent->px[j] - a.px, ry = tent->py[j] - a.py;
-                const double d = sqrt(rx * rx + ry * ry);
+                const double d = sqrt_dist2(rx * rx + ry * ry);
                 const bool other = present && (rjf >= 0.0f);
                 const double gap_c = d - (ri + (double)rjf);          // pair_pass: the unordered-pair gap
                 min_gap = other ? fmin(min_gap, gap_c) : min_gap;
