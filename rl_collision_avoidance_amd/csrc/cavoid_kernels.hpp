@@ -44,6 +44,10 @@ __device__ unsigned long long *g_trace = nullptr;
 #define CAVOID_STAMP(k) do { } while (0)
 #endif
 
+// branch-probability hint: the block is laid out behind the hot path (the step loop of the larger instantiations is tens of
+// KB of code, most of it rarely taken paths; the instruction cache is 64 KB per two CUs)
+#define CAVOID_RARE(x) __builtin_expect(!!(x), 0)
+
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kRelayMaxConsumers = 4;   // observation wavefronts per tile of env_relay_kernel (cavoid_relay.hpp)
 
@@ -109,7 +113,7 @@ struct KIO {
 __device__ __forceinline__ double wrap_angle(double a) {
     a = a >= kPi ? a - 2.0 * kPi : a;
     a = a < -kPi ? a + 2.0 * kPi : a;
-    if (__ballot(a >= kPi || a < -kPi) != 0ull) {
+    if (CAVOID_RARE(__ballot(a >= kPi || a < -kPi) != 0ull)) {
         while (a >= kPi) a -= 2.0 * kPi;
         while (a < -kPi) a += 2.0 * kPi;
     }
@@ -624,7 +628,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     // p, q in the same bucket: does p come first (smaller lateral offset, then smaller agent index)?
     auto tie_first = [&](int p, int q, bool tied) -> bool {
         bool first = false;
-        if (__ballot(tied) != 0ull) {
+        if (CAVOID_RARE(__ballot(tied) != 0ull)) {
             const double lp = lateral(p), lq = lateral(q);
             const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
             first = (lp < lq) || (lp == lq && idx_lt);
@@ -650,7 +654,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         }
         generic = __ballot(tie) != 0ull;                        // wave-uniform: redo this tile's ranks the exact way
     }
-    if (generic) {
+    if (CAVOID_RARE(generic)) {
         int gpos[K];
 #pragma unroll
         for (int o = 0; o < K; ++o) gpos[o] = 0;
@@ -692,7 +696,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     for (int o = 0; o < NO; ++o) keep |= (((valid >> o) & 1u) && pos.get(o) >= first) ? (1u << o) : 0u;
     // pos - first IS the slot (closest_last / time_to_impact); subtracted at the use
     int slot_bias = first;
-    if (c.sort_method == CAVOID_SORT_CLOSEST_FIRST) {      // kept set re-ranked near -> far; full ties keep index order
+    if (CAVOID_RARE(c.sort_method == CAVOID_SORT_CLOSEST_FIRST)) {      // kept set re-ranked near -> far; full ties keep index order
         slot_bias = 0;
         Key k2[K];
 #pragma unroll
@@ -1134,7 +1138,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
             a0 = (double)a.pref * lds_tab[2 * act];
             a1 = lds_tab[2 * act + 1];
         }
-        if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {   // scripted agents in this tile
+        if (CAVOID_RARE(__ballot(present_in && !done_in && pol != 0u) != 0ull)) {   // scripted agents in this tile
             if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
             if (pol == 2u) {                                            // straight at the goal, full speed
                 const Ego e0 = ego_frame_exact(a);
@@ -1142,7 +1146,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
                 a1 = -e0.heading_ego;
             }
         }
-        if (RVO && __ballot(present_in && !done_in && pol == 3u) != 0ull) {   // RVO agents in this tile
+        if (RVO && CAVOID_RARE(__ballot(present_in && !done_in && pol == 3u) != 0ull)) {   // RVO agents in this tile
             // stage the PRE-move state of every agent: position, last velocity (speed along the heading), radius
             double sn, cs;
             sincos_bounded(a.heading, &sn, &cs);
@@ -1160,14 +1164,14 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
         const bool moving = present_in && !done_in;
         moved_any = moved_any || moving;
         double npx, npy, nh, nvx, nvy, nsp;
-        if (c.dynamics == CAVOID_DYN_HOLONOMIC) {
+        if (CAVOID_RARE(c.dynamics == CAVOID_DYN_HOLONOMIC)) {
             nsp = sqrt(a0 * a0 + a1 * a1);
             nh = nsp > 0.0 ? atan2(a1, a0) : a.heading;
             npx = a.px + a0 * c.dt; npy = a.py + a1 * c.dt;
             nvx = a0; nvy = a1;
         } else {
             double dh = a1;
-            if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
+            if (CAVOID_RARE(c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN)) {
                 const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
                 dh = rate * c.dt;
             }
@@ -1236,7 +1240,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
         }
         if (kAuto) {
             const bool restart = active && game_over;
-            if (__ballot(restart) != 0ull) {               // wave-uniform: some world of this tile restarts
+            if (CAVOID_RARE(__ballot(restart) != 0ull)) {               // wave-uniform: some world of this tile restarts
                 wave_lds_sync();                           // every lane is done reading the old positions
                 if (restart) {
                     episode += 1u;
@@ -1399,7 +1403,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 act = act < 0 ? 0 : (act >= c.num_actions ? c.num_actions - 1 : act);
                 a0 = (double)a.pref * lds_tab[2 * act];
                 a1 = lds_tab[2 * act + 1];
-                if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {   // scripted agents in this tile
+                if (CAVOID_RARE(__ballot(present_in && !done_in && pol != 0u) != 0ull)) {   // scripted agents in this tile
                     if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
                     if (pol == 2u) {
                         const Ego e0 = ego_frame_exact(a);
@@ -1424,7 +1428,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 const bool moving = present_in && !done_in;
                 moved_any = moved_any || moving;
                 double dh = a1;
-                if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
+                if (CAVOID_RARE(c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN)) {
                     const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
                     dh = rate * c.dt;
                 }
