@@ -34,5 +34,6 @@ PY
 done
 timeout 1500 python bench.py --sweep --full-loop > $out/${tag}_bench.json 2>> $out/errors.txt
 timeout 900 python bench.py --agents 10 --sweep --no-full-loop > $out/${tag}_bench_n10.json 2>> $out/errors.txt
+timeout 300 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_k20.json 2>> $out/errors.txt   # the driver's command line
 ls -la $out; cat $out/errors.txt 2>/dev/null | tail -5
 head -c 1500 $out/${tag}_kernel_trace_stats.csv; head -c 900 $out/${tag}_pmc_traffic_n4_w8192.json
