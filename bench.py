@@ -9,11 +9,20 @@ observation, in-kernel restart of finished worlds) over one batch of synthetic w
 configs[1], 4 agents x 8192 worlds per GPU, unicycle dynamics, random actions pre-generated on the
 device.  The K timed steps go through `cavoid_step_autoreset_n`: launches of up to --slices steps, the
 world state staying in registers between the steps of a launch; EVERY step reads its action slice and
-writes its observations, rewards, done flags and game_over.  Weak scaling: every rank steps its own
-8192 worlds (RNG keyed on global world ids); no data-path collective in the headline region (for N>1
-the packed (obs|reward|done) all-gather of configs[2] -- `cavoid_gather_*`, RCCL -- is timed afterwards
-and reported under "extra").  `python bench.py --gpus N` without a launcher starts its own N ranks
+writes its observations, rewards, done flags and game_over INTO ITS OWN OUTPUT SLOT ([K, W, N, .] tensors:
+every step's outputs are there to be read afterwards -- what a rollout consumes, ProcessAgent.py:149-157).
+N = 1: no collective.  N > 1 (BASELINE configs[2]: W x N worlds sharded over the GPUs "with a RCCL all-gather of
+obs"): every launch writes packed (obs|reward|done) records and their all-gather to every rank
+(`cavoid_gather*`, RCCL over xGMI, on its own stream, overlapped with the next launch) is INSIDE the timed
+region; the shard-only rate is reported under "extra".  Weak scaling: every rank steps its own 8192 worlds
+(RNG keyed on global world ids).  `python bench.py --gpus N` without a launcher starts its own N ranks
 (torch.distributed.run, 127.0.0.1).  Rank 0 prints ONE JSON line.
+
+roofline: `achieved` / `frac` are priced on the bytes the timed launch form really moves per agent-step (K-step
+launch: action in, observation row + reward + done (+ game_over) out; the world state stays in registers), `traffic`
+is the PMC measurement of the same launches, `frac_contract` keeps SURVEY section 8d's 192 / 360 B figure (which
+includes a state round trip a K-step launch does not make), and `one_step_launch` is the same set of figures for the
+closed-loop form (one step per launch: state in and out every step).
 """
 from __future__ import annotations
 
@@ -31,9 +40,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md);
 
 
 def algorithmic_bytes_per_agent_step(M: int) -> int:
-    """fp32 words -- state read 11 + action 1 + state write 7 + obs (2+4+7M)
+    """SURVEY.md section 8(d), the contract figure: fp32 words -- state read 11 + action 1 + state write 7 + obs (2+4+7M)
     + reward 1 + done 1.  192 B at M=3, 360 B at M=9."""
     return 4 * (11 + 1 + 7 + (6 + 7 * M) + 1 + 1)
+
+
+def moved_bytes_per_agent_step(M: int, N: int, one_step: bool) -> float:
+    """Bytes a launch really has to move per agent-step.  K-step launch (state in registers): action
+    4 in; obs row 4(6+7M) + reward 4 + done 1 + game_over 1/N out -- 117.25 B at N=4, 285.1 B at N=10.  One step per launch
+    adds the state round trip of the float64 world buffer: read px,py,heading,t (32) + gx,gy,radius,pref (16) + flags 4 +
+    episode 4/N, write px,py,heading,t (32) + speed 4 + flags 4 -- 210.25 B at N=4."""
+    step = 4 + 4 * (6 + 7 * M) + 4 + 1 + 1.0 / N
+    return step + (32 + 16 + 4 + 4.0 / N + 32 + 4 + 4 if one_step else 0.0)
 
 
 def cpu_baseline(N: int, W: int, budget_s: float, pool_size: int):
@@ -178,11 +196,10 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         torch_us = timed(lambda: net.predict_p_and_v(obs.contiguous()), 30)
         lens = obs[:, 0].clamp(0, M)
         # The inference kernel computes the float32 GEMMs by error-free bf16 splitting (csrc/cavoid_policy_split.hpp): every
-        # float32 product is five bf16 partial products accumulated in float32.  Two figures:
-        #  * f32-equivalent: the float32 work of the graph as the float32-MFMA kernel would issue it (16-wide K chunks x 256
-        #    columns; LSTM step 0 needs the input chunk only; a 64-row tile runs as many LSTM steps as its longest row
-        #    needs), against the float32-MFMA peak the same arithmetic would otherwise be bound by;
-        #  * issued: the bf16 MFMA work really issued (32-wide K chunks x 5 partial products), against the dense bf16 peak.
+        # float32 product is five bf16 partial products accumulated in float32.  Reported: the bf16 MFMA work really issued
+        # (32-wide K chunks x 5 partial products; LSTM step 0 needs the input chunk only; a 64-row tile runs as many LSTM
+        # steps as its longest row needs) against the dense bf16 peak -- or, with CAVOID_POLICY_F32=1, the float32-MFMA kernel's
+        # issued work against the float32-MFMA peak.
         steps = lens.view(-1, 64).max(dim=1).values.mean().item() if (W * N) % 64 == 0 else float(M)
         chunks = (1 + 5 * max(steps - 1, 0)) + 5 + 16 + 16 + 1
         flop = W * N * chunks * 16 * 256 * 2
@@ -190,9 +207,7 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         chunks32 = (1 + 3 * max(steps - 1, 0)) + 3 + 8 + 8
         flop_bf16 = W * N * 5 * 32 * 2 * (chunks32 * 256 + 8 * 16)
         env.close()
-        out = {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us,
-               "f32_equivalent_TFLOPs": flop / fused_us * 1e-6, "f32_mfma_peak_TFLOPs": 157.3,
-               "f32_equivalent_frac_of_f32_mfma_peak": flop / fused_us * 1e-6 / 157.3}
+        out = {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us}
         if split:
             out.update({"issued_TFLOPs": flop_bf16 / fused_us * 1e-6, "peak_TFLOPs": 2500.0, "frac": flop_bf16 / fused_us * 1e-6 / 2500.0,
                         "bound": "mfma", "dtype": "f32 in/out; bf16 x 5 error-free split products, f32 accumulate",
@@ -255,20 +270,25 @@ def pmc_child(args) -> None:
         def __init__(self):
             self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
             EnvConfig.__init__(self)
-    env = BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=7)
+    over = {"gen_min_agents": args.min_agents} if args.min_agents else {}
+    env = BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=7, **over)
     g = torch.Generator(device="cuda").manual_seed(1234)
     acts = torch.randint(0, env.num_actions, (args.slices, W, N), generator=g, device="cuda", dtype=torch.int32)
     env.reset()
+    slots = env.new_step_slots(args.slices) if args.slices > 1 else None
     done = 0
     while done < args.warmup + args.steps:
         n = min(args.slices, args.warmup + args.steps - done)
-        env.step_autoreset_n(acts, n)
+        if args.slices > 1:
+            env.step_autoreset_n(acts, n, slots=slots)
+        else:
+            env.step_autoreset(acts[0])
         done += n
     torch.cuda.synchronize()
     env.close()
 
 
-def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 150.0):
+def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 150.0, min_agents: int = 0):
     """HBM bytes per launch of the step kernel from the PMC counters, collected live: one `rocprofv3 --pmc` pass per
     counter (FETCH_SIZE and WRITE_SIZE do not fit one pass; only --kernel-trace beside --pmc) around a child that
     repeats this bench's launch pattern.  Counters are KiB; gfx950 tallies 128-B read requests as 64 B, so FETCH_SIZE
@@ -287,7 +307,7 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
         d = tempfile.mkdtemp(prefix="cavoid_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.abspath(__file__), "--pmc-child", "--agents", str(N), "--worlds", str(W), "--slices", str(slices),
-               "--steps", str(steps), "--warmup", str(slices)]
+               "--steps", str(steps), "--warmup", str(slices), "--min-agents", str(min_agents)]
         try:
             subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -344,6 +364,9 @@ def main() -> None:
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch / rendezvous / collective check of the N>1 path without touching a GPU (CPU boxes, gloo)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--min-agents", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--overwrite-outputs", action="store_true",
+                    help="round-2 form: every step of a launch overwrites ONE output slot (only the last step's outputs survive)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
@@ -410,34 +433,98 @@ def main() -> None:
         env.reset()
         return env, acts
 
-    def run_steps(env, acts, k):
-        """k auto-reset steps in launches of up to T = --slices steps (step t of a launch reads acts[t])."""
+    def run_steps(env, acts, k, slots=None):
+        """k auto-reset steps in launches of up to T = --slices steps (step t of a launch reads acts[t] and, with `slots`,
+        writes its outputs into slot t)."""
         T = acts.shape[0]
         done = 0
         while done < k:
             n = min(T, k - done)
-            env.step_autoreset_n(acts, n)
+            env.step_autoreset_n(acts, n, slots=slots)
             done += n
 
-    def kernel_figures(env, acts, n_agents, Wl, k):
-        """per-launch HIP-event durations of the step kernel, in launches shaped like the timed region's"""
+    def form_figures(name, n_agents, Wl, spl, launch_ms, one_step):
+        """roofline figures of one launch form: priced on the bytes it really moves, the contract figure beside it"""
+        M = n_agents - 1
+        moved = moved_bytes_per_agent_step(M, n_agents, one_step) * Wl * n_agents * spl
+        contract = algorithmic_bytes_per_agent_step(M) * Wl * n_agents * spl
+        achieved = moved / (launch_ms * 1e-3) / 1e9
+        return {"kernel": name, "steps_per_launch": spl, "kernel_us": launch_ms * 1e3, "kernel_us_per_step": launch_ms * 1e3 / spl,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "moved_bytes_per_agent_step": moved_bytes_per_agent_step(M, n_agents, one_step), "moved_bytes_per_launch": moved,
+                "frac_contract": contract / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "contract_bytes_per_agent_step": algorithmic_bytes_per_agent_step(M), "traffic": None}
+
+    def bound_of(fig, Wl, n_agents):
+        """what the evidence says limits the kernel: HBM only when the measured traffic really is most of the pipe"""
+        real = fig["traffic"] if fig.get("traffic") else fig["moved_bytes_per_launch"]
+        if real / (fig["kernel_us"] * 1e-6) / 1e9 >= 0.5 * HBM_PEAK_GBS:
+            return "hbm"
+        # <= 2 wavefronts per SIMD: the step is ONE wavefront's dependent float64 chain; beyond that the VALU issue rate
+        return "latency" if Wl * n_agents <= 131072 else "valu-issue"
+
+    def kernel_figures(env, acts, n_agents, Wl, k, slots=None):
+        """per-launch HIP-event durations of the step kernel, in launches shaped like the timed region's, + the one-step form"""
         spl = min(acts.shape[0], k)
-        launch_ms = env.kernel_time_ms(acts, max(k, spl), spl)
-        bytes_per_launch = algorithmic_bytes_per_agent_step(n_agents - 1) * Wl * n_agents * spl
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": step_kernel_name(n_agents, Wl, spl),
-                "steps_per_launch": spl, "kernel_us": launch_ms * 1e3, "kernel_us_per_step": launch_ms * 1e3 / spl,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(n_agents - 1)}
+        launch_ms = env.kernel_time_ms(acts, max(k, spl), spl, slots=slots)
+        fig = form_figures(step_kernel_name(n_agents, Wl, spl), n_agents, Wl, spl, launch_ms, one_step=(spl == 1))
+        fig["outputs"] = "per-step slots [K,W,N,.]" if slots is not None else "one slot, overwritten by every step"
+        single_ms = env.kernel_time_ms(acts, min(max(k, 64), 256), 1)          # the closed-loop form: one step per launch
+        fig["one_step_launch"] = form_figures(step_kernel_name(n_agents, Wl, 1), n_agents, Wl, 1, single_ms, one_step=True)
+        return fig
+
+    def add_traffic(fig, n_agents, Wl, min_agents=0):
+        """PMC traffic of both forms, live (rocprofv3 --pmc passes around a child that repeats the launch pattern)"""
+        for form, slices in ((fig, fig["steps_per_launch"]), (fig["one_step_launch"], 1)):
+            try:
+                pmc = measure_traffic(n_agents, Wl, slices, max(slices * 4, 128), min_agents=min_agents)
+            except Exception:      # noqa: BLE001 -- measurement aid only
+                pmc = None
+            if pmc is not None:
+                form["traffic"] = pmc["traffic"]
+                form["traffic_over_moved"] = pmc["traffic"] / form["moved_bytes_per_launch"]
+                form["traffic_GBps"] = pmc["traffic"] / (form["kernel_us"] * 1e-6) / 1e9
+                form["traffic_source"] = pmc
+            form["bound"] = bound_of(form, Wl, n_agents)
 
     env, acts = make(W)
-    run_steps(env, acts, args.warmup)
+    gather_in_metric = world_size > 1 and not args.no_gather
+    slots = None if (args.overwrite_outputs or gather_in_metric) else env.new_step_slots(min(args.slices, max(args.steps, 1)))
+    sh = None
+    if gather_in_metric:
+        # configs[2]: this rank's shard of a (world_size x W)-world env; every launch writes packed records into per-step slots
+        # and their gather to every rank is begun on the communicator's stream -- launch t+1 runs while gather t is on the wire.
+        # nccl: cavoid_gather* (RCCL); gloo dry run (CPU tests / --share-device): the same records through torch.distributed.
+        from rl_collision_avoidance_amd.sharding import ShardedEnv
+        env.close()
+        sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7)
+        sh.reset()
+        env = sh.env
+        native = args.backend == "nccl"
+        # launches of `spl` steps: the largest divisor of K that fits the action slices, so that K steps are whole launches
+        spl = max(d for d in range(1, min(args.slices, args.steps) + 1) if args.steps % d == 0)
+        acts_l = acts[:spl].contiguous()
+        gslots = None if native else env.new_step_slots(spl, packed=True)
+
+        def run_steps_gather(k):
+            for _ in range(-(-k // spl)):
+                if native:
+                    sh.gathered(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))
+                else:
+                    from rl_collision_avoidance_amd.sharding import gather_step_outputs
+                    env.step_autoreset_packed(acts_l, gslots)
+                    gather_step_outputs(gslots.packed.transpose(0, 1).contiguous(), world_size * W)
+        run_steps_gather(args.warmup)
+    else:
+        run_steps(env, acts, args.warmup, slots)
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks -------
     sync_all()
     t0 = time.perf_counter()
-    run_steps(env, acts, args.steps)
+    if gather_in_metric:
+        run_steps_gather(args.steps)
+    else:
+        run_steps(env, acts, args.steps, slots)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
@@ -448,92 +535,59 @@ def main() -> None:
     value = world_size * W * N * args.steps / elapsed
 
     # ---- roofline of the dominant (only) kernel ------------------------------------------------------
-    roofline = kernel_figures(env, acts, N, W, args.steps)
-    single = env.kernel_time_ms(acts, min(args.steps, 256), 1)          # the closed-loop form: one step per launch
-    roofline["single_step_launch_us"] = single * 1e3
-    roofline["single_step_launch_frac"] = algorithmic_bytes_per_agent_step(N - 1) * W * N / (single * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if slots is None and not args.overwrite_outputs:
+        slots = env.new_step_slots(min(args.slices, max(args.steps, 1)))
+    roofline = kernel_figures(env, acts, N, W, args.steps, slots)
 
     extra = {}
-    if world_size > 1 and not args.no_gather:
-        # BASELINE configs[2]: the one real exchange of the path -- the packed (obs | reward | done) record of every world
-        # back to every rank, ONE all-gather per step.  nccl: the kernel writes the packed record and cavoid_gather_* issues
-        # ncclAllGather on the communicator's own stream, gather(t) overlapping step(t+1).  gloo dry run: torch.distributed.
-        # Timed OUTSIDE the headline region; a failure here must not cost the headline number.
+    if gather_in_metric:
+        # the same K steps WITHOUT the gather (every rank its own shard, per-step slots, a barrier only): what the exchange costs
         try:
-            from rl_collision_avoidance_amd.sharding import ShardedEnv
-            sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7)
-            sh.reset()
-            native = args.backend == "nccl"
-
-            def one(t):
-                if native:
-                    sh.gathered(sh.step_and_gather(acts[t % acts.shape[0]]))
-                else:
-                    sh.step_autoreset(acts[t % acts.shape[0]])
-                    sh.gather()
-            n_g = 200 if native else 10
-            for t in range(20 if native else 2):
-                one(t)
+            run_steps(env, acts, min(args.warmup, 64), slots)
             sync_all()
             tg = time.perf_counter()
-            for t in range(n_g):
-                one(t)
+            run_steps(env, acts, args.steps, slots)
             sync_all()
-            t_both = (time.perf_counter() - tg) / n_g
-            tg = time.perf_counter()
-            for t in range(n_g):
-                sh.step_autoreset_packed(acts[t % acts.shape[0]], sh._send[0]) if native else sh.step_autoreset(acts[t % acts.shape[0]])
-            sync_all()
-            t_step = (time.perf_counter() - tg) / n_g
-            extra["allgather"] = {"path": "cavoid_gather_* (ncclAllGather, own stream, double-buffered)" if native else "torch.distributed (gloo dry run)",
-                                  "ms_per_step_with_gather": t_both * 1e3, "ms_per_single_step_launch_alone": t_step * 1e3,
-                                  "pack_cost_ms": 0.0 if native else None,
-                                  "bytes_per_rank": W * N * (env.obs_width + 2) * 4,
-                                  "bytes_received_per_rank": world_size * W * N * (env.obs_width + 2) * 4,
-                                  "agent_steps_per_s_with_gather": world_size * W * N / t_both}
-            sh.close()
+            t_shard = time.perf_counter() - tg
+            rec = W * N * (env.obs_width + 2) * 4
+            extra["configs2_gather"] = {
+                "path": ("cavoid_gather* (RCCL over xGMI, own stream, double-buffered; %s)" % ("ncclAllGather" if spl == 1 else "point-to-point gather of K-step blocks"))
+                        if args.backend == "nccl" else "torch.distributed (gloo dry run)",
+                "steps_per_launch": spl, "bytes_sent_per_rank_per_step": rec, "bytes_received_per_rank_per_step": (world_size - 1) * rec,
+                "agent_steps_per_s_with_gather": value, "ms_per_step_with_gather": ms_per_step,
+                "agent_steps_per_s_shard_only": world_size * W * N * args.steps / t_shard, "ms_per_step_shard_only": t_shard * 1e3 / args.steps,
+                "note": "value = the with-gather rate (BASELINE configs[2]); no multi-GPU scaling curve has been measured by the builder "
+                        "(1-GPU boxes only): the driver's run is the first execution across devices"}
         except Exception as exc:      # noqa: BLE001 -- report, never lose the headline
-            extra["allgather"] = {"error": repr(exc)}
+            extra["configs2_gather"] = {"error": repr(exc)}
 
     if rank == 0 and world_size == 1 and not args.no_pmc:
-        try:
-            pmc = measure_traffic(N, W, args.slices, max(args.slices * 4, 256))
-            if pmc is not None:
-                # the PMC child's launches are `slices` steps long; scale to this run's launch length
-                per_step = pmc["traffic"] / pmc["steps_per_launch"]
-                roofline["traffic"] = per_step * roofline["steps_per_launch"]
-                roofline["traffic_source"] = pmc
-        except Exception:      # noqa: BLE001
-            pass
-    if roofline["traffic"] is None:
-        # fall back to the committed summary of a PMC run of this command (same kernel and shape), naming it
-        try:
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_traffic*.json")), reverse=True):
-                pmc = json.load(open(path))
-                if pmc.get("worlds") == W and pmc.get("agents") == N and "traffic_bytes_per_step" in pmc:
-                    roofline["traffic"] = pmc["traffic_bytes_per_step"] * roofline["steps_per_launch"]
-                    roofline["traffic_source"] = os.path.relpath(path, ROOT)
-                    break
-        except Exception:      # noqa: BLE001
-            pass
+        add_traffic(roofline, N, W)
+    for form in (roofline, roofline["one_step_launch"]):
+        form.setdefault("bound", bound_of(form, W, N))
+    roofline["bound_note"] = ("latency = the dependent float64 chain of the wavefront(s) that own a tile (<= 2 wavefronts per SIMD at this "
+                              "batch size); valu-issue = vector issue rate at saturation; hbm only when the measured traffic exceeds half "
+                              "the 8 TB/s pipe.  `frac` is still the HBM-roofline fraction the contract asks for.")
 
     if rank == 0 and not args.no_configs3 and N != 10:
         # BASELINE configs[3] beside the headline: 10 agents (TrainPhase2 shape, 2..10 agents per world, M = 9) x 8192 worlds
         try:
             e3, a3 = make(8192, 10, gen_min_agents=2)
-            run_steps(e3, a3, 256)                          # (past the first, synchronised wave of restarts)
+            s3 = None if args.overwrite_outputs else e3.new_step_slots(a3.shape[0])
+            run_steps(e3, a3, 256, s3)                      # (past the first, synchronised wave of restarts)
             torch.cuda.synchronize(device)
             t3 = time.perf_counter()
-            run_steps(e3, a3, 640)
+            run_steps(e3, a3, 640, s3)
             torch.cuda.synchronize(device)
             dt3 = time.perf_counter() - t3
-            r3 = kernel_figures(e3, a3, 10, 8192, 640)
-            s3 = e3.kernel_time_ms(a3, 128, 1)
-            c3 = {"workload": "BASELINE configs[3]: 10 agents (2..10 present) x 8192 worlds, M = 9, obs width 69",
-                  "value": 8192 * 10 * 640 / dt3, "unit": "agent-steps/s", "ms_per_step": dt3 * 1e3 / 640, "roofline": r3,
-                  "single_step_launch_us": s3 * 1e3,
-                  "single_step_launch_frac": 360 * 81920 / (s3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            r3 = kernel_figures(e3, a3, 10, 8192, 640, s3)
+            if world_size == 1 and not args.no_pmc:
+                add_traffic(r3, 10, 8192, min_agents=2)
+            for form in (r3, r3["one_step_launch"]):
+                form.setdefault("bound", bound_of(form, 8192, 10))
+            c3 = {"workload": "BASELINE configs[3]: 10 agents (2..10 present) x 8192 worlds, M = 9, obs width 69; per-step output slots",
+                  "value": 8192 * 10 * 640 / dt3, "unit": "agent-steps/s", "ms_per_step": dt3 * 1e3 / 640, "roofline": r3}
+            del s3
             if not args.no_cpu_baseline:
                 c3["cpu_baseline"] = cpu_baseline(10, 2048, min(3.0, args.cpu_seconds), int(e3.cfg.gen_pool_size))
             extra["configs3_n10"] = c3
@@ -547,8 +601,10 @@ def main() -> None:
         # episode) scenarios) -- the pool only moves scenario generation (E2) off the step's critical path
         try:
             e0, a0 = make(W, N, gen_pool_size=0)
-            run_steps(e0, a0, 128)
-            extra["no_scenario_pool"] = kernel_figures(e0, a0, N, W, 256)
+            s0 = None if args.overwrite_outputs else e0.new_step_slots(a0.shape[0])
+            run_steps(e0, a0, 128, s0)
+            extra["no_scenario_pool"] = kernel_figures(e0, a0, N, W, 256, s0)
+            del s0
             e0.close()
         except Exception as exc:      # noqa: BLE001
             extra["no_scenario_pool"] = {"error": repr(exc)}
@@ -565,18 +621,21 @@ def main() -> None:
 
     if args.sweep and rank == 0:
         sweep = []
-        for Ws in (1024, 8192, 65536, 262144, 1048576, 4194304):
+        for Ws in (1024, 8192, 65536, 262144, 1048576):
             e2, a2 = make(Ws)
-            run_steps(e2, a2, 64)
-            f = kernel_figures(e2, a2, N, Ws, 128)
-            k1 = e2.kernel_time_ms(a2, 64, 1)
+            spl2 = min(a2.shape[0], max(1, (1 << 30) // (Ws * N * (e2.obs_width + 2) * 4)))     # <= 1 GiB of output slots
+            a2 = a2[:spl2].contiguous()
+            s2 = None if args.overwrite_outputs else e2.new_step_slots(spl2)
+            run_steps(e2, a2, spl2, s2)
+            f = kernel_figures(e2, a2, N, Ws, 2 * spl2, s2)
             torch.cuda.synchronize(device)
+            one = f["one_step_launch"]
             sweep.append({"worlds": Ws, "kernel_us_per_step": f["kernel_us_per_step"], "steps_per_launch": f["steps_per_launch"],
                           "agent_steps_per_s": Ws * N / (f["kernel_us_per_step"] * 1e-6), "GBps": f["achieved"], "frac": f["frac"],
-                          "single_step_launch_us": k1 * 1e3,
-                          "single_step_launch_frac": algorithmic_bytes_per_agent_step(N - 1) * Ws * N / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                          "frac_contract": f["frac_contract"], "one_step_launch_us": one["kernel_us"], "one_step_launch_frac": one["frac"],
+                          "one_step_launch_frac_contract": one["frac_contract"]})
             e2.close()
-            del e2, a2
+            del e2, a2, s2
         extra["saturation_sweep"] = sweep
 
     which = {4: "configs[1]", 10: "configs[3]"}.get(N, "configs[1]-style")
@@ -587,10 +646,14 @@ def main() -> None:
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE %s: %d agents x %d worlds per GPU, unicycle dynamics, GEN v1 synthetic scenarios, "
                                "uniform random actions pre-staged on the device, in-kernel auto-reset; launches of up to %d steps "
-                               "(world state in registers between the steps of a launch, every step's outputs written)"
-                               % (which, N, W, args.slices),
+                               "(world state in registers between the steps of a launch); %s%s"
+                               % (which, N, W, args.slices,
+                                  "every step overwrites one output slot" if args.overwrite_outputs else
+                                  "every step's obs / reward / done / game_over written into its own output slot [K,W,N,.]",
+                                  "; + all-gather of the packed records to every rank inside the timed region (configs[2])" if gather_in_metric else ""),
                    "worlds_per_gpu": W, "agents_per_world": N, "obs_width": env.obs_width, "steps_per_launch": min(args.slices, args.steps),
-                   "parallelism": "worlds sharded over %d GPU(s), no data-path collective" % world_size},
+                   "parallelism": ("worlds sharded over %d GPU(s), one gather of (obs|reward|done) per launch (RCCL over xGMI)" % world_size)
+                                  if gather_in_metric else ("worlds sharded over %d GPU(s), no data-path collective" % world_size)},
         "roofline": roofline,
     }
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
@@ -603,7 +666,10 @@ def main() -> None:
             extra["cpu_baseline_all_cores"] = {"error": repr(exc)}
     if extra:
         line["extra"] = extra
-    env.close()
+    if sh is not None:
+        sh.close()
+    else:
+        env.close()
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define CAVOID_ABI_VERSION 2
+#define CAVOID_ABI_VERSION 3
 #define CAVOID_MAX_ACTIONS 32
 #define CAVOID_MAX_AGENTS 16
 
@@ -62,7 +62,11 @@ extern "C" {
 #define CAVOID_F_WAS_IN_COLL 0x10u
 #define CAVOID_F_PRESENT 0x20u
 #define CAVOID_F_LEARNING 0x40u
-#define CAVOID_F_POLICY_SHIFT 8 /* bits 8..9: 0 external (learning), 1 static, 2 non-cooperative, 3 RVO (ORCA) */
+#define CAVOID_F_POLICY_SHIFT 8 /* bits 8..10: 0 external (learning), 1 static, 2 non-cooperative, 3 RVO (ORCA),
+                                   4 frozen network: a NON-learning agent whose action index the caller supplies like a learner's
+                                   (from a second, frozen NetworkVP_rnn -- the GA3C-CADRL agent, ga3c/GA3C/Server.py:36) */
+#define CAVOID_F_POLICY_MASK 7u
+enum { CAVOID_POLICY_EXTERNAL = 0, CAVOID_POLICY_STATIC = 1, CAVOID_POLICY_NONCOOP = 2, CAVOID_POLICY_RVO = 3, CAVOID_POLICY_FROZEN_NET = 4 };
 #define CAVOID_F_DONE_MASK 0x07u
 
 enum { CAVOID_SORT_CLOSEST_LAST = 0, CAVOID_SORT_CLOSEST_FIRST = 1, CAVOID_SORT_TIME_TO_IMPACT = 2 };
@@ -92,6 +96,12 @@ typedef struct cavoid_cfg {
     int32_t time_budget_from_goal_edge; /* U11: 1 (default): an agent's time budget is MAX_TIME_RATIO * (dist_to_goal -
                                    NEAR_GOAL_THRESHOLD) / pref_speed (upstream agent.py as recalled); 0: SURVEY App. A's
                                    MAX_TIME_RATIO * dist_to_goal / pref_speed.  Either way at least one DT. */
+    int32_t wrap_closed_end;   /* U2: 0 (default) angles wrap to [-pi, pi); 1: to (-pi, pi] */
+    int32_t done_agents_collide; /* U4: 1 (default) an agent that is already done (frozen) still takes part in the others' collision
+                                   test and nearest gap; 0: a pair with an agent that was done before the step is skipped */
+    int32_t sort_round_gap;    /* U7a: 1 (default) neighbours are ordered by the gap rounded to centimetres; 0: by the exact gap */
+    int32_t sort_tie_lateral;  /* U7b: 1 (default) equal (rounded) gaps are ordered by the lateral offset p_orth, then agent index;
+                                   0: by agent index alone (a stable sort on the gap) */
     int32_t _pad0;
     double dt;                 /* DT 0.2 */
     double near_goal_threshold;/* 0.2 */
@@ -126,7 +136,9 @@ typedef struct cavoid_cfg {
     uint32_t gen_pool_epoch;      /* the pool holds generator worlds 0..P-1 of THIS episode index (cavoid_pool_refresh) */
     int32_t rvo_enabled;          /* agents with policy 3 may exist: the step kernels reserve the ORCA scratch (4 KiB of LDS per
                                      wavefront and neighbour; max_agents <= 15, else CAVOID_EUNSUPPORTED) */
-    double gen_rvo_fraction;      /* of the scripted agents: P(static) = gen_static_fraction, P(RVO) = this, the rest non-cooperative */
+    double gen_rvo_fraction;      /* of the scripted agents: P(static) = gen_static_fraction, P(RVO) = this, P(frozen network) =
+                                     gen_frozen_fraction, the rest non-cooperative */
+    double gen_frozen_fraction;   /* policy 4 agents (their actions come from the caller: cavoid_policy_rows lists them) */
     double gen_box_small[2], gen_box_large[2];   /* (4,5), (6,8) */
     double gen_min_trip;          /* 1.0 */
     /* RVO scripted policy: ORCA over the other agents' positions and last velocities */
@@ -176,12 +188,16 @@ int cavoid_step_continuous(cavoid_env *env, const float *actions /* [W,N,2] */, 
  * observation of the new episode (rewards/done/game_over still describe the finished step) */
 int cavoid_step_autoreset(cavoid_env *env, const int32_t *actions, float *obs, float *rewards, uint8_t *done,
                           uint8_t *game_over, void *stream);
-/* n_steps back-to-back autoreset steps in ONE launch; step t reads actions + t*action_stride
- * (int32 elements) and overwrites the same outputs (after the call they hold the LAST step's).  Worlds are
- * independent and a wavefront owns whole worlds, so the world state stays in registers between the steps: per
- * step only the action slice is read and the outputs are written; the world buffer is updated once.
- * Open-loop driver for benchmarks / scripted runs (a policy in the loop needs cavoid_step_autoreset). */
-int cavoid_step_autoreset_n(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+/* n_steps back-to-back autoreset steps in ONE launch; step t reads actions + t*action_stride (int32 elements) and
+ * writes its outputs into SLOT t: with S = out_step_stride (in WORLDS, >= num_worlds) the outputs are arrays
+ *   obs [n_steps, S, N, width], rewards / done [n_steps, S, N], game_over [n_steps, S]
+ * -- what ProcessAgent.run_episode consumes of EVERY step (rewards, which_agents_done, the next observation:
+ * ga3c/GA3C/ProcessAgent.py:149-157).  out_step_stride = 0: every step overwrites slot 0 (after the call the outputs hold
+ * the LAST step's).  Worlds are independent and a wavefront owns whole worlds, so the world state stays in registers
+ * between the steps: per step only the action slice is read and the outputs are written; the world buffer is updated
+ * once.  The actions are pre-staged (scripted / open-loop runs; a policy in the loop: cavoid_step_autoreset or
+ * cavoid_actor_run). */
+int cavoid_step_autoreset_n(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
                             float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream);
 
 /* ---- packed outputs: one record per agent, [W, N, cavoid_packed_width()] floats = (obs row | reward | done) ----
@@ -192,7 +208,8 @@ int32_t cavoid_packed_width(const cavoid_env *env);
 int cavoid_reset_packed(cavoid_env *env, const uint8_t *world_mask, float *packed, void *stream);
 int cavoid_observe_packed(cavoid_env *env, float *packed, void *stream);
 int cavoid_step_packed(cavoid_env *env, const int32_t *actions, float *packed, uint8_t *game_over, void *stream);
-int cavoid_step_autoreset_packed(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+/* packed [n_steps, S, N, width + 2] and game_over [n_steps, S] with S = out_step_stride worlds, or one slot when it is 0 */
+int cavoid_step_autoreset_packed(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
                                  float *packed, uint8_t *game_over, void *stream);
 
 /* ---- multi-GPU hand-over: ONE all-gather of every rank's packed shard (RCCL over xGMI) ------------------------------
@@ -213,6 +230,12 @@ int cavoid_comm_create(const void *unique_id, int32_t nranks, int32_t rank, int 
 void cavoid_comm_destroy(cavoid_comm *comm);
 int cavoid_gather_begin(cavoid_comm *comm, int32_t slot, const float *send, float *recv, int64_t floats_per_rank,
                         void *producer_stream);
+/* the same hand-over for RAGGED shards and / or to ONE rank: counts[r] (host array [nranks], identical on every rank) = floats of
+ * rank r's shard; recv [sum(counts)] holds the shards in rank order.  root < 0: every rank receives every shard; root >= 0:
+ * only that rank does (the trainer rank of the full GA3C loop; recv may be NULL on the others).  Point-to-point sends inside
+ * one RCCL group: on the fully connected xGMI mesh every shard travels over its own link (a direct gather, no padding). */
+int cavoid_gatherv_begin(cavoid_comm *comm, int32_t slot, const float *send, float *recv, const int64_t *counts, int32_t root,
+                         void *producer_stream);
 int cavoid_gather_wait(cavoid_comm *comm, int32_t slot, void *consumer_stream);
 int cavoid_last_comm_error(void);               /* raw ncclResult_t of the last CAVOID_ECOMM */
 
@@ -220,8 +243,13 @@ int cavoid_last_comm_error(void);               /* raw ncclResult_t of the last 
  * event pair (recorded with the dispatch, so launch gaps are excluded); synchronises and returns the MEAN duration
  * of a launch in milliseconds.  Measurement aid for bench.py's roofline figure. */
 int cavoid_step_autoreset_n_timed(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps,
-                                  int32_t steps_per_launch, float *obs, float *rewards, uint8_t *done, uint8_t *game_over,
-                                  void *stream, float *mean_launch_ms);
+                                  int32_t steps_per_launch, int64_t out_step_stride, float *obs, float *rewards, uint8_t *done,
+                                  uint8_t *game_over, void *stream, float *mean_launch_ms);
+
+/* the (world, agent) slots whose agent runs scripted policy `policy_id` (CAVOID_POLICY_*) and is present and, with
+ * only_running != 0, not done: row_index int32 [W*N] (unspecified order), row_count int32 [1], both on the device (feed them
+ * to cavoid_policy_forward_rows of the frozen network that drives CAVOID_POLICY_FROZEN_NET agents). */
+int cavoid_policy_rows(cavoid_env *env, int32_t policy_id, int32_t only_running, int32_t *row_index, int32_t *row_count, void *stream);
 
 /* ---- batched GA3C actor bookkeeping (rollout) -------------------------------------------------------
  * Stands in for one ProcessAgent per world: ProcessAgent.run_episode / _accumulate_rewards /

@@ -26,7 +26,8 @@ class OracleCfg(C.Structure):
         "rvo_time_horizon", "rvo_collab_coeff", "rvo_radius_scale", "rvo_max_delta_heading")] + [
         (n, C.c_int32) for n in ("max_agents", "max_other", "sort_method", "actions_fp32",
                                  "timeout_enabled", "dynamics", "num_actions", "evaluate_mode",
-                                 "time_budget_from_goal_edge", "_pad0")] + [
+                                 "time_budget_from_goal_edge", "wrap_closed_end", "done_agents_collide",
+                                 "sort_round_gap", "sort_tie_lateral", "_pad0")] + [
         ("actions", (C.c_double * 2) * MAX_ACTIONS)]
 
 
@@ -35,7 +36,7 @@ class OracleGen(C.Structure):
                 ("static_fraction", C.c_double), ("goal_jitter", C.c_double), ("angle_jitter", C.c_double),
                 ("pool_size", C.c_int32), ("mode", C.c_int32), ("rvo_fraction", C.c_double),
                 ("box_small", C.c_double * 2), ("box_large", C.c_double * 2), ("min_trip", C.c_double),
-                ("box_large_from", C.c_int32), ("pool_epoch", C.c_uint32)]
+                ("box_large_from", C.c_int32), ("pool_epoch", C.c_uint32), ("frozen_fraction", C.c_double)]
 
 
 class _State(C.Structure):
@@ -97,12 +98,12 @@ def set_actions(cfg: OracleCfg, table) -> None:
 def default_gen(min_agents: int = 4, max_agents: int = 4, nonlearning_fraction: float = 0.0,
                 static_fraction: float = 0.5, goal_jitter: float = 0.5, angle_jitter: float = 0.25,
                 pool_size: int = 0, mode: int = 0, rvo_fraction: float = 0.0, box_small=(4.0, 5.0), box_large=(6.0, 8.0),
-                box_large_from: int = 5, min_trip: float = 1.0, pool_epoch: int = 0) -> OracleGen:
+                box_large_from: int = 5, min_trip: float = 1.0, pool_epoch: int = 0, frozen_fraction: float = 0.0) -> OracleGen:
     g = OracleGen(min_agents, max_agents, nonlearning_fraction, static_fraction, goal_jitter, angle_jitter, pool_size, mode,
                   rvo_fraction)
     g.box_small[0], g.box_small[1] = box_small
     g.box_large[0], g.box_large[1] = box_large
-    g.min_trip, g.box_large_from, g.pool_epoch = min_trip, box_large_from, pool_epoch
+    g.min_trip, g.box_large_from, g.pool_epoch, g.frozen_fraction = min_trip, box_large_from, pool_epoch, frozen_fraction
     return g
 
 

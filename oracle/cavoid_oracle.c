@@ -26,7 +26,8 @@ enum {
     F_WAS_IN_COLL = 1u << 4, F_PRESENT = 1u << 5, F_LEARNING = 1u << 6, F_POLICY_SHIFT = 8
 };
 #define F_DONE_MASK (F_AT_GOAL | F_RAN_OUT | F_IN_COLL)
-enum { POLICY_EXTERNAL = 0, POLICY_STATIC = 1, POLICY_NONCOOP = 2, POLICY_RVO = 3 };
+enum { POLICY_EXTERNAL = 0, POLICY_STATIC = 1, POLICY_NONCOOP = 2, POLICY_RVO = 3, POLICY_FROZEN_NET = 4 };
+#define F_POLICY_MASK 7
 enum { SORT_CLOSEST_LAST = 0, SORT_CLOSEST_FIRST = 1, SORT_TTI = 2 };
 enum { DYN_UNICYCLE = 0, DYN_UNICYCLE_MAX_TURN = 1, DYN_HOLONOMIC = 2 };
 
@@ -44,6 +45,7 @@ void oracle_default_cfg(oracle_cfg *c, int32_t max_agents, int32_t max_other) {
     c->rvo_time_horizon = 5.0; c->rvo_collab_coeff = 0.5; c->rvo_radius_scale = 1.05; c->rvo_max_delta_heading = PI / 6;
     c->max_agents = max_agents; c->max_other = max_other; c->sort_method = SORT_CLOSEST_LAST;
     c->actions_fp32 = 1; c->timeout_enabled = 1; c->time_budget_from_goal_edge = 1; c->dynamics = DYN_UNICYCLE; c->num_actions = 11;
+    c->wrap_closed_end = 0; c->done_agents_collide = 1; c->sort_round_gap = 1; c->sort_tie_lateral = 1;   /* U2, U4, U7a, U7b */
     /* E4: 5 headings at full speed (step pi/12), 3 at half speed, 3 at zero speed (step pi/6) */
     const double fr[3] = {1.0, 0.5, 0.0}, st[3] = {PI / 12, PI / 6, PI / 6};
     const int cnt[3] = {5, 3, 3};
@@ -52,7 +54,13 @@ void oracle_default_cfg(oracle_cfg *c, int32_t max_agents, int32_t max_other) {
         for (int k = 0; k < cnt[g]; ++k, ++r) { c->actions[r][0] = fr[g]; c->actions[r][1] = -PI / 6 + k * st[g]; }
 }
 
-static double wrap(double a) {
+/* U2: [-pi, pi) by default, (-pi, pi] with wrap_closed_end */
+static double wrap(const oracle_cfg *c, double a) {
+    if (c->wrap_closed_end) {
+        while (a > PI) a -= 2.0 * PI;
+        while (a <= -PI) a += 2.0 * PI;
+        return a;
+    }
     while (a >= PI) a -= 2.0 * PI;
     while (a < -PI) a += 2.0 * PI;
     return a;
@@ -65,13 +73,13 @@ typedef struct {
     uint32_t flags;
 } agent_t;
 
-static void ego_frame(agent_t *a) {
+static void ego_frame(const oracle_cfg *c, agent_t *a) {
     double tx = a->gx - a->px, ty = a->gy - a->py;
     a->dist_to_goal = sqrt(tx * tx + ty * ty);
     if (a->dist_to_goal > 1e-8) { a->prll_x = tx / a->dist_to_goal; a->prll_y = ty / a->dist_to_goal; }
     else { a->prll_x = tx; a->prll_y = ty; }
     a->orth_x = -a->prll_y; a->orth_y = a->prll_x;
-    a->heading_ego = wrap(a->heading - atan2(a->prll_y, a->prll_x));
+    a->heading_ego = wrap(c, a->heading - atan2(a->prll_y, a->prll_x));
 }
 
 static int load_world(const oracle_cfg *c, const oracle_state *s, int64_t w, agent_t *ag) {
@@ -84,7 +92,7 @@ static int load_world(const oracle_cfg *c, const oracle_state *s, int64_t w, age
         g->gx = s->gx[a]; g->gy = s->gy[a]; g->radius = s->radius[a]; g->pref_speed = s->pref_speed[a];
         g->speed = s->speed[a]; g->flags = s->flags[a];
         g->vx = g->speed * cos(g->heading); g->vy = g->speed * sin(g->heading);
-        ego_frame(g);
+        ego_frame(c, g);
     }
     return n;
 }
@@ -116,11 +124,11 @@ static void take_action(const oracle_cfg *c, agent_t *a, double a0, double a1) {
             double rate = fmin(fmax(dh / dt, -c->max_turn_rate), c->max_turn_rate);
             dh = rate * dt;
         }
-        double h = wrap(dh + a->heading), cs = cos(h), sn = sin(h);
+        double h = wrap(c, dh + a->heading), cs = cos(h), sn = sin(h);
         a->px += a0 * cs * dt; a->py += a0 * sn * dt;
         a->vx = a0 * cs; a->vy = a0 * sn; a->speed = a0; a->heading = h;
     }
-    ego_frame(a);
+    ego_frame(c, a);
     double dx = a->px - a->gx, dy = a->py - a->gy;
     if (dx * dx + dy * dy <= c->near_goal_threshold * c->near_goal_threshold) a->flags |= F_AT_GOAL;
     a->t_rem -= dt;
@@ -162,7 +170,7 @@ static void observe_world(const oracle_cfg *c, agent_t *ag, int n, double *obs /
     memset(obs, 0, sizeof(double) * (size_t)c->max_agents * width);
     for (int i = 0; i < n; ++i) {
         agent_t *h = &ag[i];
-        ego_frame(h);
+        ego_frame(c, h);
         crit_t crit[ORACLE_MAX_AGENTS];
         int m = 0;
         for (int j = 0; j < n; ++j) {
@@ -172,7 +180,8 @@ static void observe_world(const oracle_cfg *c, agent_t *ag, int n, double *obs /
             if (d > c->sensing_horizon) continue;
             double gap = d - h->radius - o->radius;
             double p_orth = rx * h->orth_x + ry * h->orth_y;
-            double gr = rint(gap * 100.0) / 100.0;
+            double gr = c->sort_round_gap ? rint(gap * 100.0) / 100.0 : gap;     /* U7a */
+            if (!c->sort_tie_lateral) p_orth = 0.0;                               /* U7b: ties keep index order (stable sort) */
             crit[m].j = j;
             if (c->sort_method == SORT_TTI) { crit[m].k0 = -time_to_impact(h, o); crit[m].k1 = -gr; crit[m].k2 = p_orth; }
             else { crit[m].k0 = -gr; crit[m].k1 = p_orth; crit[m].k2 = 0.0; }
@@ -313,7 +322,7 @@ static void rvo_action(const oracle_cfg *c, const agent_t *ag, int n, int hi, do
     int fail = lp_plane(ln, m, h->pref_speed, pvx, pvy, 0, &vx, &vy);
     if (fail < m) lp_least_penetration(ln, m, fail, h->pref_speed, &vx, &vy);
     double speed = sqrt(vx * vx + vy * vy);
-    double delta = speed > 0.0 ? wrap(atan2(vy, vx) - h->heading) : 0.0;
+    double delta = speed > 0.0 ? wrap(c, atan2(vy, vx) - h->heading) : 0.0;
     if (fabs(delta) > c->rvo_max_delta_heading) { delta = copysign(c->rvo_max_delta_heading, delta); speed = 0.0; }
     *a0 = speed; *a1 = delta;
 }
@@ -323,11 +332,13 @@ static void step_world(const oracle_cfg *c, agent_t *ag, int n, const int32_t *a
     const int N = c->max_agents;
     double a0[ORACLE_MAX_AGENTS], a1[ORACLE_MAX_AGENTS];
     /* E4: every agent picks its action first ... */
+    int frozen[ORACLE_MAX_AGENTS];                       /* done BEFORE this step's move (U4) */
+    for (int i = 0; i < n; ++i) frozen[i] = (ag[i].flags & F_DONE_MASK) ? 1 : 0;
     for (int i = 0; i < n; ++i) {
         a0[i] = a1[i] = 0.0;
         if (ag[i].flags & F_DONE_MASK) continue;
-        int pol = (ag[i].flags >> F_POLICY_SHIFT) & 3;
-        if (pol == POLICY_EXTERNAL) {
+        int pol = (ag[i].flags >> F_POLICY_SHIFT) & F_POLICY_MASK;
+        if (pol == POLICY_EXTERNAL || pol == POLICY_FROZEN_NET) {   /* frozen network: its action index comes in like a learner's */
             if (cont) { a0[i] = cont[2 * i]; a1[i] = cont[2 * i + 1]; }
             else { const double *r = c->actions[act[i]]; a0[i] = ag[i].pref_speed * r[0]; a1[i] = r[1]; }
         } else if (pol == POLICY_NONCOOP) { a0[i] = ag[i].pref_speed; a1[i] = -ag[i].heading_ego; }
@@ -342,6 +353,7 @@ static void step_world(const oracle_cfg *c, agent_t *ag, int n, const int32_t *a
     for (int i = 0; i < n; ++i) { hit[i] = 0; min_gap[i] = INFINITY; }
     for (int i = 0; i < n; ++i)
         for (int j = i + 1; j < n; ++j) {
+            if (!c->done_agents_collide && (frozen[i] || frozen[j])) continue;      /* U4 flipped */
             double dx = ag[i].px - ag[j].px, dy = ag[i].py - ag[j].py;
             double gap = sqrt(dx * dx + dy * dy) - (ag[i].radius + ag[j].radius);
             min_gap[i] = fmin(min_gap[i], gap); min_gap[j] = fmin(min_gap[j], gap);
@@ -408,7 +420,8 @@ static uint32_t draw_policy(const oracle_gen *g, const uint32_t b[4], int i) {
     if (i > 0 && u01(b[2]) < g->nonlearning_fraction) {
         double u = u01(b[3]);
         if (u < g->static_fraction) return POLICY_STATIC;
-        return u < g->static_fraction + g->rvo_fraction ? POLICY_RVO : POLICY_NONCOOP;
+        if (u < g->static_fraction + g->rvo_fraction) return POLICY_RVO;
+        return u < g->static_fraction + g->rvo_fraction + g->frozen_fraction ? POLICY_FROZEN_NET : POLICY_NONCOOP;
     }
     return POLICY_EXTERNAL;
 }

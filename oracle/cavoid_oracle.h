@@ -26,6 +26,10 @@ typedef struct oracle_cfg {
     int32_t num_actions;
     int32_t evaluate_mode;     /* game over when EVERY agent is done (EVALUATE_MODE) instead of every learning agent */
     int32_t time_budget_from_goal_edge; /* U11: budget = ratio*(dist - near_goal)/pref (1, default) or ratio*dist/pref (0) */
+    int32_t wrap_closed_end;     /* U2: 0 [-pi, pi) (default), 1 (-pi, pi] */
+    int32_t done_agents_collide; /* U4: 1 (default) frozen agents still collide with movers, 0 pairs with a frozen agent are skipped */
+    int32_t sort_round_gap;      /* U7a: 1 (default) order by the gap rounded to centimetres, 0 by the exact gap */
+    int32_t sort_tie_lateral;    /* U7b: 1 (default) ties by lateral offset then index, 0 by index alone */
     int32_t _pad0;
     double actions[ORACLE_MAX_ACTIONS][2];
 } oracle_cfg;
@@ -39,6 +43,7 @@ typedef struct oracle_gen {
     double box_small[2], box_large[2], min_trip;
     int32_t box_large_from;
     uint32_t pool_epoch;
+    double frozen_fraction; /* ... P(frozen network, policy 4) */
 } oracle_gen;
 
 /* SoA over A = W*N agents, agent a = w*N + i */

@@ -48,10 +48,14 @@ F_WAS_AT_GOAL = 1 << 3      # Agent.was_at_goal_already
 F_WAS_IN_COLL = 1 << 4      # Agent.was_in_collision_already
 F_PRESENT = 1 << 5          # row holds a real agent (worlds may have fewer than N agents)
 F_LEARNING = 1 << 6         # policy is the external (GA3C) learning policy -> obs col 0
-F_POLICY_SHIFT = 8          # bits 8..9: 0 external/learning, 1 static, 2 non-cooperative, 3 RVO (ORCA)
+F_POLICY_SHIFT = 8          # bits 8..10: 0 external/learning, 1 static, 2 non-cooperative, 3 RVO (ORCA), 4 frozen network
+F_POLICY_MASK = 7
 F_DONE_MASK = F_AT_GOAL | F_RAN_OUT | F_IN_COLL
 
-POLICY_EXTERNAL, POLICY_STATIC, POLICY_NONCOOP, POLICY_RVO = 0, 1, 2, 3
+# POLICY_FROZEN_NET: a NON-learning agent driven by a frozen copy of the GA3C-CADRL network (ga3c/GA3C/Server.py:36 imports
+# that policy class from the env package): the env decodes its action index from the same table as a learner's, the index
+# itself comes from outside (the caller evaluates the frozen network), it never counts as "learning".
+POLICY_EXTERNAL, POLICY_STATIC, POLICY_NONCOOP, POLICY_RVO, POLICY_FROZEN_NET = 0, 1, 2, 3, 4
 SORT_CLOSEST_LAST, SORT_CLOSEST_FIRST, SORT_TIME_TO_IMPACT = 0, 1, 2
 DYN_UNICYCLE, DYN_UNICYCLE_MAX_TURN, DYN_HOLONOMIC = 0, 1, 2
 
@@ -97,6 +101,11 @@ class OracleConfig:
     evaluate_mode: bool = False          # EVALUATE_MODE: the episode ends when EVERY agent is done
     time_budget_from_goal_edge: bool = True   # U11: budget = ratio*(dist - NEAR_GOAL_THRESHOLD)/pref (upstream agent.py as
                                          # recalled) vs SURVEY App. A's ratio*dist/pref (False)
+    wrap_closed_end: bool = False        # U2: angles wrap to [-pi, pi) (False) or to (-pi, pi] (True)
+    done_agents_collide: bool = True     # U4: an agent that is already done still takes part in the others' collision test and
+                                         # nearest gap (True); False: a pair with an agent that was done before the step is skipped
+    sort_round_gap: bool = True          # U7a: neighbours ordered by the gap rounded to centimetres (True) or by the exact gap
+    sort_tie_lateral: bool = True        # U7b: equal (rounded) gaps ordered by the lateral offset, then index (True); index alone
     # --- RVO scripted policy (run-ws/config.yaml:231-239: RVO_TIME_HORIZON 5.0, RVO_COLLAB_COEFF 0.5) -----------
     rvo_time_horizon: float = 5.0
     rvo_collab_coeff: float = 0.5        # share of the avoidance effort the RVO agent takes (0.5 = reciprocal)
@@ -112,8 +121,14 @@ class OracleConfig:
         return 2 + 4 + 7 * self.max_other_agents_observed
 
 
-def wrap(angle: float) -> float:
-    """Wrap to [-pi, pi) by repeated +-2*pi (U2: half-open at +pi)."""
+def wrap(angle: float, closed_end: bool = False) -> float:
+    """Wrap by repeated +-2*pi to [-pi, pi) (U2 default: half-open at +pi) or, ``closed_end``, to (-pi, pi]."""
+    if closed_end:
+        while angle > math.pi:
+            angle -= 2.0 * math.pi
+        while angle <= -math.pi:
+            angle += 2.0 * math.pi
+        return angle
     while angle >= math.pi:
         angle -= 2.0 * math.pi
     while angle < -math.pi:
@@ -178,7 +193,7 @@ class Agent:
         self.in_collision = bool(f & F_IN_COLL)
         self.was_at_goal_already = bool(f & F_WAS_AT_GOAL)
         self.was_in_collision_already = bool(f & F_WAS_IN_COLL)
-        self.policy = (f >> F_POLICY_SHIFT) & 3
+        self.policy = (f >> F_POLICY_SHIFT) & F_POLICY_MASK
 
     # -- ego frame (E9 host part) --------------------------------------------------------------
     def update_ego_frame(self) -> None:
@@ -190,7 +205,7 @@ class Agent:
         else:
             self.ref_prll = to_goal.copy()
         self.ref_orth = np.array([-self.ref_prll[1], self.ref_prll[0]])
-        self.heading_ego = wrap(self.heading - math.atan2(self.ref_prll[1], self.ref_prll[0]))
+        self.heading_ego = wrap(self.heading - math.atan2(self.ref_prll[1], self.ref_prll[0]), self.cfg.wrap_closed_end)
 
     # -- E5: one dynamics step -----------------------------------------------------------------
     def take_action(self, action: Sequence[float], dt: float) -> None:
@@ -218,7 +233,7 @@ class Agent:
             if cfg.dynamics == DYN_UNICYCLE_MAX_TURN:
                 rate = min(max(dh / dt, -cfg.max_turn_rate), cfg.max_turn_rate)
                 dh = rate * dt
-            new_heading = wrap(dh + self.heading)
+            new_heading = wrap(dh + self.heading, cfg.wrap_closed_end)
             c, s = math.cos(new_heading), math.sin(new_heading)
             self.pos += np.array([speed * c * dt, speed * s * dt])
             self.vel[0], self.vel[1] = speed * c, speed * s
@@ -400,7 +415,7 @@ def rvo_action(hi: int, agents: List["Agent"], cfg: "OracleConfig") -> np.ndarra
     if fail < len(lines):
         vx, vy = _lp_least_penetration(lines, fail, host.pref_speed, vx, vy)
     speed = math.sqrt(vx * vx + vy * vy)
-    delta = wrap(math.atan2(vy, vx) - host.heading) if speed > 0.0 else 0.0
+    delta = wrap(math.atan2(vy, vx) - host.heading, cfg.wrap_closed_end) if speed > 0.0 else 0.0
     if abs(delta) > cfg.rvo_max_delta_heading:
         delta = math.copysign(cfg.rvo_max_delta_heading, delta)
         speed = 0.0
@@ -413,6 +428,7 @@ class World:
     def __init__(self, agents: List[Agent], cfg: Optional[OracleConfig] = None):
         self.cfg = cfg or (agents[0].cfg if agents else OracleConfig())
         self.agents = agents
+        self._frozen = [False] * len(agents)
         assert len(agents) <= self.cfg.max_agents
 
     # -- E4: decode ----------------------------------------------------------------------------
@@ -439,10 +455,11 @@ class World:
         n = len(self.agents)
         dtype = np.float32 if cfg.actions_fp32 else np.float64
         joint = np.zeros((n, 2), dtype=dtype)
+        self._frozen = [ag.is_done for ag in self.agents]      # done BEFORE this step's move (U4)
         for i, ag in enumerate(self.agents):
             if ag.is_done:
                 continue
-            if ag.policy == POLICY_EXTERNAL:
+            if ag.policy in (POLICY_EXTERNAL, POLICY_FROZEN_NET):
                 a = actions[i]
                 joint[i, :] = np.asarray(a, dtype=np.float64) if continuous else self._decode(ag, a)
             else:
@@ -465,6 +482,8 @@ class World:
         for i in range(n):
             for j in range(i + 1, n):
                 a, b = self.agents[i], self.agents[j]
+                if not self.cfg.done_agents_collide and (self._frozen[i] or self._frozen[j]):
+                    continue                                   # U4 flipped: frozen agents are out of the collision check
                 dx, dy = a.pos[0] - b.pos[0], a.pos[1] - b.pos[1]
                 d = math.sqrt(dx * dx + dy * dy)
                 gap = d - (a.radius + b.radius)
@@ -507,8 +526,9 @@ class World:
             gap = d - host.radius - other.radius
             p_orth = rel[0] * host.ref_orth[0] + rel[1] * host.ref_orth[1]
             tti = time_to_impact(host, other) if cfg.sort_method == SORT_TIME_TO_IMPACT else 0.0
-            # U7: gap rounded to centimetres, lateral offset breaks ties
-            crit.append((j, np.rint(gap * 100.0) / 100.0, p_orth, tti))
+            # U7a: gap rounded to centimetres (or the exact gap); U7b: lateral offset breaks ties (or nothing: index order)
+            crit.append((j, np.rint(gap * 100.0) / 100.0 if cfg.sort_round_gap else gap,
+                         p_orth if cfg.sort_tie_lateral else 0.0, tti))
         if cfg.sort_method == SORT_TIME_TO_IMPACT:
             far_to_near = sorted(crit, key=lambda c: (-c[3], -c[1], c[2]))
         else:
@@ -583,7 +603,8 @@ class GenConfig:
     angle_jitter: float = 0.25            # GEN v1: fraction of the angular slot
     pool_size: int = 0                    # > 0: scenario pool (episode ep of world gw = pool entry pool_index(seed, gw, ep, P))
     mode: int = 0                         # 0 = GEN v1 (ring, antipodal goals), 1 = GEN v2 (uniform boxes, rejection sampling)
-    rvo_fraction: float = 0.0             # of the scripted agents, P(RVO); the rest (1 - static - rvo) are non-cooperative
+    rvo_fraction: float = 0.0             # of the scripted agents, P(RVO)
+    frozen_fraction: float = 0.0          # ... P(frozen network); the rest (1 - static - rvo - frozen) are non-cooperative
     box_small: Tuple[float, float] = (4.0, 5.0)    # GEN v2: half side of the box ~ U(lo, hi) for worlds of < box_large_from agents
     box_large: Tuple[float, float] = (6.0, 8.0)    # ... and for the larger worlds (keeps the density roughly constant)
     box_large_from: int = 5
@@ -609,7 +630,9 @@ def _draw_policy(b, i: int, gen: GenConfig) -> int:
         u = _u01(b[3])
         if u < gen.static_fraction:
             return POLICY_STATIC
-        return POLICY_RVO if u < gen.static_fraction + gen.rvo_fraction else POLICY_NONCOOP
+        if u < gen.static_fraction + gen.rvo_fraction:
+            return POLICY_RVO
+        return POLICY_FROZEN_NET if u < gen.static_fraction + gen.rvo_fraction + gen.frozen_fraction else POLICY_NONCOOP
     return POLICY_EXTERNAL
 
 
@@ -702,7 +725,7 @@ def world_from_arrays(f64, f32, flags, cfg: OracleConfig) -> World:
         if not f & F_PRESENT:
             break
         ag = Agent(f64[0, i], f64[1, i], float(f32[0, i]), float(f32[1, i]), float(f32[2, i]),
-                   float(f32[3, i]), float(f64[2, i]), (f >> F_POLICY_SHIFT) & 3, cfg)
+                   float(f32[3, i]), float(f64[2, i]), (f >> F_POLICY_SHIFT) & F_POLICY_MASK, cfg)
         ag.t_remaining = float(f64[3, i])
         ag.set_flags(f)
         ag.speed = float(f32[4, i])

@@ -15,10 +15,12 @@ LIB_PATH = os.environ.get("CAVOID_LIB", _DEFAULT_LIB_PATH)
 
 MAX_ACTIONS = 32
 MAX_AGENTS = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F_AT_GOAL, F_RAN_OUT, F_IN_COLL, F_WAS_AT_GOAL, F_WAS_IN_COLL, F_PRESENT, F_LEARNING = 1, 2, 4, 8, 16, 32, 64
 F_POLICY_SHIFT = 8
+F_POLICY_MASK = 7
+POLICY_EXTERNAL, POLICY_STATIC, POLICY_NONCOOP, POLICY_RVO, POLICY_FROZEN_NET = 0, 1, 2, 3, 4
 F_DONE_MASK = 7
 
 
@@ -28,7 +30,8 @@ class CavoidCfg(C.Structure):
         ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
         ("max_agents", C.c_int32), ("max_other", C.c_int32), ("sort_method", C.c_int32), ("dynamics", C.c_int32),
         ("actions_fp32", C.c_int32), ("timeout_enabled", C.c_int32), ("num_actions", C.c_int32), ("evaluate_mode", C.c_int32),
-        ("time_budget_from_goal_edge", C.c_int32), ("_pad0", C.c_int32),
+        ("time_budget_from_goal_edge", C.c_int32), ("wrap_closed_end", C.c_int32), ("done_agents_collide", C.c_int32),
+        ("sort_round_gap", C.c_int32), ("sort_tie_lateral", C.c_int32), ("_pad0", C.c_int32),
         ("dt", C.c_double), ("near_goal_threshold", C.c_double), ("max_time_ratio", C.c_double),
         ("collision_dist", C.c_double), ("getting_close_range", C.c_double), ("reward_at_goal", C.c_double),
         ("reward_collision", C.c_double), ("reward_getting_close", C.c_double), ("reward_time_step", C.c_double),
@@ -40,7 +43,7 @@ class CavoidCfg(C.Structure):
         ("gen_goal_jitter", C.c_double), ("gen_angle_jitter", C.c_double),
         ("gen_pool_size", C.c_int32),
         ("gen_mode", C.c_int32), ("gen_box_large_from", C.c_int32), ("gen_pool_epoch", C.c_uint32), ("rvo_enabled", C.c_int32),
-        ("gen_rvo_fraction", C.c_double), ("gen_box_small", C.c_double * 2), ("gen_box_large", C.c_double * 2),
+        ("gen_rvo_fraction", C.c_double), ("gen_frozen_fraction", C.c_double), ("gen_box_small", C.c_double * 2), ("gen_box_large", C.c_double * 2),
         ("gen_min_trip", C.c_double),
         ("rvo_time_horizon", C.c_double), ("rvo_collab_coeff", C.c_double), ("rvo_radius_scale", C.c_double),
         ("rvo_max_delta_heading", C.c_double),
@@ -93,17 +96,19 @@ SYMBOLS = [
     ("cavoid_step", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("cavoid_step_continuous", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("cavoid_step_autoreset", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
-    ("cavoid_step_autoreset_n", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
-    ("cavoid_step_autoreset_n_timed", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.POINTER(C.c_float)]),
+    ("cavoid_step_autoreset_n", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P, _P, _P]),
+    ("cavoid_step_autoreset_n_timed", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_float)]),
+    ("cavoid_policy_rows", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("cavoid_packed_width", C.c_int32, [_P]),
     ("cavoid_reset_packed", C.c_int, [_P, _P, _P, _P]),
     ("cavoid_observe_packed", C.c_int, [_P, _P, _P]),
     ("cavoid_step_packed", C.c_int, [_P, _P, _P, _P, _P]),
-    ("cavoid_step_autoreset_packed", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
+    ("cavoid_step_autoreset_packed", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P]),
     ("cavoid_comm_unique_id", C.c_int, [_P]),
     ("cavoid_comm_create", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int, C.POINTER(_P)]),
     ("cavoid_comm_destroy", None, [_P]),
     ("cavoid_gather_begin", C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, _P]),
+    ("cavoid_gatherv_begin", C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(C.c_int64), C.c_int32, _P]),
     ("cavoid_gather_wait", C.c_int, [_P, C.c_int32, _P]),
     ("cavoid_last_comm_error", C.c_int, []),
     ("cavoid_rollout_create", C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int, C.POINTER(_P)]),
@@ -133,11 +138,13 @@ def lib():
         if "CAVOID_LIB" not in os.environ:
             from . import build as _build
             if os.path.exists(LIB_PATH) and _build.is_stale():
-                # sources newer than the binary: rebuild when a compiler is here (development box), refuse otherwise
-                try:
+                # the binary does not match the in-tree sources.  Never rebuild behind an import's back (minutes of hipcc):
+                # CAVOID_AUTO_REBUILD=1 opts a development box into it, everyone else gets told what to run.
+                if os.environ.get("CAVOID_AUTO_REBUILD", "0") not in ("", "0"):
                     _build.build()
-                except Exception as exc:      # noqa: BLE001
-                    raise ImportError("%s is older than its sources and could not be rebuilt (%s)" % (LIB_PATH, exc))
+                else:
+                    raise ImportError("%s does not match its sources: run `python -m rl_collision_avoidance_amd.build` "
+                                      "(or set CAVOID_AUTO_REBUILD=1)" % LIB_PATH)
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s is missing: build it with `python -m rl_collision_avoidance_amd.build` (needs hipcc). "

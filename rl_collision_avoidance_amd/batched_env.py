@@ -69,6 +69,27 @@ def make_cfg(config: Optional[EnvConfig] = None, **overrides) -> _lib.CavoidCfg:
     return cfg
 
 
+class StepSlots(object):
+    """Per-step outputs of a K-step launch: slot t holds what ``env.step`` returned at step t --
+    ``obs [K,W,N,1+D]``, ``rewards [K,W,N]``, ``done [K,W,N]``, ``game_over [K,W]`` (what
+    ``ProcessAgent.run_episode`` reads after every step, /root/reference/ga3c/GA3C/ProcessAgent.py:149-157), or with
+    ``packed=True`` one ``packed [K,W,N,1+D+2]`` record tensor + ``game_over``."""
+
+    def __init__(self, env: "BatchedCollisionAvoidanceEnv", steps: int, packed: bool = False):
+        K, W, N, dev = int(steps), env.num_worlds, env.max_agents, env.device
+        self.steps, self.is_packed = K, packed
+        self.game_over = torch.zeros((K, W), dtype=torch.uint8, device=dev)
+        if packed:
+            self.packed = torch.zeros((K, W, N, env.packed_width), dtype=torch.float32, device=dev)
+            self.obs = self.packed[..., :env.obs_width]
+            self.rewards = self.packed[..., env.obs_width]
+            self.done = self.packed[..., env.obs_width + 1]
+        else:
+            self.obs = torch.zeros((K, W, N, env.obs_width), dtype=torch.float32, device=dev)
+            self.rewards = torch.zeros((K, W, N), dtype=torch.float32, device=dev)
+            self.done = torch.zeros((K, W, N), dtype=torch.uint8, device=dev)
+
+
 class BatchedCollisionAvoidanceEnv(object):
     """``num_worlds`` worlds of up to ``N`` agents on one GPU.
 
@@ -140,8 +161,9 @@ class BatchedCollisionAvoidanceEnv(object):
                                                 self._stream()), "cavoid_step_packed")
         return packed, self.game_over
 
-    def step_autoreset_packed(self, actions: torch.Tensor, packed: torch.Tensor, n_steps: Optional[int] = None):
-        """``step_autoreset`` (actions [W,N]) or ``step_autoreset_n`` (actions [T,W,N]) into a packed record buffer."""
+    def step_autoreset_packed(self, actions: torch.Tensor, packed, n_steps: Optional[int] = None):
+        """``step_autoreset`` (actions [W,N]) or ``step_autoreset_n`` (actions [T,W,N]) into a packed record buffer
+        ([W,N,1+D+2]: it holds the last step's records afterwards) or into ``StepSlots(packed=True)`` (every step's)."""
         if actions.dim() == 2:
             a, n, stride = self._actions(actions), 1, 0
         else:
@@ -151,9 +173,19 @@ class BatchedCollisionAvoidanceEnv(object):
                 raise ValueError("n_steps > number of action slices")
             a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
             stride = self.num_worlds * self.max_agents
-        _lib.check(self._lib.cavoid_step_autoreset_packed(self._h, self._ptr(a), stride, n, self._ptr(self._packed(packed)),
+        if isinstance(packed, StepSlots):
+            if not packed.is_packed or packed.steps < n:
+                raise ValueError("need StepSlots(packed=True) of at least n_steps slots")
+            _lib.check(self._lib.cavoid_step_autoreset_packed(self._h, self._ptr(a), stride, n, self.num_worlds, self._ptr(packed.packed),
+                                                              self._ptr(packed.game_over), self._stream()), "cavoid_step_autoreset_packed")
+            return packed.packed, packed.game_over
+        _lib.check(self._lib.cavoid_step_autoreset_packed(self._h, self._ptr(a), stride, n, 0, self._ptr(self._packed(packed)),
                                                           self._ptr(self.game_over), self._stream()), "cavoid_step_autoreset_packed")
         return packed, self.game_over
+
+    def new_step_slots(self, steps: int, packed: bool = False) -> StepSlots:
+        """Output slots for ``steps`` steps of one multi-step launch (``step_autoreset_n(..., slots=...)``)."""
+        return StepSlots(self, steps, packed)
 
     # -- lifetime ------------------------------------------------------------------------------
     def close(self) -> None:
@@ -291,26 +323,47 @@ class BatchedCollisionAvoidanceEnv(object):
             _lib.check(rc, "cavoid_step_autoreset")
         return obs, self.rewards, self.done, self.game_over
 
-    def step_autoreset_n(self, actions: torch.Tensor, n_steps: Optional[int] = None):
-        """Open-loop run: actions int32 [T,W,N]; ``n_steps`` (default T, at most T) auto-reset steps in ONE launch --
-        the world state stays in registers between the steps, step t reads ``actions[t]``; the outputs hold the last
-        step's values afterwards."""
+    def step_autoreset_n(self, actions: torch.Tensor, n_steps: Optional[int] = None, slots: Optional[StepSlots] = None):
+        """Pre-staged actions int32 [T,W,N]; ``n_steps`` (default T, at most T) auto-reset steps in ONE launch -- the
+        world state stays in registers between the steps, step t reads ``actions[t]``.  With ``slots`` (``new_step_slots``)
+        step t's observations, rewards, done flags and game_over land in slot t; without, every step overwrites the env's
+        own output buffers (they hold the last step's values afterwards)."""
         T = actions.shape[0]
         n = T if n_steps is None else int(n_steps)
         if n > T:
             raise ValueError("n_steps > number of action slices")
         a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
         stride = self.num_worlds * self.max_agents
-        rc = self._lib.cavoid_step_autoreset_n(self._h, C.c_void_p(a.data_ptr()), stride, n, self._p_obs, self._p_rew, self._p_done,
+        if slots is not None:
+            if slots.is_packed or slots.steps < n:
+                raise ValueError("need plain StepSlots of at least n_steps slots")
+            rc = self._lib.cavoid_step_autoreset_n(self._h, C.c_void_p(a.data_ptr()), stride, n, self.num_worlds,
+                                                   C.c_void_p(slots.obs.data_ptr()), C.c_void_p(slots.rewards.data_ptr()),
+                                                   C.c_void_p(slots.done.data_ptr()), C.c_void_p(slots.game_over.data_ptr()), self._stream())
+            if rc != 0:
+                _lib.check(rc, "cavoid_step_autoreset_n")
+            return slots.obs, slots.rewards, slots.done, slots.game_over
+        rc = self._lib.cavoid_step_autoreset_n(self._h, C.c_void_p(a.data_ptr()), stride, n, 0, self._p_obs, self._p_rew, self._p_done,
                                                self._p_go, self._stream())
         if rc != 0:
             _lib.check(rc, "cavoid_step_autoreset_n")
         return self.obs, self.rewards, self.done, self.game_over
 
+    def policy_rows(self, policy_id: int, only_running: bool = True):
+        """(row_index int32 [W*N], row_count int32 [1]) on the device: the (world, agent) slots run by scripted policy
+        ``policy_id`` (``_lib.POLICY_*``) -- for POLICY_FROZEN_NET the rows a frozen network must supply actions for."""
+        if not hasattr(self, "_prow_index"):
+            self._prow_index = torch.zeros((self.num_worlds * self.max_agents,), dtype=torch.int32, device=self.device)
+            self._prow_count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.cavoid_policy_rows(self._h, int(policy_id), 1 if only_running else 0, self._ptr(self._prow_index),
+                                                self._ptr(self._prow_count), self._stream()), "cavoid_policy_rows")
+        return self._prow_index, self._prow_count
+
     # -- measurement -------------------------------------------------------------------------------
-    def kernel_time_ms(self, actions: torch.Tensor, n_steps: int, steps_per_launch: int = 1) -> float:
+    def kernel_time_ms(self, actions: torch.Tensor, n_steps: int, steps_per_launch: int = 1, slots: Optional[StepSlots] = None) -> float:
         """Run ``n_steps`` autoreset steps (cycling through actions [T,W,N]) in launches of ``steps_per_launch`` steps,
-        a HIP event pair per launch; returns the mean duration of ONE LAUNCH in ms (launch gaps excluded)."""
+        a HIP event pair per launch; returns the mean duration of ONE LAUNCH in ms (launch gaps excluded).  ``slots``:
+        every launch writes its steps into these per-step output slots (else all into the env's own buffers)."""
         T = actions.shape[0]
         a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
         stride = self.num_worlds * self.max_agents
@@ -319,9 +372,12 @@ class BatchedCollisionAvoidanceEnv(object):
         while left > 0:
             n = min((T // spl) * spl, left)
             ms = C.c_float(0.0)
+            o = slots if slots is not None else self
+            if slots is not None and (slots.is_packed or slots.steps < spl):
+                raise ValueError("need plain StepSlots of at least steps_per_launch slots")
             _lib.check(self._lib.cavoid_step_autoreset_n_timed(
-                self._h, self._ptr(a), stride, n, spl, self._ptr(self.obs), self._ptr(self.rewards), self._ptr(self.done),
-                self._ptr(self.game_over), self._stream(), C.byref(ms)), "cavoid_step_autoreset_n_timed")
+                self._h, self._ptr(a), stride, n, spl, self.num_worlds if slots is not None else 0, self._ptr(o.obs), self._ptr(o.rewards),
+                self._ptr(o.done), self._ptr(o.game_over), self._stream(), C.byref(ms)), "cavoid_step_autoreset_n_timed")
             k = -(-n // spl)
             total += ms.value * k
             launches += k

@@ -86,8 +86,9 @@ def _compile_objects(extra_flags, tag: str, force: bool, verbose: bool):
 
 
 def _link(objs, out: str, verbose: bool) -> str:
-    # RCCL by SONAME: inside a PyTorch process the loader binds to the librccl.so PyTorch has already mapped
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-o", out]
+    # no -lrccl: cavoid_comm_capi.hip binds RCCL with dlopen at the first multi-rank call (single-GPU users and host-only
+    # tests load without it; inside a PyTorch process it takes the librccl PyTorch has already mapped)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

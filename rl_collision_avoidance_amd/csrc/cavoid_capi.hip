@@ -63,6 +63,10 @@ extern "C" int cavoid_default_cfg(cavoid_cfg *c, int32_t max_agents, int32_t max
     c->actions_fp32 = 1;
     c->timeout_enabled = 1;
     c->time_budget_from_goal_edge = 1;
+    c->wrap_closed_end = 0;             /* U2 */
+    c->done_agents_collide = 1;         /* U4 */
+    c->sort_round_gap = 1;              /* U7a */
+    c->sort_tie_lateral = 1;            /* U7b */
     c->dt = 0.2;
     c->near_goal_threshold = 0.2;
     c->max_time_ratio = 2.0;
@@ -90,6 +94,7 @@ extern "C" int cavoid_default_cfg(cavoid_cfg *c, int32_t max_agents, int32_t max
     c->gen_pool_epoch = 0;
     c->rvo_enabled = 0;
     c->gen_rvo_fraction = 0.0;
+    c->gen_frozen_fraction = 0.0;
     c->gen_box_small[0] = 4.0; c->gen_box_small[1] = 5.0;
     c->gen_box_large[0] = 6.0; c->gen_box_large[1] = 8.0;
     c->gen_min_trip = 1.0;
@@ -114,6 +119,7 @@ static int validate(const cavoid_cfg *c) {
                               c->gen_box_large[0] > 0.0 && c->gen_box_large[1] >= c->gen_box_large[0] && c->gen_min_trip >= 0.0))
         return CAVOID_EINVAL;
     if (c->gen_rvo_fraction < 0.0 || c->gen_rvo_fraction > 1.0) return CAVOID_EINVAL;
+    if (c->gen_frozen_fraction < 0.0 || c->gen_frozen_fraction > 1.0) return CAVOID_EINVAL;
     if (c->gen_rvo_fraction > 0.0 && !c->rvo_enabled) return CAVOID_EINVAL;    /* the generator would create agents the step cannot drive */
     if (c->rvo_enabled && !(c->rvo_time_horizon > 0.0 && c->rvo_radius_scale > 0.0)) return CAVOID_EINVAL;
     return CAVOID_OK;
@@ -205,7 +211,11 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.horizon = cfg->sensing_horizon; k.max_turn_rate = cfg->max_turn_rate;
     k.gen_nonlearning = cfg->gen_nonlearning_fraction; k.gen_static = cfg->gen_static_fraction;
     k.gen_goal_jitter = cfg->gen_goal_jitter; k.gen_angle_jitter = cfg->gen_angle_jitter;
-    k.gen_rvo = cfg->gen_rvo_fraction; k.gen_min_trip = cfg->gen_min_trip;
+    k.gen_rvo = cfg->gen_rvo_fraction; k.gen_min_trip = cfg->gen_min_trip; k.gen_frozen = cfg->gen_frozen_fraction;
+    k.wrap_hi = cfg->wrap_closed_end ? std::nextafter(kPi, 4.0) : kPi;          /* a > pi  <=>  a >= next(pi) */
+    k.wrap_lo = cfg->wrap_closed_end ? std::nextafter(-kPi, 0.0) : -kPi;        /* a <= -pi <=>  a < next(-pi) */
+    k.skip_done_pairs = cfg->done_agents_collide ? 0 : 1;
+    k.sort_round_gap = cfg->sort_round_gap ? 1 : 0; k.sort_tie_lateral = cfg->sort_tie_lateral ? 1 : 0;
     k.gen_box_small_lo = cfg->gen_box_small[0]; k.gen_box_small_hi = cfg->gen_box_small[1];
     k.gen_box_large_lo = cfg->gen_box_large[0]; k.gen_box_large_hi = cfg->gen_box_large[1];
     k.gen_mode = cfg->gen_mode; k.gen_box_large_from = cfg->gen_box_large_from; k.pool_epoch = cfg->gen_pool_epoch;
@@ -251,7 +261,12 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     // footprint (and the wavefronts resident per CU) does not scale with N*(1+D)   [N=10: +7 % at saturation]
     // ORCA scratch: two sets of N-1 lines (4 doubles) per lane, only when RVO agents may exist
     k.rvo_lds_floats = cfg->rvo_enabled ? 64 * 2 * (N - 1) * 4 * 2 : 0;
-    k.park_floats = (N >= kParkFromN && !cfg->rvo_enabled) ? 3 * (N - 1) * 64 : 0;      // the tile region also parks the sort keys and gaps
+    // the tile region also parks the sort keys and gaps of the one-step / reset / observe instantiations (kPark).  With
+    // rvo_enabled the STEP launches take the RVO instantiations (no parking, the ORCA scratch is theirs); reset / observe still
+    // run the parking instantiations, whose parked floats may then run past a small tile into the wavefront's ORCA scratch --
+    // by construction: that scratch (1024 (N-1) floats) is idle in those modes and always larger than the 192 (N-1) parked.
+    k.park_floats = (N >= kParkFromN && !cfg->rvo_enabled) ? 3 * (N - 1) * 64 : 0;
+    static_assert(64 * 2 * 4 * 2 >= 3 * 64, "reset / observe of an RVO env park keys and gaps in the idle ORCA scratch");
     const int row_floats = k.width + 2;
     int tile_rows = (int)(9216 / ((size_t)row_floats * sizeof(float))) & ~3;
     if (tile_rows < 4) tile_rows = 4;
@@ -425,10 +440,12 @@ extern "C" int cavoid_step_continuous(cavoid_env *e, const float *actions, float
 
 // the auto-reset step, n_steps >= 1 steps in ONE launch.  Latency mode (small batch with a scenario pool) takes the
 // register-prefetch instantiation for multi-step launches (and for single steps when CAVOID_PREFETCH_POOL=1).
-static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
                             hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
     if (n_steps < 1 || action_stride < 0) return CAVOID_EINVAL;
+    if (out_step_stride != 0 && out_step_stride < e->W) return CAVOID_EINVAL;   // slots of consecutive steps must not overlap
+    io.out_step_stride = n_steps > 1 ? out_step_stride : 0;
     if (e->cfg.gen_mode == 1 && e->pool_size <= 0) return CAVOID_EINVAL;   // GEN v2 restarts come from the scenario pool
     io.actions = actions;
     io.action_stride = action_stride;
@@ -440,26 +457,28 @@ static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64
 
 extern "C" int cavoid_step_autoreset(cavoid_env *e, const int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
     if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
-    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), actions, 0, 1, static_cast<hipStream_t>(stream));
+    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), actions, 0, 1, 0, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int cavoid_step_autoreset_n(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+extern "C" int cavoid_step_autoreset_n(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
                                        float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
     if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 0) return CAVOID_EINVAL;
     if (n_steps == 0) return CAVOID_OK;
-    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), actions, action_stride, n_steps, static_cast<hipStream_t>(stream));
+    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), actions, action_stride, n_steps, out_step_stride,
+                            static_cast<hipStream_t>(stream));
 }
 
-extern "C" int cavoid_step_autoreset_packed(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
+extern "C" int cavoid_step_autoreset_packed(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
                                             float *packed, uint8_t *game_over, void *stream) {
     if (!e || !actions || !packed || !game_over || n_steps < 0) return CAVOID_EINVAL;
     if (n_steps == 0) return CAVOID_OK;
-    return launch_autoreset(e, packed_io(e, packed, game_over), actions, action_stride, n_steps, static_cast<hipStream_t>(stream));
+    return launch_autoreset(e, packed_io(e, packed, game_over), actions, action_stride, n_steps, out_step_stride,
+                            static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,
-                                             int32_t steps_per_launch, float *obs, float *rew, uint8_t *done, uint8_t *game_over,
-                                             void *stream, float *mean_launch_ms) {
+                                             int32_t steps_per_launch, int64_t out_step_stride, float *obs, float *rew, uint8_t *done,
+                                             uint8_t *game_over, void *stream, float *mean_launch_ms) {
     if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 1 || steps_per_launch < 1 || !mean_launch_ms) return CAVOID_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int kPool = 128;
@@ -473,7 +492,7 @@ extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actio
         int n = 0;
         for (; n < kPool && t0 < n_steps && rc == CAVOID_OK; ++n) {
             const int32_t k = (n_steps - t0) < steps_per_launch ? (n_steps - t0) : steps_per_launch;
-            rc = launch_autoreset(e, io, actions + (int64_t)t0 * action_stride, action_stride, k, s, ev[2 * n], ev[2 * n + 1]);
+            rc = launch_autoreset(e, io, actions + (int64_t)t0 * action_stride, action_stride, k, out_step_stride, s, ev[2 * n], ev[2 * n + 1]);
             t0 += k;
         }
         if (rc != CAVOID_OK) break;
@@ -488,6 +507,37 @@ extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actio
     for (int i = 0; i < 2 * kPool; ++i) (void)hipEventDestroy(ev[i]);
     if (rc == CAVOID_OK) *mean_launch_ms = (float)(total_ms / launches);
     return rc;
+}
+
+// the slots driven by one scripted policy (CAVOID_POLICY_FROZEN_NET: the rows a frozen network must act for)
+__global__ void __launch_bounds__(256) policy_rows_kernel(const uint32_t *flags, int64_t slots, uint32_t policy, int only_running,
+                                                          int32_t *row_index, int32_t *row_count) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool take = false;
+    if (a < slots) {
+        const uint32_t f = flags[a];
+        take = (f & CAVOID_F_PRESENT) && ((f >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK) == policy &&
+               !(only_running && (f & CAVOID_F_DONE_MASK));
+    }
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0ull) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(row_count, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (take) row_index[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)a;
+}
+__global__ void zero_counter_kernel(int32_t *counter) { *counter = 0; }
+
+extern "C" int cavoid_policy_rows(cavoid_env *e, int32_t policy_id, int32_t only_running, int32_t *row_index, int32_t *row_count, void *stream) {
+    if (!e || !row_index || !row_count || policy_id < 0 || policy_id > (int32_t)CAVOID_F_POLICY_MASK) return CAVOID_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(zero_counter_kernel, dim3(1), dim3(1), 0, s, row_count);          // (a kernel, not a memset node: hipGraph replays)
+    hipLaunchKernelGGL(policy_rows_kernel, dim3((unsigned)((e->A + 255) / 256)), dim3(256), 0, s, e->st.flags, e->A, (uint32_t)policy_id,
+                       only_running ? 1 : 0, row_index, row_count);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
 }
 
 #ifdef CAVOID_TRACE

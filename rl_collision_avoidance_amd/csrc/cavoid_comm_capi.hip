@@ -10,8 +10,9 @@
 //   consumer stream:  cavoid_gather_wait(slot) = wait ev_done[slot]  (the trainer side reads recv[slot])
 // The caller double-buffers send / recv; step(t+1) is enqueued on the producer stream right after
 // cavoid_gather_begin(t) returns and runs while gather(t) is on the wire.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>      // types and constants only: the library itself is bound lazily (see rccl())
 
 #include <cstring>
 #include <new>
@@ -22,6 +23,43 @@
 static_assert(CAVOID_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
 
 thread_local int g_last_comm_error = 0;
+
+// RCCL is bound at the first multi-rank call, not at load time: the single-GPU env, the policy kernels and the host-only
+// tests must load on a box without librccl on the loader path, and inside a PyTorch process the communicator must use the
+// librccl PyTorch has already mapped (RTLD_NOLOAD first), not a second copy.
+struct RcclApi {
+    ncclResult_t (*get_unique_id)(ncclUniqueId *);
+    ncclResult_t (*comm_init_rank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*comm_destroy)(ncclComm_t);
+    ncclResult_t (*all_gather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*gather_send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*gather_recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*group_start)(void);
+    ncclResult_t (*group_end)(void);
+};
+static const RcclApi *rccl() {
+    static RcclApi api{};
+    static int state = 0;                                   // 0 untried, 1 bound, -1 unavailable
+    if (state == 0) {
+        void *h = nullptr;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (int pass = 0; pass < 2 && !h; ++pass)
+            for (const char *n : names) {
+                h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (h) break;
+            }
+        bool ok = h != nullptr;
+        auto bind = [&](auto &fn, const char *sym) { if (ok) { fn = reinterpret_cast<decltype(+fn)>(dlsym(h, sym)); ok = fn != nullptr; } };
+        bind(api.get_unique_id, "ncclGetUniqueId"); bind(api.comm_init_rank, "ncclCommInitRank"); bind(api.comm_destroy, "ncclCommDestroy");
+        bind(api.all_gather, "ncclAllGather"); bind(api.gather_send, "ncclSend"); bind(api.gather_recv, "ncclRecv");
+        bind(api.group_start, "ncclGroupStart"); bind(api.group_end, "ncclGroupEnd");
+        state = ok ? 1 : -1;
+    }
+    return state == 1 ? &api : nullptr;
+}
+#define RCCL_OR_FAIL(var)                                                        \
+    const RcclApi *var = rccl();                                                 \
+    if (!var) { g_last_comm_error = (int)ncclSystemError; return CAVOID_ECOMM; }
 
 #define COMM_TRY(expr)                                 \
     do {                                               \
@@ -45,8 +83,9 @@ extern "C" int cavoid_last_comm_error(void) { return g_last_comm_error; }
 
 extern "C" int cavoid_comm_unique_id(void *id_out) {
     if (!id_out) return CAVOID_EINVAL;
+    RCCL_OR_FAIL(api);
     ncclUniqueId id;
-    COMM_TRY(ncclGetUniqueId(&id));
+    COMM_TRY(api->get_unique_id(&id));
     std::memcpy(id_out, &id, sizeof(id));
     return CAVOID_OK;
 }
@@ -73,7 +112,8 @@ extern "C" int cavoid_comm_create(const void *unique_id, int32_t nranks, int32_t
     if (nranks > 1) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id, sizeof(id));
-        ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+        const RcclApi *api = rccl();
+        ncclResult_t r = api ? api->comm_init_rank(&c->comm, nranks, id, rank) : ncclSystemError;
         if (r != ncclSuccess) {
             g_last_comm_error = (int)r;
             c->comm = nullptr;
@@ -89,7 +129,7 @@ extern "C" void cavoid_comm_destroy(cavoid_comm *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->comm && rccl()) (void)rccl()->comm_destroy(c->comm);
     for (int k = 0; k < CAVOID_COMM_SLOTS; ++k) {
         if (c->ev_ready[k]) (void)hipEventDestroy(c->ev_ready[k]);
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
@@ -107,7 +147,55 @@ extern "C" int cavoid_gather_begin(cavoid_comm *c, int32_t slot, const float *se
         if (floats_per_rank > 0 && send != recv)
             HIP_TRY(hipMemcpyAsync(recv, send, (size_t)floats_per_rank * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     } else {
-        COMM_TRY(ncclAllGather(send, recv, (size_t)floats_per_rank, ncclFloat, c->comm, c->stream));
+        RCCL_OR_FAIL(api);
+        COMM_TRY(api->all_gather(send, recv, (size_t)floats_per_rank, ncclFloat, c->comm, c->stream));
+    }
+    HIP_TRY(hipEventRecord(c->ev_done[slot], c->stream));
+    c->pending[slot] = true;
+    return CAVOID_OK;
+}
+
+// Ragged shards / gather to one rank: point-to-point over the xGMI mesh inside ONE RCCL group -- every pair of GPUs has its own
+// link, so "each rank sends its shard straight to whoever wants it" is the direct all-gather (no ring, no padding).
+// counts[r] = floats of rank r's shard (host array, identical on every rank); recv is laid out in rank order, rank r's shard at
+// offset sum(counts[0..r)).  root < 0: every rank receives every shard (all-gather-v); root >= 0: only that rank does (recv may be
+// NULL elsewhere) -- the trainer-rank variant of SURVEY.md section 8e.
+extern "C" int cavoid_gatherv_begin(cavoid_comm *c, int32_t slot, const float *send, float *recv, const int64_t *counts, int32_t root,
+                                    void *producer_stream) {
+    if (!c || !send || !counts || slot < 0 || slot >= CAVOID_COMM_SLOTS || root >= c->nranks) return CAVOID_EINVAL;
+    const bool receiver = root < 0 || root == c->rank;
+    if (receiver && !recv) return CAVOID_EINVAL;
+    int64_t my_off = 0;
+    for (int r = 0; r < c->nranks; ++r) {
+        if (counts[r] < 0) return CAVOID_EINVAL;
+        if (r < c->rank) my_off += counts[r];
+    }
+    hipStream_t prod = static_cast<hipStream_t>(producer_stream);
+    HIP_TRY(hipEventRecord(c->ev_ready[slot], prod));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ready[slot], 0));
+    const int64_t mine = counts[c->rank];
+    if (receiver && mine > 0 && send != recv + my_off)
+        HIP_TRY(hipMemcpyAsync(recv + my_off, send, (size_t)mine * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if (c->nranks > 1) {
+        RCCL_OR_FAIL(api);
+        COMM_TRY(api->group_start());
+        ncclResult_t bad = ncclSuccess;
+        int64_t off = 0;
+        for (int p = 0; p < c->nranks; ++p) {
+            if (p != c->rank) {
+                if (mine > 0 && (root < 0 || root == p)) {               // p wants my shard
+                    ncclResult_t r = api->gather_send(send, (size_t)mine, ncclFloat, p, c->comm, c->stream);
+                    if (r != ncclSuccess) bad = r;
+                }
+                if (receiver && counts[p] > 0) {
+                    ncclResult_t r = api->gather_recv(recv + off, (size_t)counts[p], ncclFloat, p, c->comm, c->stream);
+                    if (r != ncclSuccess) bad = r;
+                }
+            }
+            off += counts[p];
+        }
+        ncclResult_t end = api->group_end();                          // (always close the group, even after a failed call)
+        if (bad != ncclSuccess || end != ncclSuccess) { g_last_comm_error = (int)(bad != ncclSuccess ? bad : end); return CAVOID_ECOMM; }
     }
     HIP_TRY(hipEventRecord(c->ev_done[slot], c->stream));
     c->pending[slot] = true;

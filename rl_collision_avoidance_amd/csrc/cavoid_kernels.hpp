@@ -58,6 +58,9 @@ struct KCfg {
     double gen_nonlearning, gen_static, gen_goal_jitter, gen_angle_jitter;
     double gen_rvo, gen_box_small_lo, gen_box_small_hi, gen_box_large_lo, gen_box_large_hi, gen_min_trip;
     double rvo_inv_horizon, rvo_collab, rvo_radius_scale, rvo_max_dh;
+    double wrap_hi, wrap_lo;     // U2: an angle a folds down when a >= wrap_hi, up when a < wrap_lo: (pi, -pi) for [-pi, pi); the next
+                                 // doubles above them for (-pi, pi]
+    double gen_frozen;           // P(frozen-network agent) among the scripted ones
     int32_t max_other, width, sort_method, dynamics, actions_fp32, timeout_enabled, num_actions;
     int32_t gen_min_agents, gen_max_agents;
     int32_t gen_mode, gen_box_large_from, rvo_enabled;
@@ -69,6 +72,9 @@ struct KCfg {
     int32_t rvo_lds_floats;      // per-wavefront LDS floats of the ORCA line scratch (0 unless rvo_enabled)
     int32_t park_floats;         // N >= kParkFromN: the obs tile region is at least this large (it parks the sort keys / gaps)
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
+    int32_t skip_done_pairs;     // U4 flipped: a pair with an agent that was done before the step takes no part in E6
+    int32_t sort_round_gap;      // U7a: 1 = order by the gap rounded to centimetres (fast integer keys); 0 = exact gap (generic path)
+    int32_t sort_tie_lateral;    // U7b: 1 = ties by lateral offset then index; 0 = by index alone
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
     const double *action_table;  // [num_actions][2]
@@ -102,6 +108,8 @@ struct KIO {
     uint8_t *done;           // [W,N]; null in packed mode
     uint8_t *game_over;      // [W]
     int64_t action_stride;   // int32 elements between the action slices of consecutive steps
+    int64_t out_step_stride; // multi-step launches: step t writes its outputs into slot t -- obs + t*S*N*obs_stride, rew / done + t*S*N,
+                             // game_over + t*S with S = out_step_stride WORLDS (>= num_worlds); 0: every step overwrites slot 0
     int32_t n_steps;         // steps taken by ONE launch (MODE_STEP_AUTORESET; 1 elsewhere)
     int32_t obs_stride;      // floats per output row: width, or width + 2 in packed mode
     int32_t packed;          // != 0: reward and done (as 0.0f / 1.0f) are columns width, width+1 of the agent's row
@@ -110,14 +118,21 @@ struct KIO {
 // wrap to [-pi, pi) by repeated +-2*pi, exactly the oracle's `while` loops: one branch-free fold each way covers every
 // table action (|heading + delta| < 3*pi); anything still outside (huge continuous actions) takes the loops, as a
 // wave-uniform branch.  A fold that does not apply leaves the value untouched, so the results are bit-identical.
-__device__ __forceinline__ double wrap_angle(double a) {
-    a = a >= kPi ? a - 2.0 * kPi : a;
-    a = a < -kPi ? a + 2.0 * kPi : a;
-    if (CAVOID_RARE(__ballot(a >= kPi || a < -kPi) != 0ull)) {
-        while (a >= kPi) a -= 2.0 * kPi;
-        while (a < -kPi) a += 2.0 * kPi;
+// U2: [-pi, pi) by default (hi = pi, lo = -pi); (-pi, pi] with hi / lo = the next doubles above pi / -pi (a > pi <=> a >= next(pi)).
+__device__ __forceinline__ double wrap_angle(double a, double hi, double lo) {
+    a = a >= hi ? a - 2.0 * kPi : a;
+    a = a < lo ? a + 2.0 * kPi : a;
+    if (CAVOID_RARE(__ballot(a >= hi || a < lo) != 0ull)) {
+        while (a >= hi) a -= 2.0 * kPi;
+        while (a < lo) a += 2.0 * kPi;
     }
     return a;
+}
+// one fold each way: enough for a difference of two angles of magnitude <= pi
+__device__ __forceinline__ double wrap_once(double h, double hi, double lo) {
+    h = h >= hi ? h - 2.0 * kPi : h;
+    h = h < lo ? h + 2.0 * kPi : h;
+    return h;
 }
 
 // wave-private LDS hand-off: LDS ops of one wavefront execute in order; the fences only stop the
@@ -190,7 +205,8 @@ __device__ __forceinline__ uint32_t draw_policy(const KCfg &c, const U4 &q, int 
     if (i > 0 && u01(q.z) < c.gen_nonlearning) {
         const double u = u01(q.w);
         if (u < c.gen_static) return 1u;
-        return u < c.gen_static + c.gen_rvo ? 3u : 2u;
+        if (u < c.gen_static + c.gen_rvo) return 3u;
+        return u < c.gen_static + c.gen_rvo + c.gen_frozen ? 4u : 2u;
     }
     return 0u;
 }
@@ -293,7 +309,7 @@ struct Ego { double dist, tx, ty, prll_x, prll_y, heading_ego; };
 
 // exact form: correctly-rounded sqrt, float64 atan2.  Used where the result feeds the STATE (the
 // non-cooperative policy steers by -heading_ego).
-__device__ __forceinline__ Ego ego_frame_exact(const Agent &a) {
+__device__ __forceinline__ Ego ego_frame_exact(const KCfg &c, const Agent &a) {
     Ego e;
     e.tx = (double)a.gx - a.px;
     e.ty = (double)a.gy - a.py;
@@ -301,10 +317,7 @@ __device__ __forceinline__ Ego ego_frame_exact(const Agent &a) {
     const double inv = e.dist > 1e-8 ? 1.0 / e.dist : 1.0;
     e.prll_x = e.tx * inv;
     e.prll_y = e.ty * inv;
-    double h = a.heading - atan2(e.prll_y, e.prll_x);
-    h = h >= kPi ? h - 2.0 * kPi : h;            // |heading| <= pi and |atan2| <= pi: one fold each way
-    h = h < -kPi ? h + 2.0 * kPi : h;
-    e.heading_ego = h;
+    e.heading_ego = wrap_once(a.heading - atan2(e.prll_y, e.prll_x), c.wrap_hi, c.wrap_lo);   // |heading|, |atan2| <= pi: one fold each way
     return e;
 }
 
@@ -312,7 +325,7 @@ __device__ __forceinline__ Ego ego_frame_exact(const Agent &a) {
 // flag, a reward branch, a sort key or the state, so the long float64 sqrt/div/atan2 chains are
 // replaced by a Newton-refined v_rsq_f32 seed (relative error ~1e-14) and a float32 atan2
 // (absolute error < 1e-6 rad) -- a third of the dependent latency of the exact form.
-__device__ __forceinline__ Ego ego_from(double tx, double ty, double heading) {
+__device__ __forceinline__ Ego ego_from(const KCfg &c, double tx, double ty, double heading) {
     Ego e;
     e.tx = tx;
     e.ty = ty;
@@ -325,13 +338,10 @@ __device__ __forceinline__ Ego ego_from(double tx, double ty, double heading) {
     const double inv = tiny ? 1.0 : y;
     e.prll_x = e.tx * inv;
     e.prll_y = e.ty * inv;
-    double h = heading - (double)atan2f((float)e.ty, (float)e.tx);
-    h = h >= kPi ? h - 2.0 * kPi : h;
-    h = h < -kPi ? h + 2.0 * kPi : h;
-    e.heading_ego = h;
+    e.heading_ego = wrap_once(heading - (double)atan2f((float)e.ty, (float)e.tx), c.wrap_hi, c.wrap_lo);
     return e;
 }
-__device__ __forceinline__ Ego ego_frame_obs(const Agent &a) { return ego_from((double)a.gx - a.px, (double)a.gy - a.py, a.heading); }
+__device__ __forceinline__ Ego ego_frame_obs(const KCfg &c, const Agent &a) { return ego_from(c, (double)a.gx - a.px, (double)a.gy - a.py, a.heading); }
 
 __device__ __forceinline__ double time_to_impact(double rx, double ry, double vx, double vy, double R) {
     const double cc = rx * rx + ry * ry - R * R;
@@ -404,7 +414,10 @@ template <int N, bool PARK = false>
 __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
                                           const double *lds_px, const double *lds_py, const float *lds_r,
                                           Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K],
-                                          uint32_t &valid, bool &hit, double &min_gap, uint32_t *park = nullptr, int lane = 0) {
+                                          uint32_t &valid, bool &hit, double &min_gap, uint32_t *park = nullptr, int lane = 0,
+                                          uint32_t frozen_w = 0u) {
+    // frozen_w (U4 flipped, else 0): bit jj = agent jj of this lane's world was done before the step -- its pairs are skipped in
+    // the collision test and the nearest gap (the observation still shows it)
     constexpr int K = Others<N>::K;
     const double ri = (double)a.radius;
     valid = 0u;
@@ -412,22 +425,29 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
     min_gap = INFINITY;
     if (!PARK) { key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f; }
     auto one = [&](int o) {
-        const int j = base + other_index(i, o, N);
+        const int jj = other_index(i, o, N), j = base + jj;
         const float rjf = lds_r[j];
         const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
         const double d = sqrt_dist2(rx * rx + ry * ry);
         const bool other = present && (rjf >= 0.0f);
+        const bool collides = other && ((frozen_w >> jj) & 1u) == 0u && ((frozen_w >> i) & 1u) == 0u;
         // unordered-pair gap d - (r_lo + r_hi): the sum is commutative, both ends agree bitwise
         const double gap_c = d - (ri + (double)rjf);
-        min_gap = other ? fmin(min_gap, gap_c) : min_gap;
-        hit = hit || (other && gap_c <= c.collision_dist);
+        min_gap = collides ? fmin(min_gap, gap_c) : min_gap;
+        hit = hit || (collides && gap_c <= c.collision_dist);
         const bool seen = other && !(d > c.horizon);
         valid |= seen ? (1u << o) : 0u;
         // the observation's gap, host-side association (d - r_host) - r_other; rint(gap*100) is
         // order-isomorphic to round(gap, 2) and integer-valued: exact in int32 (|gap| < 1e7 m)
         const double gap_o = d - ri - (double)rjf;
-        const uint32_t hi = seen ? kKeyBias - (uint32_t)(int)rint(gap_o * 100.0) : 0x7FFFFFFFu;
-        const uint32_t lo = seen ? orderable((float)(ry * e.tx - rx * e.ty)) : (uint32_t)o;
+        uint32_t hi = kKeyBias - (uint32_t)(int)rint(gap_o * 100.0);
+        // U7a flipped (order by the exact gap): the float32 rounding of the gap, one bit dropped -- monotonic, so different values
+        // order exactly as the float64 gaps; equal ones fall back to the exact comparison (assemble_obs, tie_first)
+        if (CAVOID_RARE(!c.sort_round_gap)) hi = 0x7FFFFFFEu - (orderable((float)gap_o) >> 1);
+        hi = seen ? hi : 0x7FFFFFFFu;
+        // U7b flipped: the agent index (distinct per neighbour) instead of the lateral offset -- a stable sort on the bucket
+        // (and with exact gaps: nothing -- equal float32 gaps must compare EQUAL so that the exact path decides)
+        const uint32_t lo = seen ? (!c.sort_round_gap ? 0u : (c.sort_tie_lateral ? orderable((float)(ry * e.tx - rx * e.ty)) : (uint32_t)jj)) : (uint32_t)o;
         if (PARK) {
             park[(0 * K + o) * 64 + lane] = hi;
             park[(1 * K + o) * 64 + lane] = lo;
@@ -617,23 +637,44 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     // ry*tx - rx*ty orders the same), then the agent index (what a stable sort does).  Fast path: the integer
     // tournament over the 63-bit keys of the pair pass.  Two neighbours with EQUAL keys (same bucket, same float32
     // lateral) need the exact float64 laterals and the index rule: the generic path below (wave-uniform branch).
-    // index tie-break without an index array: others run in ring order j = (i+1+o) mod N, so for p < q
-    // j_p < j_q unless the wrap (at o = N-1-i) falls between them
-    const int wrap_o = N - 1 - i;
-    auto lateral = [&](int o) -> double {
-        const int j = base + other_index(i, o, N);
-        const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
-        return ry * e.tx - rx * e.ty;
-    };
-    // p, q in the same bucket: does p come first (smaller lateral offset, then smaller agent index)?
-    auto tie_first = [&](int p, int q, bool tied) -> bool {
-        bool first = false;
-        if (CAVOID_RARE(__ballot(tied) != 0ull)) {
-            const double lp = lateral(p), lq = lateral(q);
-            const bool idx_lt = (q < wrap_o) || (p >= wrap_o);
-            first = (lp < lq) || (lp == lq && idx_lt);
+    // The exact ranking (rare: two equal fast keys in the tile, the time_to_impact order): ROLLED loops over the others with every
+    // criterion re-derived from the LDS-staged state -- O(N^2) square roots at run time, but a constant amount of code (unrolled
+    // per pair, this path was a third of the kernel's code).  `among`: the candidates; near_first: the closest_first re-rank of the
+    // kept set.  Criteria, in order: [time to impact, larger first]; the gap (its centimetre bucket, or -- U7a flipped -- the exact
+    // float64 gap), larger first (smaller first when near_first); the lateral offset, smaller first (U7b flipped: skipped); the
+    // agent index (what the oracle's stable sort leaves).
+    auto rank_exact = [&](uint32_t among, bool near_first, bool use_tti) -> Slots {
+        Slots out;
+        out.clear();
+        auto criteria = [&](int o, double &g, double &l, double &t, int &jj) {
+            jj = other_index(i, o, N);
+            const int j = base + jj;
+            const double rj = (double)lds_r[j];
+            const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
+            const double gap = sqrt_dist2(rx * rx + ry * ry) - ri - rj;
+            g = c.sort_round_gap ? rint(gap * 100.0) : gap;
+            l = c.sort_tie_lateral ? ry * e.tx - rx * e.ty : 0.0;
+            t = use_tti ? time_to_impact(rx, ry, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + rj) : 0.0;
+        };
+#pragma unroll 1
+        for (int p = 0; p < NO; ++p) {
+            double gp, lp, tp;
+            int jp;
+            criteria(p, gp, lp, tp, jp);
+            int before = 0;
+#pragma unroll 1
+            for (int q = 0; q < NO; ++q) {
+                double gq, lq, tq;
+                int jq;
+                criteria(q, gq, lq, tq, jq);
+                const bool tie_break = (lq < lp) || (lq == lp && jq < jp);
+                const bool by_gap = near_first ? (gq < gp) || (gq == gp && tie_break) : (gq > gp) || (gq == gp && tie_break);
+                const bool q_first = use_tti ? (tq > tp) || (tq == tp && by_gap) : by_gap;
+                before += (q != p && ((among >> q) & 1u) && q_first) ? 1 : 0;
+            }
+            out.set(p, before);
         }
-        return first;
+        return out;
     };
     const int m = __popc(valid);
     const int first = m > M ? m - M : 0;
@@ -654,44 +695,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         }
         generic = __ballot(tie) != 0ull;                        // wave-uniform: redo this tile's ranks the exact way
     }
-    if (CAVOID_RARE(generic)) {
-        int gpos[K];
-#pragma unroll
-        for (int o = 0; o < K; ++o) gpos[o] = 0;
-        if (c.sort_method == CAVOID_SORT_TIME_TO_IMPACT) {
-            double tti[K];
-            tti[0] = 0.0;
-#pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                const int j = base + other_index(i, o, N);
-                tti[o] = time_to_impact(lds_px[j] - a.px, lds_py[j] - a.py, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + (double)lds_r[j]);
-            }
-#pragma unroll
-            for (int p = 0; p < NO; ++p)           // far -> near: larger time first, then larger gap, then smaller lateral
-#pragma unroll
-                for (int q = p + 1; q < NO; ++q) {
-                    const int gp = key_bucket(key[p]), gq = key_bucket(key[q]);
-                    const bool tied = tti[p] == tti[q] && gp == gq && ((valid >> p) & (valid >> q) & 1u);
-                    const bool p_first = (tti[p] > tti[q]) || (tti[p] == tti[q] && gp > gq) || (tied && tie_first(p, q, tied));
-                    gpos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
-                    gpos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
-                }
-        } else {
-#pragma unroll
-            for (int p = 0; p < NO; ++p)           // far -> near: larger gap first, then smaller lateral, then index
-#pragma unroll
-                for (int q = p + 1; q < NO; ++q) {
-                    const int gp = key_bucket(key[p]), gq = key_bucket(key[q]);
-                    const bool tied = gp == gq && ((valid >> p) & (valid >> q) & 1u);
-                    const bool p_first = (gp > gq) || (tied && tie_first(p, q, tied));
-                    gpos[q] += (p_first && ((valid >> p) & 1u)) ? 1 : 0;
-                    gpos[p] += (!p_first && ((valid >> q) & 1u)) ? 1 : 0;
-                }
-        }
-        pos.clear();
-#pragma unroll
-        for (int o = 0; o < NO; ++o) pos.set(o, gpos[o]);
-    }
+    if (CAVOID_RARE(generic)) pos = rank_exact(valid, false, c.sort_method == CAVOID_SORT_TIME_TO_IMPACT);
 #pragma unroll
     for (int o = 0; o < NO; ++o) keep |= (((valid >> o) & 1u) && pos.get(o) >= first) ? (1u << o) : 0u;
     // pos - first IS the slot (closest_last / time_to_impact); subtracted at the use
@@ -713,24 +717,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
 #pragma unroll
             for (int o = 0; o < NO; ++o) pos.set(o, tour.position(o));
         }
-        if (__ballot(tie) != 0ull) {
-            pos.clear();
-            int gpos[K];
-#pragma unroll
-            for (int o = 0; o < K; ++o) gpos[o] = 0;
-#pragma unroll
-            for (int p = 0; p < NO; ++p)
-#pragma unroll
-                for (int q = p + 1; q < NO; ++q) {
-                    const int gp = key_bucket(key[p]), gq = key_bucket(key[q]);
-                    const bool tied = gp == gq && ((keep >> p) & (keep >> q) & 1u);
-                    const bool p_first = (gp < gq) || (tied && tie_first(p, q, tied));
-                    gpos[q] += (p_first && ((keep >> p) & 1u)) ? 1 : 0;
-                    gpos[p] += (!p_first && ((keep >> q) & 1u)) ? 1 : 0;
-                }
-#pragma unroll
-            for (int o = 0; o < NO; ++o) pos.set(o, gpos[o]);
-        }
+        if (CAVOID_RARE(__ballot(tie) != 0ull)) pos = rank_exact(keep, true, false);
     }
 
     CAVOID_STAMP(9);                                             // ranks done
@@ -968,8 +955,8 @@ __device__ __forceinline__ void rvo_action(const KCfg &c, const Agent &a, int i,
     double delta = 0.0;
     if (speed > 0.0) {
         delta = atan2(vy, vx) - a.heading;
-        while (delta >= kPi) delta -= 2.0 * kPi;
-        while (delta < -kPi) delta += 2.0 * kPi;
+        while (delta >= c.wrap_hi) delta -= 2.0 * kPi;
+        while (delta < c.wrap_lo) delta += 2.0 * kPi;
     }
     if (fabs(delta) > c.rvo_max_dh) { delta = copysign(c.rvo_max_dh, delta); speed = 0.0; }
     a0 = speed; a1 = delta;
@@ -1126,11 +1113,12 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
     int act = act_next;
     if (kLoop && t + 1 < n_steps && active) act_next = io.actions[(int64_t)(t + 1) * io.action_stride + a_idx];
+    const int64_t slot_w = kLoop ? (int64_t)t * io.out_step_stride : 0;   // first world row of this step's output slot
 
     if (kStepping) {
         // ---- E4 decode ------------------------------------------------------------------------------
         wave_lds_sync();
-        const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
+        const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK;   // (4 = frozen network: its action index comes in like a learner's)
         double a0 = 0.0, a1 = 0.0;
         if (io.cont) { a0 = (double)c0; a1 = (double)c1; }
         else {
@@ -1141,7 +1129,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
         if (CAVOID_RARE(__ballot(present_in && !done_in && pol != 0u) != 0ull)) {   // scripted agents in this tile
             if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
             if (pol == 2u) {                                            // straight at the goal, full speed
-                const Ego e0 = ego_frame_exact(a);
+                const Ego e0 = ego_frame_exact(c, a);
                 a0 = (double)a.pref;
                 a1 = -e0.heading_ego;
             }
@@ -1175,7 +1163,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
                 const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
                 dh = rate * c.dt;
             }
-            nh = wrap_angle(dh + a.heading);
+            nh = wrap_angle(dh + a.heading, c.wrap_hi, c.wrap_lo);
             double sn, cs;
             sincos_bounded(nh, &sn, &cs);
             npx = a.px + a0 * cs * c.dt; npy = a.py + a0 * sn * c.dt;
@@ -1201,13 +1189,17 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = a.vx; lds_vy[lane] = a.vy;
     lds_r[lane] = present ? a.radius : -1.0f;              // radius < 0 marks an absent row
     wave_lds_sync();
-    Ego e = ego_frame_obs(a);
+    Ego e = ego_frame_obs(c, a);
     Key key[Others<N>::K];
     float gapf[Others<N>::K];
     uint32_t valid;
     bool hit;
     double min_gap;
-    pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, reinterpret_cast<uint32_t *>(tile), lane);
+    uint32_t frozen_w = 0u;                                 // U4 flipped: the agents of this lane's world that were done before the step
+    if (kStepping && CAVOID_RARE(c.skip_done_pairs))
+        frozen_w = (uint32_t)(__ballot(present_in && done_in) >> base) & ((1u << N) - 1u);
+    pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, reinterpret_cast<uint32_t *>(tile), lane,
+                        frozen_w);
 
     CAVOID_STAMP(4);                                        // ego frame + pair pass done
     float rew_f = 0.0f, done_f = (present && (a.flags & CAVOID_F_DONE_MASK) == 0u) ? 0.0f : 1.0f;   // reset / observe, packed
@@ -1233,10 +1225,10 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
         done_f = done ? 1.0f : 0.0f;
         if (active) {
             if (!packed) {
-                io.rew[a_idx] = rew_f;
-                io.done[a_idx] = done ? 1 : 0;
+                io.rew[slot_w * N + a_idx] = rew_f;
+                io.done[slot_w * N + a_idx] = done ? 1 : 0;
             }
-            if (i == 0) io.game_over[w] = game_over ? 1 : 0;
+            if (i == 0) io.game_over[slot_w + w] = game_over ? 1 : 0;
         }
         if (kAuto) {
             const bool restart = active && game_over;
@@ -1256,7 +1248,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
                 }
                 wave_lds_sync();
                 if (restart) {
-                    e = ego_frame_obs(a);
+                    e = ego_frame_obs(c, a);
                     bool hit2;
                     double gap2;
                     pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit2, gap2, reinterpret_cast<uint32_t *>(tile), lane);
@@ -1270,7 +1262,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     if (io.obs) {
         CAVOID_STAMP(6);
         assemble_obs<N, kPark>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, key, gapf, valid, tile,
-                        io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave);
+                        io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave);
     }
     CAVOID_STAMP(7);                                        // tile flushed
     if (kLoop && n_steps > 1) wave_lds_sync();             // the next step re-stages the LDS arrays and the tile
@@ -1398,7 +1390,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 if (t + 1 < n_steps && active) act_next = io.actions[(int64_t)(t + 1) * io.action_stride + a_idx];
                 // ---- E4 decode -----------------------------------------------------------------------------------------
                 wave_lds_sync();
-                const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
+                const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK;   // (4 = frozen network: its action index comes in like a learner's)
                 double a0 = 0.0, a1 = 0.0;
                 act = act < 0 ? 0 : (act >= c.num_actions ? c.num_actions - 1 : act);
                 a0 = (double)a.pref * lds_tab[2 * act];
@@ -1406,7 +1398,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 if (CAVOID_RARE(__ballot(present_in && !done_in && pol != 0u) != 0ull)) {   // scripted agents in this tile
                     if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
                     if (pol == 2u) {
-                        const Ego e0 = ego_frame_exact(a);
+                        const Ego e0 = ego_frame_exact(c, a);
                         a0 = (double)a.pref;
                         a1 = -e0.heading_ego;
                     }
@@ -1432,7 +1424,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                     const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
                     dh = rate * c.dt;
                 }
-                const double nh = wrap_angle(dh + a.heading);
+                const double nh = wrap_angle(dh + a.heading, c.wrap_hi, c.wrap_lo);
                 double sn, cs;
                 sincos_bounded(nh, &sn, &cs);
                 const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
@@ -1462,7 +1454,9 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 uint32_t valid;
                 bool hit;
                 double min_gap;
-                pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit, min_gap);
+                uint32_t frozen_w = 0u;
+                if (CAVOID_RARE(c.skip_done_pairs)) frozen_w = (uint32_t)(__ballot(present_in && done_in) >> base) & ((1u << N) - 1u);
+                pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit, min_gap, nullptr, 0, frozen_w);
                 CAVOID_STAMP(4);
                 // ---- E7 rewards, E8 done -------------------------------------------------------------------------------
                 double r = 0.0;
@@ -1482,11 +1476,12 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 const bool game_over = (running & wmask) == 0ull;
                 const float rew_f = (float)r, done_f = done ? 1.0f : 0.0f;
                 if (active) {
+                    const int64_t slot_w = (int64_t)t * io.out_step_stride;
                     if (!packed) {
-                        io.rew[a_idx] = rew_f;
-                        io.done[a_idx] = done ? 1 : 0;
+                        io.rew[slot_w * N + a_idx] = rew_f;
+                        io.done[slot_w * N + a_idx] = done ? 1 : 0;
                     }
-                    if (i == 0) io.game_over[w] = game_over ? 1 : 0;
+                    if (i == 0) io.game_over[slot_w + w] = game_over ? 1 : 0;
                 }
                 const bool restart = active && game_over;
                 if (__ballot(restart) != 0ull) {
@@ -1530,14 +1525,15 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
             ao.heading = rc.heading[lane]; ao.t_rem = 0.0;
             ao.gx = ao.gy = ao.speed = 0.0f;
             ao.radius = rc.radius[lane]; ao.pref = rc.pref[lane]; ao.flags = rc.flags[lane];
-            const Ego e = ego_from(rc.tx[lane], rc.ty[lane], ao.heading);
+            const Ego e = ego_from(c, rc.tx[lane], rc.ty[lane], ao.heading);
             Key key[Others<N>::K];
             float gapf[Others<N>::K];
             key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f;
 #pragma unroll
             for (int o = 0; o < N - 1; ++o) { key[o].hi = rc.key_hi[o][lane]; key[o].lo = rc.key_lo[o][lane]; gapf[o] = rc.gap[o][lane]; }
             assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, st.px, st.py, st.vx, st.vy, st.r, key, gapf, rc.valid[lane], tile,
-                            io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rc.rew[lane], rc.done[lane], wave);
+                            io.obs + ((int64_t)(k - 1) * io.out_step_stride + w0) * N * ostride, (int)worlds_here * N, ostride, packed,
+                            rc.rew[lane], rc.done[lane], wave);
             CAVOID_STAMP(7);
         }
         __syncthreads();

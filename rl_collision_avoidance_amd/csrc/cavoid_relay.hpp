@@ -152,13 +152,13 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &t
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
-    const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & 3u;
+    const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK;
     double a0 = (double)a.pref * tab_speed;               // the action's table row, read one step ahead by the caller
     double a1 = tab_dh;
     if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {
         if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
         if (pol == 2u) {
-            const Ego e0 = ego_frame_exact(a);
+            const Ego e0 = ego_frame_exact(c, a);
             a0 = (double)a.pref;
             a1 = -e0.heading_ego;
         }
@@ -170,7 +170,7 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &t
         const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
         dh = rate * c.dt;
     }
-    const double nh = wrap_angle(dh + a.heading);
+    const double nh = wrap_angle(dh + a.heading, c.wrap_hi, c.wrap_lo);
     double sn, cs;
     relay_sincos(trig, nh, &sn, &cs);
     const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         __builtin_amdgcn_s_setprio(3);
         KCfg cd = c;                                        // this role's constants, pinned in scalar registers (see P)
         asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.max_turn_rate), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
-                     "+s"(cd.timeout_enabled));
+                     "+s"(cd.timeout_enabled), "+s"(cd.wrap_hi), "+s"(cd.wrap_lo));
         const RelayTrig trig = relay_trig_constants();
         Agent a;
         a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const uint32_t ctl_c = v.ctl[lane];
             const float rew_c = v.rew[lane], done_c = (ctl_c & 1u) ? 1.0f : 0.0f;
             const bool present = active && (ao.flags & CAVOID_F_PRESENT);
-            const Ego e = ego_frame_obs(ao);
+            const Ego e = ego_frame_obs(c, ao);
             Key key[Others<N>::K];
             float gapf[Others<N>::K];
             uint32_t valid;
@@ -559,21 +559,22 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             double min_gap;
             pair_pass<N>(c, ao, e, present, i, base, f.px, f.py, f.r, key, gapf, valid, hit, min_gap);
             RELAY_STAMP(18);                               // C: ego frame + keys
-            const bool last = t == n_steps - 1;
+            const bool last = t == n_steps - 1 && io.out_step_stride == 0;   // (with per-step slots no two steps share an address)
+            const int64_t slot_w = (int64_t)t * io.out_step_stride;
             auto order_last = [&]() {                      // the last step's rows go out after every earlier step's have landed
                 if (last)
                     for (int o = 0; o < NC; ++o)
                         if (o != cid) relay_wait_bounded(&seq->cfin[o], 1);
             };
             assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
-                                         io.obs + w0 * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,
+                                         io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,
                                          order_last);
             if (active) {                                  // the step's plain outputs (behind order_last, like the rows)
                 if (!packed) {
-                    io.rew[a_idx0] = rew_c;
-                    io.done[a_idx0] = (ctl_c & 1u) ? 1 : 0;
+                    io.rew[slot_w * N + a_idx0] = rew_c;
+                    io.done[slot_w * N + a_idx0] = (ctl_c & 1u) ? 1 : 0;
                 }
-                if (i0 == 0) io.game_over[w] = (ctl_c & 2u) ? 1 : 0;
+                if (i0 == 0) io.game_over[slot_w + w] = (ctl_c & 2u) ? 1 : 0;
             }
             relay_post(&seq->cons[cid], t + 1);
             RELAY_STAMP(19);                               // C: rows flushed

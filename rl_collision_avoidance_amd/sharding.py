@@ -112,6 +112,19 @@ class NativeGather(object):
         self._libmod.check(self._lib.cavoid_gather_begin(self._h, slot, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
                                                          send.numel(), self._stream()), "cavoid_gather_begin")
 
+    def begin_v(self, slot: int, send: torch.Tensor, recv: Optional[torch.Tensor], counts, root: int = -1) -> None:
+        """Ragged / rooted form: ``counts[r]`` floats from rank r (the same list on every rank), shards laid out in rank
+        order in ``recv``; ``root >= 0``: only that rank receives (``recv`` may be None on the others)."""
+        if send.dtype != torch.float32 or not send.is_contiguous() or len(counts) != self.size or send.numel() != counts[self.rank]:
+            raise ValueError("send must be this rank's contiguous float32 shard of counts[rank] floats")
+        receiver = root < 0 or root == self.rank
+        if receiver and (recv is None or recv.dtype != torch.float32 or not recv.is_contiguous() or recv.numel() != sum(counts)):
+            raise ValueError("recv must be a contiguous float32 tensor of sum(counts) floats")
+        arr = (C.c_int64 * self.size)(*[int(c) for c in counts])
+        self._libmod.check(self._lib.cavoid_gatherv_begin(self._h, slot, C.c_void_p(send.data_ptr()),
+                                                          C.c_void_p(recv.data_ptr()) if receiver else None, arr, int(root),
+                                                          self._stream()), "cavoid_gatherv_begin")
+
     def wait(self, slot: int) -> None:
         """Make the current stream wait for the last gather begun in `slot` (no host synchronisation)."""
         self._libmod.check(self._lib.cavoid_gather_wait(self._h, slot, self._stream()), "cavoid_gather_wait")
@@ -160,31 +173,65 @@ class ShardedEnv(object):
         return gather_step_outputs(self._packed, self.total_worlds, self.group)
 
     # -- the native path: packed records straight from the kernel, ncclAllGather behind the C ABI, overlapped ---------
-    def _native_setup(self):
-        if self.total_worlds % self.size:
-            raise ValueError("the native gather needs equal shards (total_worlds %% world_size == 0)")
+    def _native_setup(self, steps: int = 1, root: int = -1):
+        """Buffers of the native hand-over: per slot a send buffer of `steps` packed records of this shard and, on the
+        receiving ranks, a recv buffer [steps, total_worlds, N, width+2].  Equal shards of one step go through ONE
+        ncclAllGather; ragged shards, several steps per launch (the per-rank blocks are then not contiguous in world order) or a
+        single receiving rank (`root`) go through the point-to-point gather (`cavoid_gatherv_begin`)."""
+        from .batched_env import StepSlots
         e = self.env
         self._native = NativeGather(e.device, self.group)
-        self._send = [e.new_packed() for _ in range(NativeGather.SLOTS)]
-        self._recv = [torch.zeros((self.total_worlds, e.max_agents, e.packed_width), dtype=torch.float32, device=e.device)
+        self._steps, self._root = int(steps), int(root)
+        self._counts = [shard_range(self.total_worlds, r, self.size)[1] for r in range(self.size)]
+        self._even = all(c == self._counts[0] for c in self._counts)
+        self._send = [StepSlots(e, steps, packed=True) for _ in range(NativeGather.SLOTS)]
+        receiver = root < 0 or root == self.rank
+        rec = e.max_agents * e.packed_width
+        # wire layout: rank-major blocks, rank r's block = [steps, count_r, N, width+2]
+        self._recv = [torch.zeros((steps * self.total_worlds * rec,), dtype=torch.float32, device=e.device) if receiver else None
                       for _ in range(NativeGather.SLOTS)]
+        self._floats = [steps * c * rec for c in self._counts]
 
-    def step_and_gather(self, actions: torch.Tensor) -> int:
-        """One auto-reset step of this shard into a packed buffer + the all-gather of it, begun but not waited for:
-        the NEXT call's step runs while this gather is on the wire.  Returns the slot; `gathered(slot)` makes the
-        current stream wait for it and returns [total_worlds, N, width+2] (valid until the slot's next use)."""
+    def step_and_gather(self, actions: torch.Tensor, root: int = -1) -> int:
+        """One auto-reset step (actions [Wl,N]) -- or K steps in ONE launch (actions [K,Wl,N], every step's records in its own
+        slot) -- of this shard into a packed buffer + the gather of it, begun but not waited for: the NEXT call's launch
+        runs while this gather is on the wire.  `root >= 0`: only that rank receives (the trainer rank).  Returns the slot;
+        `gathered(slot)` makes the current stream wait for it and returns the records of ALL worlds."""
+        steps = 1 if actions.dim() == 2 else int(actions.shape[0])
         if self._native is None:
-            self._native_setup()
+            self._native_setup(steps, root)
+        if steps != self._steps or root != self._root:
+            raise ValueError("step_and_gather was set up for %d step(s) per launch, root %d" % (self._steps, self._root))
         slot = self._t % NativeGather.SLOTS
         self._t += 1
         self._native.wait(slot)                     # gather(t-2) is done with send[slot] / recv[slot]
-        self.env.step_autoreset_packed(actions, self._send[slot])
-        self._native.begin(slot, self._send[slot], self._recv[slot])
+        sl = self._send[slot]
+        if steps == 1:
+            self.env.step_autoreset_packed(actions, sl.packed[0])
+        else:
+            self.env.step_autoreset_packed(actions, sl)
+        if self._even and steps == 1 and root < 0:
+            self._native.begin(slot, sl.packed, self._recv[slot])
+        else:
+            self._native.begin_v(slot, sl.packed, self._recv[slot], self._floats, root)
         return slot
 
-    def gathered(self, slot: int) -> torch.Tensor:
+    def gathered(self, slot: int) -> Optional[torch.Tensor]:
+        """[total_worlds, N, width+2] (one step per launch) or [K, total_worlds, N, width+2]; None on a rank that does not
+        receive.  Valid until the slot's next use."""
         self._native.wait(slot)
-        return self._recv[slot]
+        recv = self._recv[slot]
+        if recv is None:
+            return None
+        e, K = self.env, self._steps
+        if K == 1:
+            return recv.view(self.total_worlds, e.max_agents, e.packed_width)
+        # rank-major blocks -> [K, total_worlds, ...] (a view when there is one rank, else one gather-side copy per rank block)
+        blocks, off = [], 0
+        for c, f in zip(self._counts, self._floats):
+            blocks.append(recv[off:off + f].view(K, c, e.max_agents, e.packed_width))
+            off += f
+        return blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)
 
     def close(self) -> None:
         if self._native is not None:

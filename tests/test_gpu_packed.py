@@ -170,6 +170,121 @@ def test_multi_step_packed_run_against_the_oracle():
     env.close()
 
 
+def _oracle_run(env, N, seed, acts, gen_min=None, nonl=0.0, **cfg_over):
+    ocfg = co.default_cfg(N, **cfg_over)
+    ogen = co.default_gen(N if gen_min is None else gen_min, N, nonl, pool_size=int(env.cfg.gen_pool_size))
+    W = env.num_worlds
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    outs = []
+    for t in range(acts.shape[0]):
+        outs.append(co.step_autoreset(ocfg, ogen, seed, st, ep, acts[t].cpu().numpy()))
+    return outs, st, ep
+
+
+@pytest.mark.parametrize("N,W,pipe,gen_min,nonl", [
+    (4, 512, None, 4, 0.0),       # env_relay_kernel (BASELINE configs[1] shape; 32 tiles)
+    (4, 512, "1", 4, 0.0),        # env_pipe_kernel
+    (4, 512, "0", 4, 0.0),        # one wavefront per tile, register prefetch
+    (4, 40000, None, 2, 0.3),     # beyond latency mode: MODE_STEP_AUTORESET_N, on-demand pool gather
+    (10, 300, None, 2, 0.3),      # configs[3] shape (pipeline)
+    (3, 200, None, 2, 0.2),
+])
+def test_every_step_of_a_multi_step_launch_lands_in_its_slot_and_matches_the_oracle(N, W, pipe, gen_min, nonl, monkeypatch):
+    """cavoid_step_autoreset_n with out_step_stride: slot t of the [K,W,N,.] outputs holds what env.step returned AT step t
+    (ProcessAgent.py:149-157 consumes rewards / done / the next observation of EVERY step) -- compared with the float64
+    oracle's step t for every t, in every form of the in-launch step loop; and the packed-record form of the same."""
+    if pipe is not None:
+        monkeypatch.setenv("CAVOID_PIPELINE", pipe)
+    K, seed = 37, 19
+    kw = dict(gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
+    env, twin = _env(W, N, seed=seed, **kw), _env(W, N, seed=seed, **kw)
+    monkeypatch.delenv("CAVOID_PIPELINE", raising=False)
+    env.reset(); twin.reset()
+    acts = _acts(K, W, N, 4)
+    slots = env.new_step_slots(K)
+    pslots = twin.new_step_slots(K, packed=True)
+    obs, rew, done, go = env.step_autoreset_n(acts, slots=slots)
+    twin.step_autoreset_packed(acts, pslots)
+    assert obs.shape == (K, W, N, env.obs_width) and go.shape == (K, W)
+    outs, st, ep = _oracle_run(env, N, seed, acts, gen_min, nonl)
+    width = env.obs_width
+    restarts = 0
+    for t, (oobs, orew, odone, ogo) in enumerate(outs):
+        o = obs[t].cpu().numpy()
+        d = np.abs(o - oobs)
+        d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2 * np.pi))
+        assert d.max() <= 1e-5, (t, d.max())
+        assert np.abs(rew[t].cpu().numpy() - orew).max() <= 1e-5, t
+        assert np.array_equal(done[t].cpu().numpy(), odone), t
+        assert np.array_equal(go[t].cpu().numpy(), ogo), t
+        restarts += int(ogo.sum())
+    assert restarts > 0
+    assert np.array_equal(env.get_state()[2].cpu().numpy().view(np.uint32), st.flags)
+    assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep)
+    # the packed form: the same bits, one record per agent and step
+    assert torch.equal(pslots.packed[..., :width], obs) and torch.equal(pslots.packed[..., width], rew)
+    assert torch.equal(pslots.packed[..., width + 1], done.float()) and torch.equal(pslots.game_over, go)
+    # a shorter launch into the same slots touches only its own
+    before = obs[5:].clone()
+    env.step_autoreset_n(acts[:5], slots=slots)
+    assert torch.equal(obs[5:], before)
+    # and the overwrite form (out_step_stride = 0) leaves the LAST step's outputs, as before
+    twin2 = _env(W, N, seed=seed, **kw)
+    twin2.reset()
+    o2, r2, d2, g2 = twin2.step_autoreset_n(acts)
+    assert torch.equal(o2, pslots.packed[K - 1, ..., :width]) and torch.equal(g2, pslots.game_over[K - 1])
+    for e in (env, twin, twin2):
+        e.close()
+
+
+def test_step_slots_argument_checks():
+    import ctypes as C
+    from rl_collision_avoidance_amd import _lib
+    W, N = 64, 4
+    env = _env(W, N)
+    env.reset()
+    acts = _acts(8, W, N, 0)
+    lib = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    slots = env.new_step_slots(8)
+    # slots that overlap (stride < W) are refused; a NULL obs is fine in the single-wavefront forms and refused by none
+    rc = lib.cavoid_step_autoreset_n(env._h, p(acts), W * N, 8, W - 1, p(slots.obs), p(slots.rewards), p(slots.done), p(slots.game_over), None)
+    assert rc == -1
+    rc = lib.cavoid_step_autoreset_n(env._h, p(acts), W * N, 8, W, None, p(slots.rewards), p(slots.done), p(slots.game_over), None)
+    assert rc == 0                                            # obs = NULL: rewards / done / game_over only (no fault)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError):
+        env.step_autoreset_n(acts, slots=env.new_step_slots(4))
+    with pytest.raises(ValueError):
+        env.step_autoreset_n(acts, slots=env.new_step_slots(8, packed=True))
+    env.close()
+
+
+def test_native_gather_of_multi_step_blocks_and_to_a_root_single_rank():
+    """K steps per launch, every step's packed records gathered as one block (cavoid_gatherv_begin: the ragged / rooted /
+    multi-step form) -- with one rank a device copy through the same double-buffered protocol."""
+    from rl_collision_avoidance_amd.sharding import ShardedEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+    W, N, K, seed = 1000, 4, 6, 13
+    for root in (-1, 0):
+        sh = ShardedEnv(W, EnvConfig(), device=torch.device("cuda", 0), seed=seed)
+        ref = _env(W, N, seed=seed)
+        sh.reset(); ref.reset()
+        acts = _acts(5 * K, W, N, 8)
+        rs = ref.new_step_slots(K, packed=True)
+        prev = None
+        for r in range(5):
+            slot = sh.step_and_gather(acts[r * K:(r + 1) * K], root=root)
+            ref.step_autoreset_packed(acts[r * K:(r + 1) * K], rs)
+            if prev is not None:
+                assert torch.equal(sh.gathered(prev[0]), prev[1]), r - 1
+            prev = (slot, rs.packed.clone())
+        assert torch.equal(sh.gathered(prev[0]), prev[1])
+        sh.close(); ref.close()
+
+
 def test_configs2_eight_shards_of_8192_equal_one_65536_world_env():
     """BASELINE configs[2] on one GPU: the concatenated packed (obs | reward | done) buffers of 8 shard envs equal the
     unsharded env's, bitwise, over 50 auto-reset steps (global-world-id RNG keying + the gather layout at full size)."""

@@ -211,6 +211,116 @@ def test_u_switches_follow_the_oracle():
     env.close()
 
 
+@pytest.mark.parametrize("over", [dict(wrap_closed_end=1), dict(done_agents_collide=0), dict(sort_round_gap=0),
+                                  dict(sort_tie_lateral=0),
+                                  dict(wrap_closed_end=1, done_agents_collide=0, sort_round_gap=0, sort_tie_lateral=0)])
+@pytest.mark.parametrize("N,sort", [(4, 0), (10, 1), (5, 2)])
+def test_u2_u4_u7_switches_follow_the_oracle(over, N, sort):
+    """SURVEY App. A U2 (wrap end), U4 (done agents still collide with movers), U7 (gap rounding / tie-break) are named
+    switches of cavoid_cfg, mirrored in both oracles and the kernels: flipped on both sides, single steps and the in-launch
+    step loop."""
+    W, steps, seed = 300, 100, 8
+    ocfg, ogen = _oracle(N, None, 2, 0.3, sort_method=sort, **over)
+    env = _env(W, N, seed=seed, sort_method=sort, gen_min_agents=2, gen_nonlearning_fraction=0.3, **over)
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    env.reset()
+    _push(env, st)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = _goal_seeking_actions(rng, W, N)
+        out = env.step_autoreset(torch.from_numpy(acts).cuda())
+        _compare_step(("U247", over, t), out, co.step_autoreset(ocfg, ogen, seed, st, ep, acts), env, st)
+    assert (st.flags & 7 != 0).any() and ep.max() >= 1
+    K = 24
+    acts = np.stack([_goal_seeking_actions(rng, W, N) for _ in range(K)])
+    slots = env.new_step_slots(K)
+    obs, rew, done, go = env.step_autoreset_n(torch.from_numpy(acts).cuda(), slots=slots)
+    for t in range(K):
+        oobs, orew, odone, ogo = co.step_autoreset(ocfg, ogen, seed, st, ep, acts[t])
+        assert np.array_equal(done[t].cpu().numpy(), odone) and np.array_equal(go[t].cpu().numpy(), ogo), t
+        d = np.abs(obs[t].cpu().numpy() - oobs)
+        d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2 * np.pi))
+        assert d.max() <= OBS_TOL and np.abs(rew[t].cpu().numpy() - orew).max() <= OBS_TOL, t
+    assert np.array_equal(_pull(env)[2], st.flags)
+    env.close()
+
+
+def test_u_switch_known_answers_on_the_gpu():
+    """The hand-made cases of tests/test_oracle.py::test_u_switch_known_answers through the HIP path (no oracle in the loop)."""
+    # U4: a timed-out agent in the mover's path
+    for collide in (1, 0):
+        env = _env(1, 2, done_agents_collide=collide)
+        f64 = torch.tensor([[0.0, 1.15], [0.0, 0.0], [0.0, 0.0], [50.0, 50.0]], dtype=torch.float64).cuda()
+        f32 = torch.tensor([[10.0, 10.0], [0.0, 5.0], [0.5, 0.5], [1.0, 1.0], [0.0, 0.0]], dtype=torch.float32).cuda()
+        fl = torch.tensor([0x20 | 0x40, 0x20 | 0x40 | 0x02], dtype=torch.int32).cuda()
+        env.set_state(f64, f32, fl)
+        obs, rew, done, go = env.step(torch.tensor([[2, 2]], dtype=torch.int32).cuda())
+        flags = env.get_state()[2].cpu().numpy()
+        if collide:
+            assert rew.cpu().tolist() == [[-0.25, -0.25]] and flags[0] & 4 and flags[1] & 4
+        else:
+            assert rew.cpu().tolist() == [[0.0, 0.0]] and not flags[0] & 4 and not flags[1] & 4
+        assert obs[0, 0, 1].item() == 1.0 and obs[0, 0, 6 + 6].item() < 0.0
+        env.close()
+    # U7: two neighbours 4 mm apart in gap; slot k's p_orth identifies the neighbour
+    for round_gap, tie_lat, want in ((1, 1, (2, 1)), (0, 1, (1, 2)), (1, 0, (1, 2))):
+        env = _env(1, 3, sort_round_gap=round_gap, sort_tie_lateral=tie_lat)
+        f64 = torch.tensor([[0.0, 0.0, 0.0], [0.0, 2.004, -2.0], [0.0, 0.0, 0.0], [50.0, 50.0, 50.0]], dtype=torch.float64).cuda()
+        f32 = torch.tensor([[10.0, 5.0, 5.0], [0.0, 5.0, -5.0], [0.3, 0.3, 0.3], [1.0, 1.0, 1.0], [0.0, 0.0, 0.0]], dtype=torch.float32).cuda()
+        env.set_state(f64, f32, torch.full((3,), 0x20 | 0x40, dtype=torch.int32).cuda())
+        row = env.observe()[0, 0].cpu().numpy()
+        order = tuple(1 if row[6 + 7 * k + 1] > 0 else 2 for k in range(2))
+        assert order == want, (round_gap, tie_lat, order)
+        env.close()
+    # U2: an agent turned to exactly +-pi keeps the sign the switch says
+    for closed, want in ((0, -np.pi), (1, np.pi)):
+        env = _env(1, 1, wrap_closed_end=closed, actions=[[1.0, np.pi]], actions_fp32=0)
+        f64 = torch.tensor([[0.0], [0.0], [0.0], [50.0]], dtype=torch.float64).cuda()
+        f32 = torch.tensor([[10.0], [0.0], [0.3], [1.0], [0.0]], dtype=torch.float32).cuda()
+        env.set_state(f64, f32, torch.tensor([0x20 | 0x40], dtype=torch.int32).cuda())
+        env.step(torch.zeros((1, 1), dtype=torch.int32).cuda())
+        assert env.get_state()[0][2, 0].item() == want
+        env.close()
+
+
+@pytest.mark.parametrize("N,mode,pool", [(4, 0, 300), (6, 1, 200)])
+def test_frozen_network_agents_parity_and_row_list(N, mode, pool):
+    """Scripted policy 4 (the GA3C-CADRL agent mechanism): non-learning agents whose action index the caller
+    supplies; cavoid_policy_rows lists them for the frozen network.  HIP vs oracle incl. the generator's draw."""
+    from rl_collision_avoidance_amd import _lib
+    W, steps, seed = 400, 120, 5
+    ocfg, _ = _oracle(N)
+    ogen = co.default_gen(2, N, 0.6, 0.2, mode=mode, rvo_fraction=0.0, frozen_fraction=0.6, pool_size=pool)
+    env = _env(W, N, seed=seed, gen_min_agents=2, gen_nonlearning_fraction=0.6, gen_static_fraction=0.2, gen_frozen_fraction=0.6,
+               gen_mode=mode, gen_pool_size=pool)
+    env.reset()
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    f64, f32, fl = _pull(env)
+    assert np.array_equal(fl, st.flags)
+    pol = (st.flags >> 8) & 7
+    assert (pol == 4).sum() > 50 and (pol == 2).any() and (pol == 1).any()
+    _push(env, st)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        rows, count = env.policy_rows(_lib.POLICY_FROZEN_NET)
+        n = int(count.item())
+        got = np.sort(rows[:n].cpu().numpy())
+        want = np.nonzero(((st.flags >> 8) & 7 == 4) & (st.flags & 0x20 != 0) & (st.flags & 7 == 0))[0]
+        assert np.array_equal(got, want), t
+        acts = _goal_seeking_actions(rng, W, N)
+        out = env.step_autoreset(torch.from_numpy(acts).cuda())
+        _compare_step(("frozen", t), out, co.step_autoreset(ocfg, ogen, seed, st, ep, acts), env, st)
+        obs = out[0].cpu().numpy()
+        present4 = (((st.flags >> 8) & 7) == 4).reshape(W, N)
+        assert (obs[..., 0][present4] == 0.0).all()                  # never "learning"
+    assert ep.max() >= 1
+    env.close()
+
+
 def test_full_size_properties():
     """BASELINE configs[1] size (4 agents x 8192 worlds): size-independent properties.
     (a) worlds are independent: a 8192-world batch == the same worlds run as two 4096 shards with
@@ -533,14 +643,14 @@ def test_rvo_agents_and_box_generator_parity(N, M, mode, nonl, static, rvo, gen_
     assert np.array_equal(fl, st.flags) and np.array_equal(f32, st.f32)
     np.testing.assert_allclose(f64, st.f64, rtol=0, atol=1e-12)
     np.testing.assert_allclose(obs0, co.observe(ocfg, st), rtol=0, atol=OBS_TOL)
-    assert ((st.flags >> 8) & 3 == 3).sum() > 20                   # RVO agents exist
+    assert ((st.flags >> 8) & 7 == 3).sum() > 20                   # RVO agents exist
     _push(env, st)                                                  # continue from the oracle's (1e-16 different) headings
     rng = np.random.default_rng(seed)
     for t in range(steps):
         acts = _goal_seeking_actions(rng, W, N)
         out = env.step(torch.from_numpy(acts).cuda())
         _compare_step(("rvo", N, mode, t), out, co.step(ocfg, st, acts), env, st)
-    rvo_agents = (st.flags >> 8) & 3 == 3
+    rvo_agents = (st.flags >> 8) & 7 == 3
     assert (st.flags[rvo_agents] & 1).mean() > 0.4                 # most RVO agents arrive
     env.close()
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     handle = _lib.lib()
     for name in declared:
         assert hasattr(handle, name)
-    assert handle.cavoid_abi_version() == _lib.ABI_VERSION == 2
+    assert handle.cavoid_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_error_codes_without_gpu():

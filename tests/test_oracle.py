@@ -11,11 +11,12 @@ from oracle import c_oracle as co
 from oracle import cavoid_oracle as po
 
 
-def _cross(N, M, sort, nonl, W=12, steps=100, seed=7, dyn=0, mode=0, rvo=0.0):
-    pcfg = po.OracleConfig(max_agents=N, max_other_agents_observed=M, sort_method=sort, dynamics=dyn)
-    pgen = po.GenConfig(min_agents=2, max_agents=N, nonlearning_fraction=nonl, mode=mode, rvo_fraction=rvo)
-    ccfg = co.default_cfg(N, M, sort_method=sort, dynamics=dyn)
-    cgen = co.default_gen(2, N, nonl, mode=mode, rvo_fraction=rvo)
+def _cross(N, M, sort, nonl, W=12, steps=100, seed=7, dyn=0, mode=0, rvo=0.0, frozen=0.0, **switches):
+    pcfg = po.OracleConfig(max_agents=N, max_other_agents_observed=M, sort_method=sort, dynamics=dyn,
+                           **{k: bool(v) for k, v in switches.items()})
+    pgen = po.GenConfig(min_agents=2, max_agents=N, nonlearning_fraction=nonl, mode=mode, rvo_fraction=rvo, frozen_fraction=frozen)
+    ccfg = co.default_cfg(N, M, sort_method=sort, dynamics=dyn, **{k: int(v) for k, v in switches.items()})
+    cgen = co.default_gen(2, N, nonl, mode=mode, rvo_fraction=rvo, frozen_fraction=frozen)
     st = co.State.empty(W, N)
     ep = np.zeros(W, np.uint32)
     co.generate(ccfg, cgen, seed, st, ep)
@@ -62,6 +63,65 @@ def test_python_and_c_agree_on_rvo_agents_and_the_box_generator(N, M, sort, nonl
     pol = (st.flags >> po.F_POLICY_SHIFT) & 3
     if rvo > 0:
         assert (pol == po.POLICY_RVO).any()
+
+
+@pytest.mark.parametrize("switches", [dict(wrap_closed_end=1), dict(done_agents_collide=0), dict(sort_round_gap=0),
+                                      dict(sort_tie_lateral=0), dict(wrap_closed_end=1, done_agents_collide=0, sort_round_gap=0,
+                                                                     sort_tie_lateral=0)])
+def test_python_and_c_agree_with_the_u_switches_flipped(switches):
+    """SURVEY App. A U2 (wrap end), U4 (done agents collide with movers), U7 (gap rounding / tie-break) as named switches:
+    both statements follow them, bit for bit (scripted + RVO + frozen-network agents in the mix)."""
+    for sort in (0, 1, 2):
+        _cross(5, 3, sort, 0.5, W=10, steps=90, seed=5, rvo=0.3, frozen=0.2, **switches)
+
+
+def test_u_switch_known_answers():
+    """What each switch changes, on hand-made cases."""
+    # U2: an angle exactly on the cut
+    assert po.wrap(math.pi) == -math.pi and po.wrap(math.pi, True) == math.pi
+    assert po.wrap(-math.pi) == -math.pi and po.wrap(-math.pi, True) == math.pi
+    assert po.wrap(3 * math.pi) == -math.pi + 0.0 or abs(po.wrap(3 * math.pi)) <= math.pi
+    # U4: agent 1 has timed out (frozen) in agent 0's path
+    for collide in (True, False):
+        cfg = po.OracleConfig(max_agents=2, max_other_agents_observed=1, done_agents_collide=collide)
+        a = po.Agent(0.0, 0.0, 10.0, 0.0, 0.5, 1.0, None, po.POLICY_EXTERNAL, cfg)
+        b = po.Agent(1.15, 0.0, 10.0, 5.0, 0.5, 1.0, None, po.POLICY_EXTERNAL, cfg)
+        b.ran_out_of_time = True
+        w = po.World([a, b], cfg)
+        obs, rew, over, info = w.step({0: 2, 1: 2})               # agent 0 moves 0.2 m: gap 1.15 - 0.2 - 1.0 < 0
+        if collide:
+            assert rew[0] == -0.25 and a.in_collision and rew[1] == -0.25 and b.in_collision
+        else:
+            assert rew[0] == 0.0 and not a.in_collision and rew[1] == 0.0 and not b.in_collision
+        assert obs[0, 1] == 1.0 and obs[0, 6 + 6] < 0.0               # still observed, gap negative
+    # U7a: two neighbours 4 mm apart in gap: same centimetre bucket -> lateral decides; exact gaps -> the gap decides
+    # U7b: without the lateral criterion the agent index decides
+    for round_gap, tie_lat, want in ((True, True, (2, 1)), (False, True, (1, 2)), (True, False, (1, 2))):
+        cfg = po.OracleConfig(max_agents=3, max_other_agents_observed=2, sort_round_gap=round_gap, sort_tie_lateral=tie_lat)
+        host = po.Agent(0.0, 0.0, 10.0, 0.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+        n1 = po.Agent(0.0, 2.004, 5.0, 5.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)      # farther by 4 mm, lateral +2
+        n2 = po.Agent(0.0, -2.0, 5.0, -5.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)      # lateral -2
+        row = po.World([host, n1, n2], cfg).observe()[0]
+        # closest_last: far ... near; slot k's p_orth identifies the neighbour
+        order = tuple(1 if row[6 + 7 * k + 1] > 0 else 2 for k in range(2))
+        assert order == want, (round_gap, tie_lat, order)
+
+
+def test_frozen_network_agents_take_outside_actions_and_never_count_as_learning():
+    cfg = po.OracleConfig(max_agents=2, max_other_agents_observed=1)
+    a = po.Agent(0.0, 0.0, 3.0, 0.0, 0.3, 1.0, None, po.POLICY_EXTERNAL, cfg)
+    b = po.Agent(0.0, 20.0, 9.0, 20.0, 0.3, 1.0, None, po.POLICY_FROZEN_NET, cfg)
+    w = po.World([a, b], cfg)
+    obs, rew, over, info = w.step({0: 2, 1: 0})                       # the frozen-network agent turns by -pi/6 at full speed
+    assert obs[0, 0] == 1.0 and obs[1, 0] == 0.0
+    assert info["which_agents_learning"] == {0: True, 1: False}
+    assert abs(b.heading + math.pi / 6) < 1e-6 and abs(b.speed - 1.0) < 1e-12
+    assert (b.flags() >> po.F_POLICY_SHIFT) & po.F_POLICY_MASK == po.POLICY_FROZEN_NET
+    for _ in range(40):
+        obs, rew, over, info = w.step({0: 2, 1: 2})
+        if over:
+            break
+    assert over and a.is_at_goal and not b.is_done                    # TRAIN_MODE: only the learner ends the episode
 
 
 def test_rvo_agents_avoid_each_other_and_arrive():
