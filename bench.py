@@ -132,7 +132,7 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
     per_graph = int(os.environ.get("CAVOID_STEPS_PER_GRAPH", "8"))   # env steps per hipGraph replay (even): one drain (a host sync) per replay
 
-    def regime(fused: bool, train: bool, fused_trainer: bool = False):
+    def regime(fused: bool, train: bool, fused_trainer: bool = False, actor_kernel: bool = False):
         env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
         net = NetworkVP_rnn(cfg).to(device)
         pol = FusedPolicy(net, seed=rank) if fused else None
@@ -141,7 +141,10 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         trainer = FusedA3CTrainer(net, pol, distributed=False) if fused_trainer else A3CTrainer(net, distributed=False)
         roll = BatchedRollout(env, pol if fused else net.predict_p_and_v, reflush_done=False)
         roll.reset()
-        roll.capture(steps_per_graph=per_graph)              # policy + sampling + env.step + bookkeeping as ONE graph
+        if actor_kernel:                                     # the same per_graph steps as ONE launch of the fused actor kernel
+            roll.capture_fused(steps_per_graph=per_graph)
+        else:
+            roll.capture(steps_per_graph=per_graph)          # policy + sampling + env.step + bookkeeping as ONE graph
         rows = [0]
 
         def run(n_replays):
@@ -216,7 +219,12 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
             out.update({"issued_TFLOPs": flop / fused_us * 1e-6, "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3,
                         "bound": "mfma", "dtype": "f32", "kernel": "cavoid::policy_forward_kernel"})
         return out
-    res = {"policy_kernel": policy_kernel(), "actors_only_fused_policy": regime(True, False),
+    # actor_kernel = cavoid_actor_run: policy -> sample -> env.step -> experience push per 64-row tile, K steps per launch, no kernel
+    # boundary inside the loop; the *_graph regimes run the same steps as one launch per phase (5 launches per env step) in a hipGraph
+    res = {"policy_kernel": policy_kernel(),
+           "actors_only_actor_kernel": regime(True, False, actor_kernel=True),
+           "actors_only_fused_policy": regime(True, False),
+           "full_loop_actor_kernel_fused_trainer": regime(True, True, True, actor_kernel=True),
            "full_loop_fused_policy_fused_trainer": regime(True, True, True)}
     if not brief:                                            # the PyTorch comparison legs take most of the time
         res["full_loop_fused_policy_autograd_trainer"] = regime(True, True)

@@ -130,7 +130,8 @@ typedef struct cavoid_cfg {
      * gen_box_large_from agents, ~ U(gen_box_large) otherwise), agents placed one after the other by rejection sampling
      * against those already placed (starts and goals at least r_i + r_j + getting_close_range apart, trips of at least
      * gen_min_trip) -- the shape of upstream's get_testcase_random as recalled (TEST_CASE_FN, run-ws/config.yaml:281-283).
-     * cavoid_reset generates directly; auto-reset steps take GEN v2 scenarios from the pool (gen_pool_size > 0). */
+     * cavoid_reset and the auto-reset steps generate in-kernel (the placement is sequential over a world's agents: the wavefront
+     * that owns the world generates it cooperatively) or, with gen_pool_size > 0, take GEN v2 scenarios from the pool. */
     int32_t gen_mode;
     int32_t gen_box_large_from;   /* 5 */
     uint32_t gen_pool_epoch;      /* the pool holds generator worlds 0..P-1 of THIS episode index (cavoid_pool_refresh) */
@@ -149,6 +150,8 @@ typedef struct cavoid_cfg {
 } cavoid_cfg;
 
 typedef struct cavoid_env cavoid_env;
+typedef struct cavoid_rollout cavoid_rollout;   /* (section 'rollout' below) */
+typedef struct cavoid_policy cavoid_policy;     /* (section 'fused policy inference' below) */
 
 int cavoid_abi_version(void);
 const char *cavoid_strerror(int code);
@@ -268,7 +271,6 @@ int cavoid_policy_rows(cavoid_env *env, int32_t policy_id, int32_t only_running,
  *   every later step); dup_count int32 [2] = (appended, dropped), reset by the caller.
  *   ep_out float [ep_capacity,3] (world, total_reward, total_length), ep_count int32 [2].
  *   step < 0: use (and advance) the handle's device-side step counter (hipGraph replays). */
-typedef struct cavoid_rollout cavoid_rollout;
 int cavoid_rollout_create(int64_t num_worlds, int32_t max_agents, int32_t obs_width, int32_t time_max, double discount,
                           int32_t reflush_done, int32_t ring_len, int device, cavoid_rollout **out);
 void cavoid_rollout_destroy(cavoid_rollout *r);
@@ -278,6 +280,30 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
                         float *x, double *val, float *ret, uint8_t *act, int32_t *emit_t,
                         float *dup_x, float *dup_r, int32_t *dup_a, int32_t *dup_src, int32_t *dup_count, int64_t dup_capacity,
                         float *ep_out, int32_t *ep_count, int64_t ep_capacity, void *stream);
+
+/* ---- the fused actor: K closed-loop steps of EVERY world in ONE launch ------------------------------------------------
+ * observe -> predict_p_and_v -> select_action -> env.step -> Experience bookkeeping, K times (ProcessAgent.run_episode's loop body,
+ * ga3c/GA3C/ProcessAgent.py:116-211, with the ThreadPredictor round trip of :89-96 and ThreadPredictor.py:61-75 inside it): per
+ * tile of floor(64/N) worlds a workgroup runs cavoid_policy_forward's arithmetic on the tile's rows, draws the actions, steps
+ * the tile's worlds (cavoid_step_autoreset's arithmetic) and records the step (cavoid_rollout_push's arithmetic) -- no kernel
+ * boundary, no host, nothing between workgroups.  Results are bit-identical to calling those three entry points K times.
+ *   obs_cur [W,N,1+D]: the observation to act on first; obs_next: a second buffer of the same shape -- step t reads one and
+ *   writes the other, so after the call the current observation is in obs_cur when n_steps is even, in obs_next when odd.
+ *   rewards / done / game_over / actions int32 [W,N] / values float [W,N]: per-step outputs, holding the LAST step's afterwards.
+ *   buffers: the experience store of cavoid_rollout_push.  The policy's launch counter and the rollout's step counter advance
+ *   by n_steps on the device (the call can sit in a hipGraph).
+ * CAVOID_EUNSUPPORTED (use the step-by-step entry points): rvo_enabled, holonomic dynamics, CAVOID_POLICY_F32, GEN v2 without
+ * a scenario pool. */
+typedef struct cavoid_rollout_buffers {
+    int32_t struct_size;             /* sizeof(cavoid_rollout_buffers) */
+    int32_t reserved;
+    float *x; double *val; float *ret; uint8_t *act; int32_t *emit_t;               /* the rings of cavoid_rollout_push */
+    float *dup_x; float *dup_r; int32_t *dup_a; int32_t *dup_src; int32_t *dup_count; int64_t dup_capacity;
+    float *ep_out; int32_t *ep_count; int64_t ep_capacity;
+} cavoid_rollout_buffers;
+int cavoid_actor_run(cavoid_env *env, cavoid_policy *policy, cavoid_rollout *rollout, const cavoid_rollout_buffers *buffers,
+                     float *obs_cur, float *obs_next, float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values,
+                     int32_t n_steps, int32_t greedy, void *stream);
 
 /* hand-over to the trainer (`training_q.put((x_, r_, a_))`, ProcessAgent.py:238): append the training rows (emit_t >= 0) of
  * the step blocks [step_lo, step_hi) to one batch -- out_x float [capacity, D], out_r float [capacity] (n-step returns),
@@ -312,7 +338,6 @@ int cavoid_rollout_active_rows(cavoid_rollout *r, const float *obs, const uint8_
  *                          actions_out (nullable) int32 [rows]: greedy != 0 -> argmax p (PLAY_MODE /
  *                          EVALUATE_MODE), else one inverse-CDF sample per row from Philox4x32-10 keyed on
  *                          (seed, row, launch counter); the counter lives on the device (hipGraph replays). */
-typedef struct cavoid_policy cavoid_policy;
 typedef struct cavoid_policy_weights {
     int32_t struct_size;             /* sizeof(cavoid_policy_weights) */
     float min_policy;                /* Config.MIN_POLICY */

@@ -63,6 +63,13 @@ class CavoidPolicyTrainBuffers(C.Structure):
         (n, C.c_void_p) for n in ("z1", "z2", "z3", "l1_in", "h_in", "save", "gh", "loss", "g1", "g2", "g3", "gl", "db")]
 
 
+class CavoidRolloutBuffers(C.Structure):
+    """Mirror of ``struct cavoid_rollout_buffers`` (include/cavoid.h): the experience store handed to ``cavoid_actor_run``."""
+    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("x", "val", "ret", "act", "emit_t", "dup_x", "dup_r", "dup_a", "dup_src", "dup_count")] + [
+        ("dup_capacity", C.c_int64), ("ep_out", C.c_void_p), ("ep_count", C.c_void_p), ("ep_capacity", C.c_int64)]
+
+
 class CavoidError(RuntimeError):
     def __init__(self, code: int, where: str):
         msg = lib().cavoid_strerror(code).decode()
@@ -115,6 +122,7 @@ SYMBOLS = [
     ("cavoid_rollout_destroy", None, [_P]),
     ("cavoid_rollout_reset", C.c_int, [_P, _P]),
     ("cavoid_rollout_push", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32] + [_P] * 10 + [C.c_int64, _P, _P, C.c_int64, _P]),
+    ("cavoid_actor_run", C.c_int, [_P, _P, _P, C.POINTER(CavoidRolloutBuffers)] + [_P] * 7 + [C.c_int32, C.c_int32, _P]),
     ("cavoid_rollout_compact", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32] + [_P] * 9 + [C.c_int64, _P]),
     ("cavoid_rollout_active_rows", C.c_int, [_P] * 7),
     ("cavoid_policy_forward_rows", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),

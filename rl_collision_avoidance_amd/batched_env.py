@@ -48,6 +48,15 @@ def make_cfg(config: Optional[EnvConfig] = None, **overrides) -> _lib.CavoidCfg:
     possible = [config.REWARD_AT_GOAL, config.REWARD_COLLISION_WITH_AGENT, config.REWARD_TIME_STEP,
                 config.REWARD_COLLISION_WITH_WALL, config.REWARD_WIGGLY_BEHAVIOR]
     cfg.reward_clip_lo, cfg.reward_clip_hi = min(possible), max(possible)
+    # scenario generator / scripted agents
+    cfg.gen_mode = {"ring": 0, "box": 1}[getattr(config, "TEST_CASE_GENERATOR", "ring")]
+    cfg.gen_nonlearning_fraction = float(getattr(config, "SCRIPTED_AGENT_FRACTION", 0.0))
+    cfg.gen_static_fraction = float(getattr(config, "SCRIPTED_STATIC_FRACTION", 0.5))
+    cfg.gen_rvo_fraction = float(getattr(config, "SCRIPTED_RVO_FRACTION", 0.0))
+    cfg.gen_frozen_fraction = float(getattr(config, "SCRIPTED_FROZEN_NET_FRACTION", 0.0))
+    cfg.rvo_enabled = 1 if cfg.gen_rvo_fraction > 0.0 and cfg.gen_nonlearning_fraction > 0.0 else 0
+    cfg.rvo_time_horizon = float(getattr(config, "RVO_TIME_HORIZON", 5.0))
+    cfg.rvo_collab_coeff = float(getattr(config, "RVO_COLLAB_COEFF", 0.5))
     for key, val in overrides.items():
         if key == "actions":
             table = np.asarray(val, dtype=np.float64)

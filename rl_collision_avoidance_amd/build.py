@@ -12,21 +12,26 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
 SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_multistep.hip"), os.path.join(CSRC, "cavoid_rvo.hip"),
            os.path.join(CSRC, "cavoid_relay.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
-           os.path.join(CSRC, "cavoid_policy_capi.hip"), os.path.join(CSRC, "cavoid_comm_capi.hip")]
+           os.path.join(CSRC, "cavoid_policy_capi.hip"), os.path.join(CSRC, "cavoid_comm_capi.hip"), os.path.join(CSRC, "cavoid_actor.hip")]
 HEADERS = {
     "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_multistep.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rvo.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_relay.hip": ["cavoid_kernels.hpp", "cavoid_relay.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
-    "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_host.hpp"],
-    "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_policy_split.hpp", "cavoid_host.hpp"],
+    "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_rollout_host.hpp", "cavoid_host.hpp"],
+    "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_policy_split.hpp", "cavoid_policy_host.hpp", "cavoid_host.hpp"],
+    "cavoid_actor.hip": ["cavoid_actor.hpp", "cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp", "cavoid_policy_split.hpp",
+                         "cavoid_policy_host.hpp", "cavoid_rollout.hpp", "cavoid_rollout_host.hpp", "cavoid_host.hpp"],
     "cavoid_comm_capi.hip": ["cavoid_host.hpp"],
 }
 # per-file extra flags.  The multi-step env kernels run their step loop inside the launch; MachineLICM would hoist every
 # constant materialisation of the body (float64 polynomial coefficients, config scalars) out of that loop into
 # registers live across it: 128 VGPRs + 276 B/lane of scratch instead of 128 VGPRs + 12 B (N = 4).
 EXTRA_FLAGS = {"cavoid_multistep.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_rvo.hip": ["-mllvm", "-disable-machine-licm"],
-               "cavoid_relay.hip": ["-mllvm", "-disable-machine-licm"]}
+               "cavoid_relay.hip": ["-mllvm", "-disable-machine-licm"],
+               # the fused actor kernel runs policy + env step + bookkeeping inside ONE step loop: same reason (without it the
+               # GEMM loops' fragment addresses are hoisted across the loop: 256 VGPRs + 232 B/lane of scratch instead of 243 + 0)
+               "cavoid_actor.hip": ["-mllvm", "-disable-machine-licm"]}
 STAMP_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so.stamp")
 DEPS = SOURCES + [os.path.join(CSRC, h) for hs in HEADERS.values() for h in hs] + [os.path.join(ROOT, "include", "cavoid.h")]
 OBJ_DIR = os.path.join(PKG_DIR, "build")
@@ -97,9 +102,12 @@ def _link(objs, out: str, verbose: bool) -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
+        digest = source_digest()             # of what is about to be compiled (a source edited meanwhile must read as stale)
+        if os.path.exists(STAMP_PATH):
+            os.remove(STAMP_PATH)
         _link(_compile_objects([], "", force, verbose), LIB_PATH, verbose)
         with open(STAMP_PATH, "w") as f:
-            f.write(source_digest() + "\n")
+            f.write(digest + "\n")
     return LIB_PATH
 
 
@@ -110,6 +118,25 @@ def build_trace(verbose: bool = False) -> str:
     return _link(_compile_objects(["-DCAVOID_TRACE"], ".trace", False, verbose), out, verbose)
 
 
+def build_fault(verbose: bool = False) -> str:
+    """Development variant with a broken relay hand-over (-DCAVOID_FAULT_RELAY: the pair-pass wavefront of tile 0 leaves at step
+    5), for tests/test_gpu_relay_fault.py: only cavoid_relay.hip is recompiled, the other objects are the product's."""
+    objs = _compile_objects([], "", False, verbose)
+    src = os.path.join(CSRC, "cavoid_relay.hip")
+    obj = os.path.join(OBJ_DIR, "cavoid_relay.fault.o")
+    cmd = [hipcc()] + FLAGS + EXTRA_FLAGS["cavoid_relay.hip"] + ["-DCAVOID_FAULT_RELAY", "-DCAVOID_DEV_ONLY_N", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs = [obj if o.endswith("cavoid_relay.o") else o for o in objs]
+    return _link(objs, os.path.join(PKG_DIR, "libcavoid_hip_fault.so"), verbose)
+
+
 if __name__ == "__main__":
     import sys
-    print(build_trace(verbose=True) if "--trace" in sys.argv else build(force=True, verbose=True))
+    if "--trace" in sys.argv:
+        print(build_trace(verbose=True))
+    elif "--fault" in sys.argv:
+        print(build_fault(verbose=True))
+    else:
+        print(build(force=True, verbose=True))

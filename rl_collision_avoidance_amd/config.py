@@ -52,7 +52,20 @@ class EnvConfig(object):
                                   'pref_speed', 'radius', 'other_agents_states']
         if not hasattr(self, "STATES_NOT_USED_IN_POLICY"):
             self.STATES_NOT_USED_IN_POLICY = ['is_learning']
-        self.TEST_CASE_FN = "get_testcase_random"   # :281-283 (here: the library's GEN v1 generator)
+        self.TEST_CASE_FN = "get_testcase_random"   # :281-283 (upstream's generator and its np.random stream are unknowable:
+        # SURVEY App. A U9; the library's own counter-based generators stand in, selected by the attributes below)
+        # --- scenario generator and scripted agents (the reference's training data used "static / non-coop /
+        #     RVO" mixes, checkpoints/RL/wandb/run-2018-backup/checkpoints/index.txt:1-3).  Subclasses may set them before __init__.
+        for name, default in (("TEST_CASE_GENERATOR", "ring"),        # "ring" = GEN v1 (antipodal goals), "box" = GEN v2 (random boxes)
+                              ("SCRIPTED_AGENT_FRACTION", 0.0),       # P(an agent other than agent 0 runs a scripted policy)
+                              ("SCRIPTED_STATIC_FRACTION", 0.5),      # of those: P(static)
+                              ("SCRIPTED_RVO_FRACTION", 0.0),         # ... P(RVO / ORCA)
+                              ("SCRIPTED_FROZEN_NET_FRACTION", 0.0),  # ... P(driven by a frozen network: the GA3C-CADRL agent);
+                                                                      #     the rest are non-cooperative
+                              ("RVO_TIME_HORIZON", 5.0),              # run-ws/config.yaml:237-239
+                              ("RVO_COLLAB_COEFF", 0.5)):             # :234-236
+            if not hasattr(self, name):
+                setattr(self, name, default)
         self.ACTION_SPACE_TYPE = 0            # continuous at the gym level; discretised by the policy
         self.NUM_TEST_CASES = 50
         self.USE_STATIC_MAP = False

@@ -1,0 +1,88 @@
+// cavoid_actor.hip -- C ABI (include/cavoid.h, cavoid_actor_run) over actor_kernel<N> (cavoid_actor.hpp): K closed-loop GA3C actor
+// steps -- policy forward, action selection, env.step, experience bookkeeping -- in ONE launch.  Own translation unit (the
+// kernel carries the policy's GEMM loops and the env step; instantiated per agent count).
+#include <hip/hip_runtime.h>
+
+#include "cavoid.h"
+#include "cavoid_actor.hpp"
+#include "cavoid_host.hpp"
+#include "cavoid_launch.hpp"
+#include "cavoid_policy_host.hpp"
+#include "cavoid_rollout_host.hpp"
+
+using namespace cavoid;
+
+template <int N>
+static int launch_actor(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
+                        hipStream_t s) {
+    static bool opted_in = false;                            // > 64 KiB of dynamic LDS: opted into once per instantiation
+    if (!opted_in) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(actor_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)policy_split_lds_bytes()));
+        opted_in = true;
+    }
+    const int64_t tiles = (e->W + e->k.wpw - 1) / e->k.wpw;
+    hipLaunchKernelGGL((actor_kernel<N>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, e->k, e->st, e->pool, sa, rc, rs, rio, io);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout *r, const cavoid_rollout_buffers *b, float *obs_cur, float *obs_next,
+                                float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values, int32_t n_steps,
+                                int32_t greedy, void *stream) {
+    if (!e || !h || !r || !b || b->struct_size != (int32_t)sizeof(cavoid_rollout_buffers) || !obs_cur || !obs_next || obs_cur == obs_next ||
+        !rewards || !done || !game_over || !actions || !values || n_steps < 0)
+        return CAVOID_EINVAL;
+    if (!b->x || !b->val || !b->ret || !b->act || !b->emit_t || !b->dup_x || !b->dup_r || !b->dup_a || !b->dup_src || !b->dup_count ||
+        !b->ep_out || !b->ep_count || b->dup_capacity < 1 || b->ep_capacity < 1)
+        return CAVOID_EINVAL;
+    if (n_steps == 0) return CAVOID_OK;
+    if (!h->loaded) return CAVOID_EINVAL;
+    // the three handles must describe the same batch
+    if (h->device != e->device || r->device != e->device || r->c.num_slots != e->A || r->c.max_agents != e->cfg.max_agents ||
+        r->c.obs_width != e->k.width || h->in_size != e->k.width - 1 || h->max_other != e->cfg.max_other)
+        return CAVOID_EINVAL;
+    // what the fused kernel does not carry (the step-by-step entry points do): ORCA agents, velocity actions, the float32-MFMA
+    // inference kernel, box scenarios generated inside the step (with a pool they are fine)
+    if (e->cfg.rvo_enabled || e->cfg.dynamics == CAVOID_DYN_HOLONOMIC || !h->use_split || (e->cfg.gen_mode == 1 && e->pool_size <= 0))
+        return CAVOID_EUNSUPPORTED;
+    const KCfg &k = e->k;
+    int tile = (k.tile_rows * k.width + 3) & ~3;
+    if (tile < k.park_floats) tile = k.park_floats;
+    if (actor_env_lds_bytes(tile) > (size_t)2 * kSpPlaneB) return CAVOID_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    PolicyArgs a{};
+    a.rows = e->A; a.stride = k.width; a.max_other = h->max_other; a.num_actions = h->num_actions; a.in_size = h->in_size;
+    a.avg = h->normalize ? h->avg : nullptr; a.std = h->normalize ? h->std : nullptr;
+    a.frags = h->frags; a.bias = h->bias; a.min_policy = h->min_policy;
+    a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
+    a.step_counter = h->step_counter; a.blocks_done = h->blocks_done; a.cu_tickets = h->cu_tickets;
+    const SplitArgs sa{a, h->sfrags};
+    RolloutCfg rc = r->c;
+    rc.dup_capacity = b->dup_capacity; rc.ep_capacity = b->ep_capacity;
+    RolloutIO rio{};
+    rio.step = -1; rio.x = b->x; rio.val = b->val; rio.ret = b->ret; rio.act = b->act; rio.emit_t = b->emit_t;
+    rio.dup_x = b->dup_x; rio.dup_r = b->dup_r; rio.dup_a = b->dup_a; rio.dup_src = b->dup_src; rio.dup_count = b->dup_count;
+    rio.ep_out = b->ep_out; rio.ep_count = b->ep_count;
+    ActorIO io{};
+    io.obs[0] = obs_cur; io.obs[1] = obs_next; io.rewards = rewards; io.done = done; io.game_over = game_over;
+    io.actions = actions; io.values = values; io.rollout_step = r->s.step_counter; io.n_steps = n_steps; io.greedy = greedy ? 1 : 0;
+    int rc_launch = CAVOID_EUNSUPPORTED;
+#define CAVOID_ACTOR_CASE(NN) case NN: rc_launch = launch_actor<NN>(e, sa, rc, r->s, rio, io, s); break;
+    switch (e->cfg.max_agents) {
+#ifdef CAVOID_DEV_ONLY_N
+        CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(10)
+#else
+        CAVOID_ACTOR_CASE(1) CAVOID_ACTOR_CASE(2) CAVOID_ACTOR_CASE(3) CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(5) CAVOID_ACTOR_CASE(6)
+        CAVOID_ACTOR_CASE(7) CAVOID_ACTOR_CASE(8) CAVOID_ACTOR_CASE(9) CAVOID_ACTOR_CASE(10) CAVOID_ACTOR_CASE(11) CAVOID_ACTOR_CASE(12)
+        CAVOID_ACTOR_CASE(13) CAVOID_ACTOR_CASE(14) CAVOID_ACTOR_CASE(15) CAVOID_ACTOR_CASE(16)
+#endif
+        default: break;
+    }
+#undef CAVOID_ACTOR_CASE
+    if (rc_launch != CAVOID_OK) return rc_launch;
+    hipLaunchKernelGGL(actor_finish_kernel, dim3(1), dim3(1), 0, s, r->s.step_counter, h->step_counter, n_steps);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}

@@ -1,0 +1,147 @@
+// cavoid_actor.hpp -- actor_kernel<N>: the GA3C actor's CLOSED loop, K env steps in ONE launch.
+//
+// What one reference ProcessAgent does per env step (ga3c/GA3C/ProcessAgent.py:116-211): observe -> predict (RPC to
+// ThreadPredictor, ThreadPredictor.py:61-75) -> select_action -> env.step -> Experience bookkeeping / n-step returns.  Here, for
+// a tile of floor(64/N) worlds x N agents = up to 64 policy rows, one workgroup of four wavefronts runs that loop K times
+// without leaving the GPU or the launch:
+//
+//   all 4 wavefronts   NetworkVP_rnn forward of the tile's 64 rows on the matrix cores (policy_split_tile, the statements of
+//                      policy_forward_split_kernel) + the Philox action draw  -> actions / values of the tile
+//   wavefront 0        env.step of the tile (env_tile<N, MODE_STEP_AUTORESET>: the statements of env_kernel, LDS carved out of the
+//                      policy's activation planes, which are idle now) -> obs(t+1), reward, done, game_over;
+//                      then the experience bookkeeping of the tile's slots (rollout_push_slot: the statements of
+//                      rollout_push_kernel) and the episode log
+//   wavefronts 1..3    meanwhile: the step's state rows -> the time-major experience ring (rollout_copy_rows)
+//
+// Worlds are independent and a tile's policy rows are exactly its own agents, so NOTHING crosses workgroups: no grid barrier,
+// no kernel boundary between policy, env and bookkeeping (five launches and ~8 dependent boundaries per env step in the
+// hipGraph form).  Two workgroups share a CU; their phases drift apart, so one tile's env step (one busy wavefront) runs under
+// the other tile's matrix phase.  State between the phases travels through global memory (L2-resident; same-CU visibility
+// after the workgroup barrier), exactly as between the launches of the hipGraph form: every value is computed by the same
+// statements in the same order, so trajectories, experience rings and episode logs are bit-identical to that form
+// (tests/test_gpu_actor.py).
+#pragma once
+#include "cavoid_kernels.hpp"
+#include "cavoid_policy_split.hpp"
+#include "cavoid_rollout.hpp"
+
+namespace cavoid {
+
+struct ActorIO {
+    float *obs[2];            // [W,N,1+D] each: step t acts on obs[t & 1]; the env writes the next observation into obs[(t+1) & 1]
+    float *rewards;           // [W,N]   the env's step outputs; after the launch they hold the LAST step's
+    uint8_t *done;            // [W,N]
+    uint8_t *game_over;       // [W]
+    int32_t *actions;         // [W,N]   select_action's choice (hand-over policy -> env inside a step; last step's afterwards)
+    float *values;            // [W,N]   V(s_t) (the bootstrap of a flush)
+    int32_t *rollout_step;    // device-side step index of the experience store (advanced by actor_finish_kernel)
+    int32_t n_steps;
+    int32_t greedy;           // PLAY_MODE / EVALUATE_MODE: argmax instead of sampling
+};
+
+// LDS the env step of a tile needs inside the (idle) activation planes: the action table + one wavefront's staging arrays and
+// obs tile
+__host__ __device__ inline size_t actor_env_lds_bytes(int tile_floats) {
+    return (size_t)(lds_floats_block() + lds_floats_fixed() + tile_floats) * sizeof(float);
+}
+
+template <int N>
+__global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KState s, const PoolRec *pool, const SplitArgs sa,
+                                                       const RolloutCfg rc, const RolloutState rs, const RolloutIO rio_arg, const ActorIO io) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // the policy's activation planes ...
+    float *len_f = reinterpret_cast<float *>(planes + 2 * kSpPlaneB);
+    int *wave_max = reinterpret_cast<int *>(len_f + 64) + 64;
+    int &ticket = wave_max[4];
+    double *lds_tab = reinterpret_cast<double *>(planes);                        // ... lent to the env step while they are idle
+    float *wbase = reinterpret_cast<float *>(planes) + lds_floats_block();
+
+    const PolicyArgs &p = sa.p;
+    const int tid0 = threadIdx.x;
+    const int wpw = c.wpw, A = p.num_actions, ow = c.width;
+    const int64_t tile = blockIdx.x, w0 = tile * wpw, a0 = w0 * N;
+    int64_t worlds_here = c.num_worlds - w0;
+    worlds_here = worlds_here > wpw ? wpw : (worlds_here < 0 ? 0 : worlds_here);
+    const int rows = (int)worlds_here * N;                   // policy rows = agent slots of this tile
+    const int32_t step0 = *io.rollout_step, pstep0 = *p.step_counter;
+
+    if (tid0 == 0) {                                         // arrival parity on the CU -> static priority (see cavoid_policy.hpp)
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        const uint32_t key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
+        ticket = (int)atomicAdd(p.cu_tickets + key, 1u);
+    }
+    __syncthreads();
+    if (ticket & 1) __builtin_amdgcn_s_setprio(1);
+
+#pragma unroll 1
+    for (int t = 0; t < io.n_steps; ++t) {
+        // Everything derived from the thread id is loop invariant, and the compiler would hoist all of it -- every weight-fragment
+        // and LDS address of the GEMM loops, every lane-to-world index of the env step -- out of the step loop into registers live
+        // across the whole body (measured: 256 VGPRs + 1.2 KB of scratch per lane).  Re-materialising the id per step keeps each
+        // phase's register footprint that of its stand-alone kernel.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int wave_in_block = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const float *obs_t = io.obs[t & 1];
+        float *obs_n = io.obs[(t + 1) & 1];
+        const int32_t step = step0 + t;
+        const int blk = step % rc.ring_len;
+
+        // ---- predict_p_and_v + select_action for the tile's rows, read in place from the observation the env wrote -----------
+        {
+            const float *src = obs_t + a0 * ow + 1;            // column 0 (is_learning) is not a network input
+            auto load = [&](int r, int k) -> float { return src[(int64_t)r * ow + k]; };
+            auto emit = [&](int trow, int g, const float (&pj)[4], const f32x4 &logit) {
+                const int64_t row = a0 + trow;
+                const int action = split_select_action(pj, g, lane, A, io.greedy != 0, row, pstep0 + t, p.seed_lo, p.seed_hi);
+                if (trow < rows) {
+                    if (g == 0) io.actions[row] = action;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r == A) io.values[row] = logit[r];
+                }
+            };
+            policy_split_tile(sa, planes, len_f, wave_max, rows, tid, load, emit);
+        }
+        __syncthreads();                                     // the tile's actions / values are in memory; the planes are idle
+
+        if (wave_in_block == 0) {
+            // ---- env.step of the tile ------------------------------------------------------------------------------------
+            KIO k{};
+            k.actions = io.actions; k.obs = obs_n; k.rew = io.rewards; k.done = io.done; k.game_over = io.game_over;
+            k.obs_stride = ow; k.n_steps = 1;
+            StepOut so{0.0f, true, false};
+            env_tile<N, MODE_STEP_AUTORESET, false>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
+            // ---- Experience bookkeeping of the tile's slots (one lane per slot, the env step's lane mapping) --------------
+            const int lw = lane / N, i = lane - lw * N;
+            const int64_t w = w0 + lw, a = w * N + i;
+            const bool in_range = lane < wpw * N && w < c.num_worlds;
+            const bool learning = in_range && obs_t[a * ow] > 0.5f;          // is_learning of the state acted on (ProcessAgent.py:130)
+            const int base = lane < wpw * N ? lw * N : 0;
+            const int n_learning = __popcll(__ballot(learning) & (((1ull << N) - 1ull) << base));
+            float value = 0.0f;
+            int action = 0;
+            if (in_range) { value = io.values[a]; action = io.actions[a]; }
+            RolloutIO rio = rio_arg;
+            rollout_push_slot(rc, rs, rio, a, in_range ? w : 0, i, in_range, learning, n_learning, so.done, so.game_over, so.reward, value,
+                              action, step, blk);
+            // episode_log_q.put: the totals above were accumulated with atomics by this wavefront's own lanes -- drain them;
+            // rollout_close_episode reads the sums at the cache the atomics went to
+            if (__ballot(in_range && so.game_over) != 0ull) {
+                __builtin_amdgcn_s_waitcnt(0);               // (vmcnt 0: the atomics have been performed at the L2)
+                if (in_range && i == 0 && so.game_over) rollout_close_episode(rc, rs, rio, w);
+            }
+        } else {
+            // ---- meanwhile: the step's state rows -> the time-major experience store -----------------------------------------
+            rollout_copy_rows(rc, obs_t, rio_arg.x, a0, rows, blk, tid - 64, 192);
+        }
+        __syncthreads();                                     // obs(t+1), the world state and the slot state are in memory
+    }
+}
+
+// after the actor launch: advance the two device-side counters the next launch (or a hipGraph replay of this one) starts from
+__global__ void actor_finish_kernel(int32_t *rollout_step, int32_t *policy_step, int32_t n_steps) {
+    *rollout_step += n_steps;
+    *policy_step += n_steps;
+}
+
+}  // namespace cavoid

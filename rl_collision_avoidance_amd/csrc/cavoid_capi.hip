@@ -214,8 +214,8 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.gen_rvo = cfg->gen_rvo_fraction; k.gen_min_trip = cfg->gen_min_trip; k.gen_frozen = cfg->gen_frozen_fraction;
     k.wrap_hi = cfg->wrap_closed_end ? std::nextafter(kPi, 4.0) : kPi;          /* a > pi  <=>  a >= next(pi) */
     k.wrap_lo = cfg->wrap_closed_end ? std::nextafter(-kPi, 0.0) : -kPi;        /* a <= -pi <=>  a < next(-pi) */
-    k.skip_done_pairs = cfg->done_agents_collide ? 0 : 1;
-    k.sort_round_gap = cfg->sort_round_gap ? 1 : 0; k.sort_tie_lateral = cfg->sort_tie_lateral ? 1 : 0;
+    k.switches = (cfg->done_agents_collide ? 0u : kSwSkipDonePairs) | (cfg->sort_round_gap ? 0u : kSwExactGap) |
+                 (cfg->sort_tie_lateral ? 0u : kSwIndexTie);
     k.gen_box_small_lo = cfg->gen_box_small[0]; k.gen_box_small_hi = cfg->gen_box_small[1];
     k.gen_box_large_lo = cfg->gen_box_large[0]; k.gen_box_large_hi = cfg->gen_box_large[1];
     k.gen_mode = cfg->gen_mode; k.gen_box_large_from = cfg->gen_box_large_from; k.pool_epoch = cfg->gen_pool_epoch;
@@ -306,7 +306,9 @@ extern "C" int32_t cavoid_obs_width(const cavoid_env *e) { return e ? e->k.width
 
 template <int MODE>
 static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    if ((MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET) && e->k.rvo_enabled)   // the ORCA instantiations: cavoid_rvo.hip
+    // the 'everything' instantiations (cavoid_rvo.hip): ORCA agents; box scenarios generated inside the auto-reset step
+    if (((MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET) && e->k.rvo_enabled) ||
+        (MODE == MODE_STEP_AUTORESET && e->k.gen_mode == 1 && e->k.pool_size <= 0))
         return cavoid_launch_rvo(e, MODE, io, s, ev_start, ev_stop);
     return launch_on<MODE>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
 }
@@ -446,7 +448,6 @@ static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64
     if (n_steps < 1 || action_stride < 0) return CAVOID_EINVAL;
     if (out_step_stride != 0 && out_step_stride < e->W) return CAVOID_EINVAL;   // slots of consecutive steps must not overlap
     io.out_step_stride = n_steps > 1 ? out_step_stride : 0;
-    if (e->cfg.gen_mode == 1 && e->pool_size <= 0) return CAVOID_EINVAL;   // GEN v2 restarts come from the scenario pool
     io.actions = actions;
     io.action_stride = action_stride;
     io.n_steps = n_steps;

@@ -72,14 +72,19 @@ struct KCfg {
     int32_t rvo_lds_floats;      // per-wavefront LDS floats of the ORCA line scratch (0 unless rvo_enabled)
     int32_t park_floats;         // N >= kParkFromN: the obs tile region is at least this large (it parks the sort keys / gaps)
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
-    int32_t skip_done_pairs;     // U4 flipped: a pair with an agent that was done before the step takes no part in E6
-    int32_t sort_round_gap;      // U7a: 1 = order by the gap rounded to centimetres (fast integer keys); 0 = exact gap (generic path)
-    int32_t sort_tie_lateral;    // U7b: 1 = ties by lateral offset then index; 0 = by index alone
+    uint32_t switches;           // kSw* bits: the rarely flipped U-switches, ONE scalar (every kernel loads and pins it, with wrap_hi /
+                                 // wrap_lo, before its first wait: a lazily loaded kernel argument costs a scalar-memory round trip on
+                                 // the step's dependent chain -- five of them were 1.3 us of the 6.8 us one-step launch)
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
     const double *action_table;  // [num_actions][2]
 };
 
+enum : uint32_t {
+    kSwSkipDonePairs = 1u,       // U4 flipped: a pair with an agent that was done before the step takes no part in E6
+    kSwExactGap = 2u,            // U7a flipped: neighbours ordered by the exact gap (default: rounded to centimetres)
+    kSwIndexTie = 4u,            // U7b flipped: ties by agent index alone (default: lateral offset, then index)
+};
 struct KState {
     double *px, *py, *heading, *t_rem;
     float *gx, *gy, *radius, *pref, *speed;
@@ -410,8 +415,11 @@ __device__ __forceinline__ int key_bucket(const Key &k) { return (int)(kKeyBias 
 // key.hi, key.lo, gap.  The loop is then rolled three neighbours at a time (three square-root chains in flight instead of
 // N-1), which is what lets the N = 10 kernels fit 128 registers.
 constexpr int kParkFromN = 6;
-template <int N, bool PARK = false>
-__device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
+// SW: some U-switch of c.switches is flipped (the caller tests the word once and picks the instantiation: inside the unrolled pair
+// loop even a never-taken uniform branch per neighbour splits the N-1 square-root chains into separate scheduling regions and
+// costs the one-step launch 9 %).
+template <int N, bool PARK = false, bool SW = false>
+__device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
                                           const double *lds_px, const double *lds_py, const float *lds_r,
                                           Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K],
                                           uint32_t &valid, bool &hit, double &min_gap, uint32_t *park = nullptr, int lane = 0,
@@ -430,7 +438,8 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
         const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
         const double d = sqrt_dist2(rx * rx + ry * ry);
         const bool other = present && (rjf >= 0.0f);
-        const bool collides = other && ((frozen_w >> jj) & 1u) == 0u && ((frozen_w >> i) & 1u) == 0u;
+        bool collides = other;
+        if (SW) collides = other && ((frozen_w >> jj) & 1u) == 0u && ((frozen_w >> i) & 1u) == 0u;    // (frozen_w = 0 unless U4 is flipped)
         // unordered-pair gap d - (r_lo + r_hi): the sum is commutative, both ends agree bitwise
         const double gap_c = d - (ri + (double)rjf);
         min_gap = collides ? fmin(min_gap, gap_c) : min_gap;
@@ -443,11 +452,15 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
         uint32_t hi = kKeyBias - (uint32_t)(int)rint(gap_o * 100.0);
         // U7a flipped (order by the exact gap): the float32 rounding of the gap, one bit dropped -- monotonic, so different values
         // order exactly as the float64 gaps; equal ones fall back to the exact comparison (assemble_obs, tie_first)
-        if (CAVOID_RARE(!c.sort_round_gap)) hi = 0x7FFFFFFEu - (orderable((float)gap_o) >> 1);
+        uint32_t lo = orderable((float)(ry * e.tx - rx * e.ty));
+        if (SW) {
+            // U7b flipped: the agent index (distinct per neighbour) instead of the lateral offset -- a stable sort on the bucket;
+            // with exact gaps: nothing -- equal float32 gaps must compare EQUAL so that the exact path decides
+            if (c.switches & kSwIndexTie) lo = (uint32_t)jj;
+            if (c.switches & kSwExactGap) { lo = 0u; hi = 0x7FFFFFFEu - (orderable((float)gap_o) >> 1); }
+        }
         hi = seen ? hi : 0x7FFFFFFFu;
-        // U7b flipped: the agent index (distinct per neighbour) instead of the lateral offset -- a stable sort on the bucket
-        // (and with exact gaps: nothing -- equal float32 gaps must compare EQUAL so that the exact path decides)
-        const uint32_t lo = seen ? (!c.sort_round_gap ? 0u : (c.sort_tie_lateral ? orderable((float)(ry * e.tx - rx * e.ty)) : (uint32_t)jj)) : (uint32_t)o;
+        lo = seen ? lo : (uint32_t)o;
         if (PARK) {
             park[(0 * K + o) * 64 + lane] = hi;
             park[(1 * K + o) * 64 + lane] = lo;
@@ -459,12 +472,26 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
         }
     };
     if (PARK) {
+        // (a scheduling fence per neighbour: left alone the scheduler interleaves all N-1 square-root chains of the unrolled loop
+        //  and the one-step kernel needs 181 registers at N = 10 -- 2 wavefronts per SIMD instead of 3; fenced: 161)
 #pragma unroll 3
-        for (int o = 0; o < N - 1; ++o) one(o);
+        for (int o = 0; o < N - 1; ++o) { one(o); __builtin_amdgcn_sched_barrier(0); }
     } else {
 #pragma unroll
         for (int o = 0; o < N - 1; ++o) one(o);
     }
+}
+
+template <int N, bool PARK = false>
+__device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
+                                          const double *lds_px, const double *lds_py, const float *lds_r,
+                                          Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K],
+                                          uint32_t &valid, bool &hit, double &min_gap, uint32_t *park = nullptr, int lane = 0,
+                                          uint32_t frozen_w = 0u) {
+    if (CAVOID_RARE(c.switches != 0u))
+        pair_pass_impl<N, PARK, true>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, park, lane, frozen_w);
+    else
+        pair_pass_impl<N, PARK, false>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, park, lane, 0u);
 }
 
 // Coalesced write-out of the wave's obs tile: n_floats contiguous floats starting at dst.
@@ -610,7 +637,9 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // PreFlush: called once, right before the first global store of the tile (env_relay_kernel orders the last step's rows behind
 // the rows of the steps before it, which other wavefronts write)
-template <int N, bool PARK = false, bool LEAN = PARK, class PreFlush = NoHook>
+// FLUSH = false: the rows stay in the LDS tile (row r at tile + r * ostride; needs c.tile_rows >= rows_active), nothing is written
+// to obs_dst
+template <int N, bool PARK = false, bool LEAN = PARK, class PreFlush = NoHook, bool FLUSH = true>
 __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
                                              const double *lds_px, const double *lds_py, const double *lds_vx,
                                              const double *lds_vy, const float *lds_r, const Key (&key_in)[Others<N>::K],
@@ -652,8 +681,8 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
             const double rj = (double)lds_r[j];
             const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
             const double gap = sqrt_dist2(rx * rx + ry * ry) - ri - rj;
-            g = c.sort_round_gap ? rint(gap * 100.0) : gap;
-            l = c.sort_tie_lateral ? ry * e.tx - rx * e.ty : 0.0;
+            g = (c.switches & kSwExactGap) ? gap : rint(gap * 100.0);
+            l = (c.switches & kSwIndexTie) ? 0.0 : ry * e.tx - rx * e.ty;
             t = use_tti ? time_to_impact(rx, ry, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + rj) : 0.0;
         };
 #pragma unroll 1
@@ -760,7 +789,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     CAVOID_STAMP(10);                                            // rows in the LDS tile
     if (p0 == 0) pre_flush();
     const int rows_here = rows_active - p0 < rpp ? rows_active - p0 : rpp;
-    {
+    if (FLUSH) {
         constexpr int kRows = (64 / N) * N, kW = 6 + 7 * (N - 1);   // a full wavefront, the default row widths
         constexpr bool kPlainOk = (kRows * kW) % 4 == 0, kPackedOk = (kRows * (kW + 2)) % 4 == 0;
         float *dst = obs_dst + (int64_t)p0 * ostride;
@@ -979,18 +1008,22 @@ enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESE
 // MODE_STEP_AUTORESET_PF the same with the NEXT episode's pool record of every lane held in registers (loaded with the
 //                        state, re-loaded after a restart): latency mode for small batches, where a wavefront is alone on
 //                        its SIMD and a restart must not cost a dependent trip to memory (may use more registers).
-// RVO: the instantiation can drive policy-3 (ORCA) agents.  A separate instantiation because the linear programmes,
-// inlined into the step, cost every other configuration registers (N = 10: +40 VGPRs and scratch) for code it never runs.
+// RVO: the instantiation can drive policy-3 (ORCA) agents and generate box scenarios (GEN v2) inside the step.  A separate
+// instantiation because the linear programmes and the generator, inlined into the step, cost every other configuration
+// registers (N = 10: +40 VGPRs and scratch) for code it never runs.
+// what the last step of a tile left in the lane's registers, for a caller that goes on in the same kernel (the fused actor:
+// cavoid_actor.hpp hands it to the experience bookkeeping)
+struct StepOut { float reward; bool done, game_over; };
+
+// The body of env_kernel for ONE tile (one wavefront): lds_tab = the workgroup's action-table copy, wbase = the wavefront's
+// private LDS (staging arrays, obs tile, ORCA scratch), wave = the tile's index.  A device function so that the fused actor
+// kernel (policy -> sample -> THIS -> experience push, per tile, in one launch) runs the very same statements.
 template <int N, int MODE, bool RVO>
-// (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
-//  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
-__global__ void __launch_bounds__(256, (MODE == MODE_STEP_AUTORESET_PF ? 2 : (N <= CAVOID_OCC4_MAX_N ? 4 : CAVOID_OCC_LARGE_N)))
-env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
+__device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const PoolRec *pool, const KIO &io, double *lds_tab, float *wbase,
+                                         const int lane, const int64_t wave, StepOut *out = nullptr) {
     constexpr bool kAuto = MODE == MODE_STEP_AUTORESET || MODE == MODE_STEP_AUTORESET_PF || MODE == MODE_STEP_AUTORESET_N;
     constexpr bool kLoop = MODE == MODE_STEP_AUTORESET_PF || MODE == MODE_STEP_AUTORESET_N;
     constexpr bool kStepping = MODE == MODE_STEP || kAuto;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int width = c.width, ostride = io.obs ? io.obs_stride : width;
     // parking pays where occupancy is the limit -- one step per launch (N = 10: 216 -> 162 VGPRs, 3 wavefronts/SIMD, saturated
     // 272 -> 235 us); the step-loop instantiations stay at 2 wavefronts/SIMD either way and lose ILP to the rolled pair loop
@@ -998,9 +1031,6 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     constexpr bool kPark = N >= kParkFromN && !RVO && MODE != MODE_STEP_AUTORESET_PF && MODE != MODE_STEP_AUTORESET_N;
     const int tile_need = (c.tile_rows * ostride + 3) & ~3;
     const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
-    const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
-    double *lds_tab = reinterpret_cast<double *>(smem);
-    float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
     double *lds_px = reinterpret_cast<double *>(wbase);
     double *lds_py = lds_px + 64, *lds_vx = lds_py + 64, *lds_vy = lds_vx + 64;
     float *lds_r = reinterpret_cast<float *>(lds_vy + 64);
@@ -1008,7 +1038,6 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     double *rvo_mem = reinterpret_cast<double *>(tile + tile_floats);   // ORCA lines (only with c.rvo_enabled)
 
     const int wpw = c.wpw, lanes_used = wpw * N;          // worlds / lanes this wavefront really owns
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const int64_t w0 = wave * wpw;                         // first world of this wavefront
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = w0 + lw;
@@ -1196,7 +1225,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     bool hit;
     double min_gap;
     uint32_t frozen_w = 0u;                                 // U4 flipped: the agents of this lane's world that were done before the step
-    if (kStepping && CAVOID_RARE(c.skip_done_pairs))
+    if (kStepping && CAVOID_RARE(c.switches & kSwSkipDonePairs))
         frozen_w = (uint32_t)(__ballot(present_in && done_in) >> base) & ((1u << N) - 1u);
     pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, reinterpret_cast<uint32_t *>(tile), lane,
                         frozen_w);
@@ -1223,6 +1252,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
         const bool game_over = (running & wmask) == 0ull;
         rew_f = (float)r;
         done_f = done ? 1.0f : 0.0f;
+        if (out) { out->reward = rew_f; out->done = done; out->game_over = game_over; }
         if (active) {
             if (!packed) {
                 io.rew[slot_w * N + a_idx] = rew_f;
@@ -1234,14 +1264,22 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
             const bool restart = active && game_over;
             if (CAVOID_RARE(__ballot(restart) != 0ull)) {               // wave-uniform: some world of this tile restarts
                 wave_lds_sync();                           // every lane is done reading the old positions
+                if (restart) { episode += 1u; restarted_any = true; }
+                // GEN v2 without a pool: the box generator places a world's agents one after the other, so the whole wavefront
+                // takes part (the restarting worlds' lanes draw, round by round, against what their world has placed so far;
+                // the staging arrays of the OTHER worlds' lanes are not touched)
+                // (carried by the RVO = true instantiations only -- the 'everything' build of the step: inlined into the plain
+                //  ones it costs the one-step kernel its occupancy, N = 10: 159 -> 210 VGPRs)
+                const bool box_in_step = RVO && !kPrefetch && c.gen_mode == 1 && c.pool_size == 0;     // wave-uniform
+                if (box_in_step)
+                    generate_world_v2<N>(c, (uint32_t)(c.world_offset + w), episode, i, base, lane, restart, lds_px, lds_py, lds_vx, lds_vy,
+                                         lds_r, a);
                 if (restart) {
-                    episode += 1u;
-                    restarted_any = true;
                     if (kPrefetch) {
                         a = nxt;
                         if (t + 1 < n_steps)               // re-arm: the record of the episode after this one
                             load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
-                    } else new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
+                    } else if (!box_in_step) new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
                     present = (a.flags & CAVOID_F_PRESENT) != 0u;
                     lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = 0.0; lds_vy[lane] = 0.0;
                     lds_r[lane] = present ? a.radius : -1.0f;
@@ -1296,6 +1334,27 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     CAVOID_STAMP(8);
 }
 
+template <int N, int MODE, bool RVO>
+// (second launch-bound = min wavefronts per SIMD: small-N instantiations sit right at the 128-VGPR cliff;
+//  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
+__global__ void __launch_bounds__(256, (MODE == MODE_STEP_AUTORESET_PF ? 2 : (N <= CAVOID_OCC4_MAX_N ? 4 : CAVOID_OCC_LARGE_N)))
+env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
+    // the switches and the wrap limits: loaded with the first burst, not on the chain.  (Inputs of an empty asm -- NOT a local copy
+    // of the struct: a copy keeps every field it ever uses live in scalar registers, which then spill into vector registers,
+    // N = 10 one step per launch: 159 -> 181 VGPRs = 3 -> 2 wavefronts per SIMD.)
+    asm volatile("" ::"s"(c.switches), "s"(c.wrap_hi), "s"(c.wrap_lo));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ostride = io.obs ? io.obs_stride : c.width;
+    const int tile_need = (c.tile_rows * ostride + 3) & ~3;
+    const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
+    const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
+    double *lds_tab = reinterpret_cast<double *>(smem);
+    float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    env_tile<N, MODE, RVO>(c, s, pool, io, lds_tab, wbase, lane, wave);
+}
+
 
 // ---- MODE_STEP_AUTORESET_PIPE: the step loop as a two-wavefront pipeline (latency mode: small batches) ----------------
 // At 4 x 8192 there are 512 tiles for 1024 SIMDs and a step is ONE wavefront's dependent chain.  Here a tile is owned by a
@@ -1324,6 +1383,7 @@ __host__ __device__ constexpr size_t pipe_lds_fixed_bytes() {
 
 template <int N, bool RVO>
 __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
+    asm volatile("" ::"s"(c.switches), "s"(c.wrap_hi), "s"(c.wrap_lo));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds_tab = reinterpret_cast<double *>(smem);
     PipeStage *stage = reinterpret_cast<PipeStage *>(smem + lds_floats_block() * sizeof(float));
@@ -1455,7 +1515,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 bool hit;
                 double min_gap;
                 uint32_t frozen_w = 0u;
-                if (CAVOID_RARE(c.skip_done_pairs)) frozen_w = (uint32_t)(__ballot(present_in && done_in) >> base) & ((1u << N) - 1u);
+                if (CAVOID_RARE(c.switches & kSwSkipDonePairs)) frozen_w = (uint32_t)(__ballot(present_in && done_in) >> base) & ((1u << N) - 1u);
                 pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit, min_gap, nullptr, 0, frozen_w);
                 CAVOID_STAMP(4);
                 // ---- E7 rewards, E8 done -------------------------------------------------------------------------------

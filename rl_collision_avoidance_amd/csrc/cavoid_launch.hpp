@@ -73,6 +73,7 @@ template <bool RVO>
 static inline int launch_pipe(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const KCfg &k = e->k;
     if (!io.obs) return CAVOID_EUNSUPPORTED;               // (the consumer wavefront IS the observation: env_kernel guards a null obs)
+    if (k.gen_mode == 1 && k.pool_size <= 0) return CAVOID_EUNSUPPORTED;   // (box scenarios generated inside the step: env_kernel's restart)
     const int64_t tiles = (e->W + k.wpw - 1) / k.wpw;
     // it pays while the chip can hold both wavefronts of every tile at <= 2 per SIMD (1024 SIMDs): measured at N = 4,
     // 32-step launches: 512 / 1024 tiles 2.50 vs 3.02 / 3.06 us per step, 2048 tiles 5.05 vs 3.75; N = 10, 1366 tiles 9.4 vs 8.2

@@ -111,6 +111,7 @@ __device__ __forceinline__ float policy_weight(const PolicyWeights &w, int layer
     }
 }
 
+#ifdef CAVOID_POLICY_KERNELS     /* non-template kernel: compiled by cavoid_policy_capi.hip only */
 __global__ void __launch_bounds__(256) policy_pack_kernel(const PolicyWeights w, f32x4 *frags, float *bias, int with_backward) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f < (with_backward ? kPackFragsTrain : kPackFrags)) {
@@ -154,6 +155,7 @@ __global__ void __launch_bounds__(256) policy_pack_kernel(const PolicyWeights w,
         bias[i] = b;
     }
 }
+#endif
 
 // Development aid (never in the product build): -DCAVOID_TRACE makes every workgroup record the constant-rate
 // wall clock at its phase boundaries and the CU it ran on into g_pol_trace[block*16 + k] (tools/trace_policy.py).

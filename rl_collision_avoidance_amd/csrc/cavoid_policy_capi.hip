@@ -6,29 +6,14 @@
 
 #include "cavoid.h"
 #include "cavoid_host.hpp"
+#define CAVOID_POLICY_KERNELS 1
 #include "cavoid_policy.hpp"
 #include "cavoid_policy_split.hpp"
+#include "cavoid_policy_host.hpp"
 
 #include <cstdlib>
 
 using namespace cavoid;
-
-struct cavoid_policy {
-    int device = 0;
-    int max_other = 0, num_actions = 0, in_size = 0;
-    bool loaded = false, normalize = false, backward_loaded = false;
-    float min_policy = 0.0f;
-    uint64_t seed = 0;
-    void *slab = nullptr;
-    f32x4 *frags = nullptr;
-    uint4 *sfrags = nullptr;         // bf16-split weight fragments of the inference kernel (cavoid_policy_split.hpp)
-    bool use_split = true;           // CAVOID_POLICY_F32=1: run inference on the float32-MFMA kernel instead (A/B runs)
-    float *bias = nullptr, *avg = nullptr, *std = nullptr;
-    int32_t *step_counter = nullptr;
-    uint32_t *blocks_done = nullptr, *cu_tickets = nullptr;
-    int row_tiles = 4;               // 16-row tiles per workgroup (64 rows, 2 workgroups per CU); the 32-row / 4-per-CU
-                                     // instantiation was measured and dropped: 175 vs 132 us
-};
 
 extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int device, cavoid_policy **out) {
     if (!out) return CAVOID_EINVAL;

@@ -81,6 +81,7 @@ __device__ __forceinline__ float split_weight(const PolicyWeights &w, int layer,
     return policy_weight(w, layer, 32 * c + 8 * g + e, col);
 }
 
+#ifdef CAVOID_POLICY_KERNELS     /* the non-template kernels are compiled by cavoid_policy_capi.hip only */
 __global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one (layer, chunk, column tile, lane): all 3 planes
     constexpr int64_t kWide = kSpOffHead / 3, kAll = kWide + kSpChWide * 64;
@@ -114,6 +115,8 @@ __global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeig
 #pragma unroll
     for (int p = 0; p < 3; ++p) frags[base + p * plane_stride] = uint4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
 }
+
+#endif
 
 struct SplitW { uint4 w[3][4]; };                            // weight fragments of one chunk: plane x column tile
 
@@ -224,50 +227,61 @@ struct SplitArgs {
     const uint4 *sfrags;               // split weight fragments
 };
 
-__global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const SplitArgs sa) {
-    const PolicyArgs &p = sa.p;
-    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // plane 1 (hi), plane 2 (lo)
-    float *len_f = reinterpret_cast<float *>(planes + 2 * kSpPlaneB);            // [64] raw num_other_agents
-    int *tile_row = reinterpret_cast<int *>(len_f + 64);                          // [64] global row of each tile row
-    int *wave_max = tile_row + 64;                                                // [4] + ticket
-    int &ticket = wave_max[4];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
-    const int64_t n_rows = p.row_count ? (int64_t)*p.row_count : p.rows;
-    const int rows_here = n_rows - row0 < 64 ? (int)(n_rows - row0 > 0 ? n_rows - row0 : 0) : 64;
-    const int M = p.max_other, A = p.num_actions;
-    const int step = p.actions_out ? *p.step_counter : 0;
-    const bool listed = p.row_index != nullptr;
-    if (listed && rows_here == 0) {                        // uniform over the workgroup: nothing listed for this tile
-        if (p.actions_out) policy_finish(p, step, tid);
-        return;
+// select_action (ProcessAgent.py:98-103) for the row whose softmax this 4-lane group holds (lane: columns 4g..4g+3 in pj): argmax
+// (PLAY_MODE / EVALUATE_MODE) or one inverse-CDF draw from Philox4x32-10 keyed on (seed, global row, step).  Every lane of the
+// group returns the same action.
+__device__ __forceinline__ int split_select_action(const float (&pj)[4], int g, int lane, int A, bool greedy, int64_t row, int step,
+                                                   uint32_t seed_lo, uint32_t seed_hi) {
+    if (greedy) {                                          // np.argmax: first index of the maximum
+        float best = fmaxf(fmaxf(pj[0], pj[1]), fmaxf(pj[2], pj[3]));
+        best = fmaxf(best, __shfl_xor(best, 16, 64)); best = fmaxf(best, __shfl_xor(best, 32, 64));
+        int idx = 99;
+#pragma unroll
+        for (int r = 3; r >= 0; --r) idx = (4 * g + r < A && pj[r] == best) ? 4 * g + r : idx;
+        int o = __shfl_xor(idx, 16, 64); idx = o < idx ? o : idx;
+        o = __shfl_xor(idx, 32, 64); idx = o < idx ? o : idx;
+        return idx;
     }
-    POLICY_STAMP(0);
-#ifdef CAVOID_TRACE
-    const unsigned long long trace_c0 = clock64();
-    if (tid == 0 && g_pol_trace)
-        g_pol_trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
-                                                  ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-#endif
+    // inverse CDF: #{c : cdf_c <= u * cdf_{A-1}}
+    const float t_g = (pj[0] + pj[1]) + (pj[2] + pj[3]);
+    float before = 0.0f, total = 0.0f;                     // sum of the lower column groups / of all four, in group order
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        const float tg = __shfl(t_g, (lane & 15) + 16 * gg, 64);
+        before += gg < g ? tg : 0.0f;
+        total += tg;
+    }
+    const uint32_t bits = policy_philox_x((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)step, 0x504F4Cu, seed_lo, seed_hi);
+    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+    float cdf = before;
+    int below = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cdf += pj[r]; below += (4 * g + r < A && cdf <= u * total) ? 1 : 0; }
+    below += __shfl_xor(below, 16, 64); below += __shfl_xor(below, 32, 64);
+    return below < A - 1 ? below : A - 1;
+}
+
+// The forward pass of ONE 64-row tile by the 4 wavefronts of a workgroup (layout: header of this file).
+//   load(r, k)  -> policy input k (0 = num_other_agents) of tile row r, r < rows_here; the rows may live in global memory (the
+//                  stand-alone kernel) or in LDS (the fused actor kernel: the env step left them there);
+//   emit(trow, g, pj, logit) is called by every lane of the heads' layout: tile row trow = 16 wave + lane%16, columns 4g..4g+3 --
+//                  pj = softmax probabilities incl. MIN_POLICY, logit[r] = raw head output (column A = the value).
+// planes / len_f / wave_max: the workgroup's LDS (policy_split_lds_bytes()).  Contains workgroup barriers: every thread calls it.
+template <class Load, class Emit>
+__device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned char *planes, float *len_f, int *wave_max, int rows_here,
+                                                  int tid, Load load, Emit emit) {
+    const PolicyArgs &p = sa.p;
+    const int wave = tid >> 6, lane = tid & 63, g = lane >> 4;
+    const int M = p.max_other, A = p.num_actions;
     const uint4 *w_lstm = sa.sfrags + kSpOffLstm;
     SplitW f0;
     split_load_w(f0, w_lstm, wave, lane, 2);               // first LSTM step: h == 0, only the input chunk contributes
 
     // ---- input tile: gather + normalise + split into the slot columns ---------------------------------------------
-    if (listed) {
-        if (tid < 64) tile_row[tid] = tid < rows_here ? p.row_index[row0 + tid] : 0;
-        __syncthreads();
-    }
     {
-        const float *src = listed ? p.x : p.x + row0 * p.stride;
-        if (tid == 0) {                                    // arrival parity on the CU -> static priority (see cavoid_policy.hpp)
-            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-            const uint32_t key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
-            ticket = (int)atomicAdd(p.cu_tickets + key, 1u);
-        }
         int local_max = 0;
         if (tid < 64) {
-            const float v = tid < rows_here ? src[(int64_t)(listed ? tile_row[tid] : tid) * p.stride] : 0.0f;
+            const float v = tid < rows_here ? load(tid, 0) : 0.0f;
             len_f[tid] = v;
             int len = (int)v;
             len = len < 0 ? 0 : (len > M ? M : len);
@@ -287,7 +301,7 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
             for (int e = 0; e < 8; ++e) {
                 float x = 0.0f;
                 if (e < n_in && r < rows_here) {
-                    x = src[(int64_t)(listed ? tile_row[r] : r) * p.stride + sc0 + e];
+                    x = load(r, sc0 + e);
                     if (p.avg) x = (x - p.avg[sc0 + e]) / p.std[sc0 + e];
                 }
                 v[e] = x;
@@ -305,7 +319,6 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
     }
     __syncthreads();
     const int steps = wave_max[0];                         // rows 0..63 are all in wavefront 0's threads
-    if (ticket & 1) __builtin_amdgcn_s_setprio(1);
     POLICY_STAMP(5);
 
     // this lane's rows (one per row tile) and their sequence lengths
@@ -406,8 +419,6 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
         // lane: row 16w + l%16, columns 4g + r.  Reductions over a row's 16 columns = over r in the lane and over the
         // four lanes l%16 + 16g'.
         const int trow = 16 * wave + (lane & 15);
-        const bool in_tile = trow < rows_here;
-        const int64_t row = listed ? (in_tile ? (int64_t)tile_row[trow] : p.rows) : row0 + trow;
         const float scale = 1.0f / (1.0f + p.min_policy * (float)A);
         float m = -INFINITY;
 #pragma unroll
@@ -420,6 +431,52 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
         float pj[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pj[r] = (4 * g + r < A) ? (e[r] / sum + p.min_policy) * scale : 0.0f;
+        emit(trow, g, pj, logit);
+    }
+    POLICY_STAMP(4);
+}
+
+#ifdef CAVOID_POLICY_KERNELS
+__global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const SplitArgs sa) {
+    const PolicyArgs &p = sa.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // plane 1 (hi), plane 2 (lo)
+    float *len_f = reinterpret_cast<float *>(planes + 2 * kSpPlaneB);            // [64] raw num_other_agents
+    int *tile_row = reinterpret_cast<int *>(len_f + 64);                          // [64] global row of each tile row
+    int *wave_max = tile_row + 64;                                                // [4] + ticket
+    int &ticket = wave_max[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t n_rows = p.row_count ? (int64_t)*p.row_count : p.rows;
+    const int rows_here = n_rows - row0 < 64 ? (int)(n_rows - row0 > 0 ? n_rows - row0 : 0) : 64;
+    const int A = p.num_actions;
+    const int step = p.actions_out ? *p.step_counter : 0;
+    const bool listed = p.row_index != nullptr;
+    if (listed && rows_here == 0) {                        // uniform over the workgroup: nothing listed for this tile
+        if (p.actions_out) policy_finish(p, step, tid);
+        return;
+    }
+    POLICY_STAMP(0);
+#ifdef CAVOID_TRACE
+    const unsigned long long trace_c0 = clock64();
+    if (tid == 0 && g_pol_trace)
+        g_pol_trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                  ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+    if (listed) {
+        if (tid < 64) tile_row[tid] = tid < rows_here ? p.row_index[row0 + tid] : 0;
+    }
+    if (tid == 0) {                                        // arrival parity on the CU -> static priority (see cavoid_policy.hpp)
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        const uint32_t key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
+        ticket = (int)atomicAdd(p.cu_tickets + key, 1u);
+    }
+    __syncthreads();
+    if (ticket & 1) __builtin_amdgcn_s_setprio(1);
+    const float *src = listed ? p.x : p.x + row0 * p.stride;
+    auto load = [&](int r, int k) -> float { return src[(int64_t)(listed ? tile_row[r] : r) * p.stride + k]; };
+    auto emit = [&](int trow, int g, const float (&pj)[4], const f32x4 &logit) {
+        const bool in_tile = trow < rows_here;
+        const int64_t row = listed ? (in_tile ? (int64_t)tile_row[trow] : p.rows) : row0 + trow;
         if (row < p.rows) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -429,43 +486,17 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
             }
         }
         if (p.actions_out) {                               // wave-uniform
-            int action;
-            if (p.greedy) {                                // np.argmax: first index of the maximum
-                float best = fmaxf(fmaxf(pj[0], pj[1]), fmaxf(pj[2], pj[3]));
-                best = fmaxf(best, __shfl_xor(best, 16, 64)); best = fmaxf(best, __shfl_xor(best, 32, 64));
-                int idx = 99;
-#pragma unroll
-                for (int r = 3; r >= 0; --r) idx = (4 * g + r < A && pj[r] == best) ? 4 * g + r : idx;
-                int o = __shfl_xor(idx, 16, 64); idx = o < idx ? o : idx;
-                o = __shfl_xor(idx, 32, 64); idx = o < idx ? o : idx;
-                action = idx;
-            } else {                                       // inverse CDF: #{c : cdf_c <= u * cdf_{A-1}}
-                const float t_g = (pj[0] + pj[1]) + (pj[2] + pj[3]);
-                float before = 0.0f, total = 0.0f;         // sum of the lower column groups / of all four, in group order
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const float tg = __shfl(t_g, (lane & 15) + 16 * gg, 64);
-                    before += gg < g ? tg : 0.0f;
-                    total += tg;
-                }
-                const uint32_t bits = policy_philox_x((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)step, 0x504F4Cu,
-                                                      p.seed_lo, p.seed_hi);
-                const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
-                float cdf = before;
-                int below = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cdf += pj[r]; below += (4 * g + r < A && cdf <= u * total) ? 1 : 0; }
-                below += __shfl_xor(below, 16, 64); below += __shfl_xor(below, 32, 64);
-                action = below < A - 1 ? below : A - 1;
-            }
+            const int action = split_select_action(pj, g, lane, A, p.greedy != 0, row, step, p.seed_lo, p.seed_hi);
             if (row < p.rows && g == 0) p.actions_out[row] = action;
         }
-    }
-    POLICY_STAMP(4);
+    };
+    policy_split_tile(sa, planes, len_f, wave_max, rows_here, tid, load, emit);
 #ifdef CAVOID_TRACE
     if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
 #endif
     if (p.actions_out) policy_finish(p, step, tid);
 }
+
+#endif
 
 }  // namespace cavoid

@@ -9,7 +9,7 @@ using namespace cavoid;
 int cavoid_launch_relay(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const KCfg &k = e->k;
     if (k.rvo_enabled || k.pool_size <= 0 || !io.obs || !io.actions || io.cont) return CAVOID_EUNSUPPORTED;
-    if (k.skip_done_pairs) return CAVOID_EUNSUPPORTED;     // (U4 flipped: P would need to know who was frozen; the other loop forms do)
+    if (k.switches & kSwSkipDonePairs) return CAVOID_EUNSUPPORTED;     // (U4 flipped: P would need to know who was frozen; the other loop forms do)
     const int64_t tiles = (e->W + k.wpw - 1) / k.wpw;
     // every tile's workgroup must be resident at once (256 CUs x 2 workgroups): beyond that the tiles run in rounds
     // (measured with 1024 tiles, N = 4: 3.87 vs 2.50 us per step for the two-wavefront pipeline; 1366 tiles, N = 10: 25 vs 8.3)

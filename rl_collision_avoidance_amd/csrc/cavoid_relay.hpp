@@ -81,7 +81,9 @@ __device__ __forceinline__ void relay_wait(const int *p, int v) {
 }
 // The observation wavefronts and the loader wait with a bound: a wait that does not end within ~1 s (2^24 polls; a step is
 // microseconds) is a broken hand-over somewhere in the workgroup, and the wavefront traps -- the process gets a launch failure
-// instead of a GPU that never answers again.  (D and P wait unbounded: the bound costs their loops 5 %.)
+// instead of a GPU that never answers again.  (D and P wait unbounded: the bound costs their loops 5 %.  They are covered all
+// the same: whichever of them stalls, `fin` stops advancing, and the consumers' and the loader's bounded waits on it trap --
+// kept honest by the fault-injection build, tests/test_gpu_relay_fault.py.)
 constexpr int kRelayPollLimit = 1 << 24;
 __device__ __forceinline__ void relay_wait_bounded(const int *p, int v) {
     int polls = 0;
@@ -400,6 +402,12 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         for (int t = 0; t < n_steps; ++t) {
             int lane = lane0, i = i0, base = base0;
             asm volatile("" : "+v"(lane), "+v"(i), "+v"(base));
+#ifdef CAVOID_FAULT_RELAY
+            // development build only (tests/test_gpu_relay_fault.py): the pair-pass wavefront of tile 0 walks away at step 5 -- D then
+            // spins on a verdict that never comes; the bounded waits of the observation wavefronts and of the loader must turn
+            // that into a trap (a failed launch), not into a GPU that never answers
+            if (t == 5 && blockIdx.x == 0) return;
+#endif
             RELAY_STAMP(8);                                // P: waiting for stage t
             // the speculative successor D posted while this wavefront worked on step t-1 is exact unless the verdict of t-1 found
             // a new collision or restarted a world: only then wait for D's corrected state
@@ -532,6 +540,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     } else {
         // ================================================ C: observation of every NC-th step ===================================
         __builtin_amdgcn_s_setprio(0);
+        KCfg cc = c;                                        // this role's switches / wrap limits, pinned (see KCfg::switches)
+        asm volatile("" : "+s"(cc.switches), "+s"(cc.wrap_hi), "+s"(cc.wrap_lo));
         const int cid = role - 2;
         float *tile = tiles + (size_t)cid * tile_floats;
         __syncthreads();
@@ -551,13 +561,13 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const uint32_t ctl_c = v.ctl[lane];
             const float rew_c = v.rew[lane], done_c = (ctl_c & 1u) ? 1.0f : 0.0f;
             const bool present = active && (ao.flags & CAVOID_F_PRESENT);
-            const Ego e = ego_frame_obs(c, ao);
+            const Ego e = ego_frame_obs(cc, ao);
             Key key[Others<N>::K];
             float gapf[Others<N>::K];
             uint32_t valid;
             bool hit;
             double min_gap;
-            pair_pass<N>(c, ao, e, present, i, base, f.px, f.py, f.r, key, gapf, valid, hit, min_gap);
+            pair_pass<N>(cc, ao, e, present, i, base, f.px, f.py, f.r, key, gapf, valid, hit, min_gap);
             RELAY_STAMP(18);                               // C: ego frame + keys
             const bool last = t == n_steps - 1 && io.out_step_stride == 0;   // (with per-step slots no two steps share an address)
             const int64_t slot_w = (int64_t)t * io.out_step_stride;
@@ -566,7 +576,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     for (int o = 0; o < NC; ++o)
                         if (o != cid) relay_wait_bounded(&seq->cfin[o], 1);
             };
-            assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
+            assemble_obs<N, false, true>(cc, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
                                          io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,
                                          order_last);
             if (active) {                                  // the step's plain outputs (behind order_last, like the rows)

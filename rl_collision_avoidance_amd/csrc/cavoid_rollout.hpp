@@ -74,61 +74,43 @@ struct RolloutIO {
 
 constexpr int kMaxRing = 32;   // T_max + 1 <= 32: the backward pass runs in registers (else a serial fallback)
 
-__global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, const RolloutState s, const RolloutIO io) {
-    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool in_range = a < c.num_slots;
-    const int N = c.max_agents, D = c.obs_width - 1, L = c.time_max + 1, RL = c.ring_len;
-    const int64_t slots = c.num_slots;
-    const int64_t w = in_range ? a / N : 0;
-    const int i = in_range ? (int)(a - w * N) : 0;
-    const int32_t step = io.step >= 0 ? io.step : *s.step_counter;
-    const int blk = step % RL;
-
-    // ---- the step's state rows -> x[blk]: a coalesced sweep of the wavefront's 64 contiguous rows --------
-    {
-        const int64_t a0 = a - lane;                             // first slot of this wavefront
-        int64_t rows = slots - a0;
-        rows = rows > 64 ? 64 : (rows < 0 ? 0 : rows);
-        const int total = (int)rows * D;
-        const uint32_t inv_d = (uint32_t)((1ull << 32) / (uint32_t)D) + 1u;   // idx / D by multiply-shift (idx < 2^16)
-        const float *src = io.prev_obs + a0 * c.obs_width;
-        float *dst = io.x + ((int64_t)blk * slots + a0) * D;
-        for (int i0 = lane; i0 < total; i0 += 64 * 8) {          // 8 loads in flight per lane, then 8 stores
-            float v[8];
+// the step's state rows -> x[blk]: a coalesced sweep of `rows` contiguous slots starting at slot a0 by the `nlanes` lanes
+// (lane = 0 .. nlanes-1) of the caller's group (a wavefront; the fused actor kernel uses three)
+__device__ __forceinline__ void rollout_copy_rows(const RolloutCfg &c, const float *prev_obs, float *x, int64_t a0, int rows, int blk,
+                                                  int lane, int nlanes) {
+    const int D = c.obs_width - 1;
+    const int total = rows * D;
+    const uint32_t inv_d = (uint32_t)((1ull << 32) / (uint32_t)D) + 1u;   // idx / D by multiply-shift (idx < 2^16)
+    const float *src = prev_obs + a0 * c.obs_width;
+    float *dst = x + ((int64_t)blk * c.num_slots + a0) * D;
+    for (int i0 = lane; i0 < total; i0 += nlanes * 8) {          // 8 loads in flight per lane, then 8 stores
+        float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = i0 + 64 * u;
-                const int r = (int)(((uint64_t)(uint32_t)idx * inv_d) >> 32), q = idx - r * D;
-                v[u] = idx < total ? src[r * c.obs_width + 1 + q] : 0.f;
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i0 + nlanes * u;
+            const int r = (int)(((uint64_t)(uint32_t)idx * inv_d) >> 32), q = idx - r * D;
+            v[u] = idx < total ? src[r * c.obs_width + 1 + q] : 0.f;
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = i0 + 64 * u;
-                if (idx < total) dst[idx] = v[u];
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i0 + nlanes * u;
+            if (idx < total) dst[idx] = v[u];
         }
     }
+}
 
-    bool learning = false, done = false, over = false;
-    float reward = 0.f, value = 0.f;
-    int action = 0;
+// One slot's bookkeeping for one env step (ProcessAgent.run_episode's body for agent i of world w, :149-211): the append, the
+// flush rule, the backward n-step return, the episode totals.  Inputs are VALUES (the stand-alone kernel reads them from the
+// step's output tensors, the fused actor kernel has them in registers); the rings are written in place.
+__device__ __forceinline__ void rollout_push_slot(const RolloutCfg &c, const RolloutState &s, const RolloutIO &io, int64_t a, int64_t w, int i,
+                                                  bool in_range, bool learning, int n_learning, bool done, bool over, float reward,
+                                                  float value, int action, int32_t step, int blk) {
+    const int D = c.obs_width - 1, L = c.time_max + 1, RL = c.ring_len;
+    const int64_t slots = c.num_slots;
     int len = 0, since = 0;
     bool trained = false;
     double score = 0.0;
-    int n_learning = 0;
-    if (in_range) {
-        learning = io.prev_obs[a * c.obs_width] > 0.5f;      // is_learning column (ProcessAgent.py:130)
-        done = io.done[a] != 0;
-        over = io.game_over[w] != 0;
-        reward = io.rewards[a];
-        value = io.values[a];
-        action = io.actions[a];
-        len = s.len[a]; since = s.since_flush[a]; trained = s.trained[a] != 0; score = s.score[a];
-        // learning agents of this lane's world: the divisor of the chunk score (:157,195).  A world's N slots
-        // are adjacent lanes but may straddle a wavefront edge, so read the is_learning column directly
-        for (int k = 0; k < N; ++k) n_learning += io.prev_obs[(w * N + k) * c.obs_width] > 0.5f ? 1 : 0;
-    }
+    if (in_range) { len = s.len[a]; since = s.since_flush[a]; trained = s.trained[a] != 0; score = s.score[a]; }
     const bool was_trained = trained;
 
     int n_rows = 0;            // rows of the main chunk
@@ -244,6 +226,60 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
     }
 }
 
+// close a finished episode of world w: episode_log_q.put((now, total_reward, total_length)) (:243)
+__device__ __forceinline__ void rollout_close_episode(const RolloutCfg &c, const RolloutState &s, const RolloutIO &io, int64_t w) {
+    const int slot = atomicAdd(io.ep_count, 1);
+    if (slot < c.ep_capacity) {
+        io.ep_out[3 * slot + 0] = (float)w;
+        // (read where the flush atomics accumulated them: agent-scope loads go to the L2, not to a stale L1 line -- the fused
+        //  actor kernel closes an episode in the launch, and on the CU, that has just added to these totals)
+        io.ep_out[3 * slot + 1] = (float)__hip_atomic_load(s.ep_reward + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        io.ep_out[3 * slot + 2] = (float)__hip_atomic_load(s.ep_length + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        atomicAdd(io.ep_count + 1, 1);
+    }
+    s.ep_reward[w] = 0.0;
+    s.ep_length[w] = 0;
+}
+
+#ifdef CAVOID_ROLLOUT_KERNELS     /* the kernels themselves are compiled by cavoid_rollout_capi.hip only */
+__global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, const RolloutState s, const RolloutIO io) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in_range = a < c.num_slots;
+    const int N = c.max_agents, RL = c.ring_len;
+    const int64_t slots = c.num_slots;
+    const int64_t w = in_range ? a / N : 0;
+    const int i = in_range ? (int)(a - w * N) : 0;
+    const int32_t step = io.step >= 0 ? io.step : *s.step_counter;
+    const int blk = step % RL;
+
+    // ---- the step's state rows -> x[blk]: a coalesced sweep of the wavefront's 64 contiguous rows --------
+    {
+        const int64_t a0 = a - lane;                             // first slot of this wavefront
+        int64_t rows = slots - a0;
+        rows = rows > 64 ? 64 : (rows < 0 ? 0 : rows);
+        rollout_copy_rows(c, io.prev_obs, io.x, a0, (int)rows, blk, lane, 64);
+    }
+
+    bool learning = false, done = false, over = false;
+    float reward = 0.f, value = 0.f;
+    int action = 0;
+    int n_learning = 0;
+    if (in_range) {
+        learning = io.prev_obs[a * c.obs_width] > 0.5f;      // is_learning column (ProcessAgent.py:130)
+        done = io.done[a] != 0;
+        over = io.game_over[w] != 0;
+        reward = io.rewards[a];
+        value = io.values[a];
+        action = io.actions[a];
+        // learning agents of this lane's world: the divisor of the chunk score (:157,195).  A world's N slots
+        // are adjacent lanes but may straddle a wavefront edge, so read the is_learning column directly
+        for (int k = 0; k < N; ++k) n_learning += io.prev_obs[(w * N + k) * c.obs_width] > 0.5f ? 1 : 0;
+    }
+    rollout_push_slot(c, s, io, a, w, i, in_range, learning, n_learning, done, over, reward, value, action, step, blk);
+}
+
 // second, tiny pass (one lane per world, after the push kernel): close finished episodes.
 // episode_log_q.put((now, total_reward, total_length)) (:243)
 __global__ void __launch_bounds__(256) rollout_episode_kernel(const RolloutCfg c, const RolloutState s, const RolloutIO io) {
@@ -251,16 +287,7 @@ __global__ void __launch_bounds__(256) rollout_episode_kernel(const RolloutCfg c
     const int64_t W = c.num_slots / c.max_agents;
     if (w == 0 && io.step < 0) *s.step_counter += 1;          // runs after every slot of the push kernel read it
     if (w >= W || io.game_over[w] == 0) return;
-    const int slot = atomicAdd(io.ep_count, 1);
-    if (slot < c.ep_capacity) {
-        io.ep_out[3 * slot + 0] = (float)w;
-        io.ep_out[3 * slot + 1] = (float)s.ep_reward[w];
-        io.ep_out[3 * slot + 2] = (float)s.ep_length[w];
-    } else {
-        atomicAdd(io.ep_count + 1, 1);
-    }
-    s.ep_reward[w] = 0.0;
-    s.ep_length[w] = 0;
+    rollout_close_episode(c, s, io, w);
 }
 
 // ---- the rows that still need a policy output ------------------------------------------------------------------
@@ -348,5 +375,7 @@ __global__ void __launch_bounds__(256) rollout_compact_kernel(const RolloutCfg c
     }
     if (a.mark_taken) a.emit_t[row] = -2;
 }
+
+#endif
 
 }  // namespace cavoid

@@ -6,18 +6,11 @@
 
 #include "cavoid.h"
 #include "cavoid_host.hpp"
+#define CAVOID_ROLLOUT_KERNELS 1
 #include "cavoid_rollout.hpp"
+#include "cavoid_rollout_host.hpp"
 
 using namespace cavoid;
-
-// ---- rollout ------------------------------------------------------------------------------------------
-struct cavoid_rollout {
-    int device = 0;
-    RolloutCfg c{};
-    RolloutState s{};
-    void *slab = nullptr;
-    size_t slab_bytes = 0;
-};
 
 extern "C" int cavoid_rollout_create(int64_t num_worlds, int32_t max_agents, int32_t obs_width, int32_t time_max, double discount,
                                      int32_t reflush_done, int32_t ring_len, int device, cavoid_rollout **out) {

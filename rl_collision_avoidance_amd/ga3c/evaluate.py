@@ -14,7 +14,7 @@ from ..batched_env import BatchedCollisionAvoidanceEnv
 
 @torch.no_grad()
 def evaluate(env: BatchedCollisionAvoidanceEnv, policy: Callable, rounds: int = 1, greedy: bool = True,
-             max_steps: Optional[int] = None) -> Dict[str, float]:
+             max_steps: Optional[int] = None, frozen_policy=None) -> Dict[str, float]:
     """Run ``rounds`` batches of ``env.num_worlds`` episodes.  ``policy``: a ``FusedPolicy`` (its ``act`` is used) or any
     callable ``x [B, NN_INPUT_SIZE] -> (p [B, A], v [B])``.  Returns rates over the learning agents that took part."""
     W, N = env.num_worlds, env.max_agents
@@ -40,7 +40,10 @@ def evaluate(env: BatchedCollisionAvoidanceEnv, policy: Callable, rounds: int = 
             else:
                 p = policy(x.contiguous())[0]
                 actions = p.argmax(dim=1) if greedy else torch.multinomial(p, 1).squeeze(1)
-            obs, rew, done, over = env.step(actions.to(torch.int32).view(W, N))
+            actions = actions.to(torch.int32).contiguous()
+            if frozen_policy is not None:                  # frozen-network agents (scripted policy 4) take their own network's argmax
+                frozen_policy.act(x, greedy=True, rows=env.policy_rows(_lib.POLICY_FROZEN_NET), actions_out=actions)
+            obs, rew, done, over = env.step(actions.view(W, N))
             ret += rew.view(-1).double()
             fl = env.get_state()[2]
             now = ((fl & _lib.F_AT_GOAL) != 0) & ~reached

@@ -78,7 +78,7 @@ class FusedPolicy(object):
         return t
 
     def forward(self, x: torch.Tensor, sample: Optional[bool] = None, greedy: bool = False,
-                rows: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                rows: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, actions_out: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         """x float32 [B, input_size] (rows may be strided: a column slice of the env's obs tensor) ->
         (p [B, A], v [B], actions int32 [B] or None).  ``rows`` = (row_index int32 [B], row_count int32 [1]) on the
@@ -94,6 +94,10 @@ class FusedPolicy(object):
         v = new((B,), dtype=torch.float32, device=self.device)
         want_actions = greedy if sample is None else (sample or greedy)
         a = new((B,), dtype=torch.int32, device=self.device) if want_actions else None
+        if actions_out is not None:                        # with a row list: ONLY the listed rows' actions are overwritten
+            if actions_out.dtype != torch.int32 or actions_out.numel() != B or not actions_out.is_contiguous():
+                raise ValueError("actions_out must be a contiguous int32 tensor of B elements")
+            a = actions_out
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         if rows is None:
             _lib.check(self._lib.cavoid_policy_forward(self._h, ptr(x), B, stride, ptr(p), ptr(v), ptr(a), 1 if greedy else 0,
@@ -107,9 +111,9 @@ class FusedPolicy(object):
         p, v, _ = self.forward(x, sample=False)
         return p, v
 
-    def act(self, x: torch.Tensor, greedy: bool = False, rows=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def act(self, x: torch.Tensor, greedy: bool = False, rows=None, actions_out=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """predict + select_action (ProcessAgent.py:89-103,128-144): (actions int32 [B], p, v)."""
-        p, v, a = self.forward(x, sample=True, greedy=greedy, rows=rows)
+        p, v, a = self.forward(x, sample=True, greedy=greedy, rows=rows, actions_out=actions_out)
         return a, p, v
 
 

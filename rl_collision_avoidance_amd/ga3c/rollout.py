@@ -45,8 +45,14 @@ class BatchedRollout(object):
     def __init__(self, env: BatchedCollisionAvoidanceEnv, policy: Optional[Policy], time_max: Optional[int] = None,
                  discount: float = 0.97, ring_len: Optional[int] = None, dup_capacity: Optional[int] = None,
                  episode_capacity: Optional[int] = None, reflush_done: bool = True, greedy: bool = False,
-                 generator: Optional[torch.Generator] = None, skip_finished: Optional[bool] = None):
+                 generator: Optional[torch.Generator] = None, skip_finished: Optional[bool] = None, frozen_policy=None):
         self.env, self.policy = env, policy
+        # the network behind the scripted "frozen network" agents (policy 4, SURVEY section 8f-N3: the GA3C-CADRL agent -- a
+        # NON-learning agent driven by a frozen NetworkVP_rnn, /root/reference/ga3c/GA3C/Server.py:36): a FusedPolicy whose argmax
+        # action replaces the learner's sample on exactly those rows (cavoid_policy_rows lists them on the device)
+        self.frozen_policy = frozen_policy
+        if frozen_policy is None and float(env.cfg.gen_frozen_fraction) > 0.0 and float(env.cfg.gen_nonlearning_fraction) > 0.0:
+            raise ValueError("the env generates frozen-network agents: pass frozen_policy (a FusedPolicy)")
         cfg = env.config
         self.time_max = int(time_max if time_max is not None else getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
         self.discount = float(getattr(cfg, "DISCOUNT", discount))
@@ -140,14 +146,21 @@ class BatchedRollout(object):
                                                                 p(self.row_index), p(self.row_count), self.env._stream()),
                            "cavoid_rollout_active_rows")
                 rows = (self.row_index, self.row_count)
-            actions, _, v = self.policy.act(obs.view(W * N, -1)[:, 1:], greedy=self.greedy, rows=rows)
+            x = obs.view(W * N, -1)[:, 1:]
+            actions, _, v = self.policy.act(x, greedy=self.greedy, rows=rows)
+            if self.frozen_policy is not None:             # policy-4 agents take the frozen network's argmax instead
+                self.frozen_policy.act(x, greedy=True, rows=self.env.policy_rows(_lib.POLICY_FROZEN_NET), actions_out=actions)
             return actions.reshape(W, N), v.reshape(W, N)
         p, v = self.policy(obs[..., 1:].reshape(W * N, -1))
         if self.greedy:
             actions = p.argmax(dim=-1)
         else:
             actions = torch.multinomial(p, 1, generator=self.generator).squeeze(-1)
-        return actions.to(torch.int32).reshape(W, N), v.reshape(W, N).to(torch.float32)
+        actions = actions.to(torch.int32).contiguous()
+        if self.frozen_policy is not None:
+            self.frozen_policy.act(obs.view(W * N, -1)[:, 1:], greedy=True, rows=self.env.policy_rows(_lib.POLICY_FROZEN_NET),
+                                   actions_out=actions)
+        return actions.reshape(W, N), v.reshape(W, N).to(torch.float32)
 
     def step(self, actions: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None):
         """One env step of every world + experience bookkeeping.  ``actions``/``values`` override the
@@ -169,6 +182,64 @@ class BatchedRollout(object):
         self._cur = 1 - self._cur
         self.step_index += 1
         return rew, done, game_over
+
+    # -- the fused actor: K closed-loop steps in ONE launch -------------------------------------------------------
+    @property
+    def fused_available(self) -> bool:
+        """``run_fused`` applies: a ``FusedPolicy`` on the bf16-split kernel, no ORCA agents / velocity actions / row lists."""
+        import os
+        cfg = self.env.cfg
+        return (getattr(self.policy, "accepts_strided_obs", False) and not self.skip_finished and not cfg.rvo_enabled
+                and self.frozen_policy is None
+                and cfg.dynamics != 2 and not (cfg.gen_mode == 1 and cfg.gen_pool_size <= 0)
+                and os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0"))
+
+    def _actor_buffers(self):
+        if getattr(self, "_bufs", None) is None:
+            p = lambda t: t.data_ptr()
+            b = _lib.CavoidRolloutBuffers()
+            b.struct_size = C.sizeof(_lib.CavoidRolloutBuffers)
+            b.x, b.val, b.ret, b.act, b.emit_t = p(self.x), p(self.val), p(self.ret), p(self.act_ring), p(self.emit_t)
+            b.dup_x, b.dup_r, b.dup_a, b.dup_src, b.dup_count = p(self.dup_x), p(self.dup_r), p(self.dup_a), p(self.dup_src), p(self.dup_count)
+            b.dup_capacity, b.ep_out, b.ep_count, b.ep_capacity = self.dup_capacity, p(self.ep_out), p(self.ep_count), self.episode_capacity
+            W, N, dev = self.env.num_worlds, self.env.max_agents, self.env.device
+            self._act_out = torch.zeros((W, N), dtype=torch.int32, device=dev)
+            self._val_out = torch.zeros((W, N), dtype=torch.float32, device=dev)
+            self._bufs = b
+        return self._bufs
+
+    def run_fused(self, n_steps: int) -> None:
+        """``n_steps`` closed-loop steps of every world -- predict, select_action, env.step, Experience bookkeeping
+        (ProcessAgent.py:116-211) -- in ONE launch (``cavoid_actor_run``): per tile of worlds a workgroup runs the policy
+        on its own rows, steps its own worlds and records the step, with no kernel boundary and no host in between.
+        Bit-identical to ``n_steps`` calls of ``step()``; capturable into a hipGraph."""
+        if not self.fused_available:
+            raise RuntimeError("run_fused needs a FusedPolicy and a configuration the fused kernel carries (see fused_available)")
+        env, pol = self.env, self.policy
+        b = self._actor_buffers()
+        cur, nxt = self._obs_buffers[self._cur], self._obs_buffers[1 - self._cur]
+        p = BatchedCollisionAvoidanceEnv._ptr
+        _lib.check(self._lib.cavoid_actor_run(env._h, pol._h, self._h, C.byref(b), p(cur), p(nxt), p(env.rewards), p(env.done),
+                                              p(env.game_over), p(self._act_out), p(self._val_out), int(n_steps), 1 if self.greedy else 0,
+                                              env._stream()), "cavoid_actor_run")
+        self._cur = (self._cur + int(n_steps)) & 1
+        self.step_index += int(n_steps)
+
+    def capture_fused(self, steps_per_graph: int = 8) -> None:
+        """``run_fused(steps_per_graph)`` as a one-node hipGraph (``replay`` then costs one graph launch per K steps)."""
+        if steps_per_graph < 2 or steps_per_graph % 2:
+            raise ValueError("steps_per_graph must be a positive even number")
+        side = torch.cuda.Stream(device=self.env.device)
+        side.wait_stream(torch.cuda.current_stream(self.env.device))
+        with torch.cuda.stream(side):
+            self.run_fused(2)
+        torch.cuda.current_stream(self.env.device).wait_stream(side)
+        torch.cuda.synchronize(self.env.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.run_fused(steps_per_graph)
+        self.step_index -= steps_per_graph                # capture records, it does not execute
+        self._graph_steps = steps_per_graph
 
     # -- hipGraph path ---------------------------------------------------------------------------------
     def capture(self, steps_per_graph: int = 2) -> None:

@@ -86,6 +86,21 @@ def main(argv=None) -> None:
                          "finish; prints success / collision / timeout rates (use with --load)")
     ap.add_argument("--pretrain-steps", type=int, default=0,
                     help="supervised initialisation before RL (the role of Regression.py): Adam steps on teacher-driven rollouts")
+    ap.add_argument("--scenario", default="ring", choices=["ring", "box"],
+                    help="scenario generator: ring = GEN v1 (antipodal goals on a ring), box = GEN v2 (random starts / goals in a box "
+                         "with minimum separations: the shape of the reference's get_testcase_random, TEST_CASE_FN run-ws/config.yaml:281-283)")
+    ap.add_argument("--scripted-fraction", type=float, default=0.0,
+                    help="P(an agent other than agent 0 runs a scripted policy) -- the reference trained against 'static / non-coop / RVO' "
+                         "mixes (checkpoints/RL/wandb/run-2018-backup/checkpoints/index.txt:1-3)")
+    ap.add_argument("--static-fraction", type=float, default=0.34, help="of the scripted agents: P(static)")
+    ap.add_argument("--rvo-fraction", type=float, default=0.33, help="... P(RVO / ORCA)")
+    ap.add_argument("--frozen-fraction", type=float, default=0.0,
+                    help="... P(frozen network: a NON-learning agent driven by a frozen NetworkVP_rnn -- the GA3C-CADRL agent, "
+                         "Server.py:36); the rest are non-cooperative")
+    ap.add_argument("--frozen-policy", default=None,
+                    help="checkpoint of the network behind the frozen-network agents (default: a frozen copy of the starting weights)")
+    ap.add_argument("--no-actor-kernel", action="store_true",
+                    help="run the actors as one launch per phase in a hipGraph instead of the fused actor kernel (cavoid_actor_run)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--print-every", type=int, default=2000, help="stats line every n episodes (rank 0)")
     ap.add_argument("--faithful-reflush", action="store_true", help="keep the reference's post-done re-flush quirk")
@@ -110,6 +125,11 @@ def main(argv=None) -> None:
     class Cfg(EnvConfig):
         def __init__(self):
             self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            self.TEST_CASE_GENERATOR = args.scenario
+            self.SCRIPTED_AGENT_FRACTION = args.scripted_fraction
+            self.SCRIPTED_STATIC_FRACTION = args.static_fraction
+            self.SCRIPTED_RVO_FRACTION = args.rvo_fraction if args.scripted_fraction > 0 else 0.0
+            self.SCRIPTED_FROZEN_NET_FRACTION = args.frozen_fraction if args.scripted_fraction > 0 else 0.0
             EnvConfig.__init__(self)
     cfg = Cfg()
     offset, count = shard_range(args.worlds, rank, size)
@@ -127,11 +147,23 @@ def main(argv=None) -> None:
     episodes_before = 0
     if args.load:
         episodes_before = load_checkpoint(args.load, net, trainer, device)
+    # the network behind the frozen-network agents: its own weights (a checkpoint, or a copy of the starting ones), never trained
+    frozen = None
+    if args.scripted_fraction > 0 and args.frozen_fraction > 0:
+        if net.arch != "rnn":
+            raise SystemExit("--frozen-fraction needs the rnn architecture (FusedPolicy)")
+        import copy
+        frozen_net = copy.deepcopy(net)
+        if args.frozen_policy:
+            load_checkpoint(args.frozen_policy, frozen_net, A3CTrainer(frozen_net, distributed=False), device)
+        for prm in frozen_net.parameters():
+            prm.requires_grad_(False)
+        frozen = FusedPolicy(frozen_net, seed=0)
     if args.evaluate:
         from .evaluate import evaluate
         if fused is not None:
             fused.refresh()
-        res = evaluate(env, fused if fused is not None else net.predict_p_and_v, rounds=args.evaluate)
+        res = evaluate(env, fused if fused is not None else net.predict_p_and_v, rounds=args.evaluate, frozen_policy=frozen)
         if rank == 0:
             print("[Evaluate] " + "  ".join("%s %.4f" % (k, v) if isinstance(v, float) else "%s %d" % (k, v) for k, v in res.items()),
                   flush=True)
@@ -157,14 +189,17 @@ def main(argv=None) -> None:
     time_max = int(getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
     ring_len = (time_max + 2) + args.steps_per_graph + 8
     roll = BatchedRollout(env, fused if fused is not None else net.predict_p_and_v, reflush_done=args.faithful_reflush,
-                          greedy=args.play, ring_len=max(ring_len, 2 * (time_max + 2) + 8),
+                          greedy=args.play, ring_len=max(ring_len, 2 * (time_max + 2) + 8), frozen_policy=frozen,
                           dup_capacity=(count * N * (args.steps_per_graph + 1) + 1024) if args.faithful_reflush else None)
     stats = EpisodeStats(print_every=args.print_every if rank == 0 else 0, agents=count)
     anneal_over = args.annealing_episodes or args.episodes
     next_save = episodes_before + args.save_every
     finished = 0
     roll.reset()
-    roll.capture(steps_per_graph=args.steps_per_graph)
+    if roll.fused_available and not args.no_actor_kernel:
+        roll.capture_fused(steps_per_graph=args.steps_per_graph)       # K closed-loop steps per launch (cavoid_actor_run)
+    else:
+        roll.capture(steps_per_graph=args.steps_per_graph)
     done_flag = torch.zeros(1, device=device)
     t0 = time.time()
     while True:

@@ -1,7 +1,7 @@
 """bench.py's N>1 plumbing: `python bench.py --gpus N` with no launcher around it starts its own ranks
 (torch.distributed.run on 127.0.0.1), they rendezvous, barrier and MAX-reduce, rank 0 prints ONE JSON line.
 CPU box: the GPU-free `--rendezvous-only` form over gloo.  GPU box: a 2-rank dry run of the real bench on ONE device
-(`--backend gloo --share-device`), including the configs[2] gather extra."""
+(`--backend gloo --share-device`), with the configs[2] gather of the packed records inside the timed region."""
 import json
 import os
 import subprocess
@@ -41,6 +41,12 @@ def test_bench_two_rank_dry_run_on_one_device():
                  "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc"], 900)
     assert line["n_gpus"] == 2 and line["steps"] == 40 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 2 * 2048 * 4 * 40 / (line["ms_per_step"] * 40e-3)) / line["value"] < 1e-6
-    assert "error" not in line["extra"]["allgather"], line["extra"]["allgather"]
-    assert line["extra"]["allgather"]["bytes_received_per_rank"] == 2 * 2048 * 4 * 29 * 4
-    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"]
+    # N > 1: the gather of the packed records is INSIDE the timed region (BASELINE configs[2]); the shard-only rate is the extra
+    g = line["extra"]["configs2_gather"]
+    assert "error" not in g, g
+    assert g["bytes_received_per_rank_per_step"] == 1 * 2048 * 4 * 29 * 4 and g["steps_per_launch"] == 40
+    assert g["agent_steps_per_s_with_gather"] == line["value"] and g["agent_steps_per_s_shard_only"] > 0
+    assert "gather" in line["config"]["parallelism"]
+    r = line["roofline"]
+    assert r["bound"] in ("latency", "valu-issue", "hbm") and 0 < r["frac"] < r["frac_contract"]
+    assert r["one_step_launch"]["steps_per_launch"] == 1 and 0 < r["one_step_launch"]["frac"]

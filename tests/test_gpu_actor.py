@@ -1,0 +1,139 @@
+"""GPU tests of the fused actor kernel (`cavoid_actor_run`, csrc/cavoid_actor.hpp): K closed-loop GA3C actor steps -- policy
+forward, action selection, env.step, Experience bookkeeping -- in ONE launch, against the same K steps taken one launch at a
+time through `cavoid_policy_forward` + `cavoid_step_autoreset` + `cavoid_rollout_push` (BatchedRollout.step).  The fused kernel
+runs the very same statements per value, so everything must be BIT-identical: observations, world state, episode counters,
+the experience rings (state rows, rewards, returns, actions, emission stamps), the training rows handed to the trainer; only
+the episode totals are compared to float32 rounding (the step-by-step form accumulates them with unordered atomics).
+
+The step-by-step form itself is pinned elsewhere: env vs the float64 oracle (test_gpu_parity.py), rollout vs the reference's
+own ProcessAgent goldens (test_gpu_rollout.py), policy vs PyTorch fp32 (test_gpu_policy.py)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(W, N, seed, reflush, greedy=False, **over):
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.ga3c.network import NetworkVP_rnn
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+    cfg = Cfg()
+    env = BatchedCollisionAvoidanceEnv(W, cfg, device="cuda:0", seed=seed, **over)
+    torch.manual_seed(1234)
+    net = NetworkVP_rnn(cfg).to("cuda:0")
+    pol = FusedPolicy(net, seed=77)
+    # short chunks: many flushes; room for every duplicate row of the re-flush quirk (a full buffer drops rows in arrival order,
+    # which legitimately differs between the two forms)
+    roll = BatchedRollout(env, pol, reflush_done=reflush, greedy=greedy, time_max=5, dup_capacity=600000 if reflush else None)
+    roll.reset()
+    return env, net, pol, roll
+
+
+def _same(a, b, what):
+    assert torch.equal(a, b), what
+
+
+@pytest.mark.parametrize("N,W,reflush,greedy,over", [
+    (4, 512, False, False, dict()),                                     # BASELINE configs[4] shape (32 tiles)
+    (4, 1000, True, False, dict(gen_min_agents=2, gen_nonlearning_fraction=0.3)),    # the reference's re-flush quirk, scripted agents, ragged last tile
+    (10, 300, False, False, dict(gen_min_agents=2, gen_nonlearning_fraction=0.2)),   # configs[3] shape (6 worlds per tile, 4 idle rows)
+    (3, 130, False, True, dict(gen_pool_size=0)),                       # greedy (PLAY_MODE), in-kernel scenario generator
+    (2, 64, False, False, dict(gen_mode=1, gen_pool_size=200)),         # box scenarios from the pool
+])
+def test_fused_actor_equals_step_by_step(N, W, reflush, greedy, over):
+    seed = 21
+    env_a, net_a, pol_a, a = _make(W, N, seed, reflush, greedy, **over)
+    env_b, net_b, pol_b, b = _make(W, N, seed, reflush, greedy, **over)
+    assert a.fused_available
+    for p, q in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(p, q)
+    _same(a.obs, b.obs, "first observation")
+    total = 0
+    for k in (2, 1, 7, 16, 4) + (16,) * 14 + (3,):                       # odd counts too: the observation buffers alternate
+        a.run_fused(k)
+        for _ in range(k):
+            b.step()
+        total += k
+        if total > 40 and total % 64:                                    # (full comparisons early on, then every fourth launch)
+            continue
+        _same(a.obs, b.obs, ("obs", total))
+        for x, y in zip(env_a.get_state(), env_b.get_state()):
+            _same(x, y, ("state", total))
+        _same(env_a.episode, env_b.episode, ("episode", total))
+        _same(env_a.rewards, env_b.rewards, ("rewards", total))
+        _same(env_a.done, env_b.done, ("done", total))
+        _same(env_a.game_over, env_b.game_over, ("game_over", total))
+        for name in ("x", "val", "ret", "act_ring", "emit_t"):
+            _same(getattr(a, name), getattr(b, name), (name, total))
+        assert a.step_index == b.step_index == total
+    assert env_a.episode.max().item() >= 1
+    # what reaches the trainer and the stats process
+    ba, bb = a.drain(flush_all=True), b.drain(flush_all=True)
+    assert len(ba) == len(bb) > 0 and ba.dropped == bb.dropped == 0
+    ka = np.lexsort(ba.src.cpu().numpy().T[::-1])
+    kb = np.lexsort(bb.src.cpu().numpy().T[::-1])
+    assert np.array_equal(ba.src.cpu().numpy()[ka], bb.src.cpu().numpy()[kb])
+    assert np.array_equal(ba.x.cpu().numpy()[ka], bb.x.cpu().numpy()[kb])
+    assert np.array_equal(ba.r.cpu().numpy()[ka], bb.r.cpu().numpy()[kb])
+    assert np.array_equal(ba.a_index.cpu().numpy()[ka], bb.a_index.cpu().numpy()[kb])
+    ea, eb = a.drain_episodes().cpu().numpy(), b.drain_episodes().cpu().numpy()
+    assert len(ea) == len(eb) > 0
+    ea, eb = ea[np.lexsort(ea.T[::-1])], eb[np.lexsort(eb.T[::-1])]
+    assert np.array_equal(ea[:, 0], eb[:, 0]) and np.array_equal(ea[:, 2], eb[:, 2])
+    np.testing.assert_allclose(ea[:, 1], eb[:, 1], rtol=1e-6, atol=1e-6)
+    # and the two forms interleave: each continues where the other stopped
+    a.step(); a.run_fused(3)
+    b.run_fused(2); b.step(); b.step()
+    _same(a.obs, b.obs, "interleaved obs")
+    _same(a.emit_t, b.emit_t, "interleaved emit_t")
+    for r in (a, b):
+        r.close()
+    for e in (env_a, env_b):
+        e.close()
+
+
+def test_fused_actor_graph_replay_equals_eager_calls():
+    """`capture_fused`: the K-step launch as a one-node hipGraph; replays advance the device-side counters like eager calls."""
+    W, N, seed = 256, 4, 3
+    env_a, _, _, a = _make(W, N, seed, False)
+    env_b, _, _, b = _make(W, N, seed, False)
+    a.capture_fused(steps_per_graph=4)          # (runs 2 warm-up steps outside the capture)
+    b.run_fused(2)
+    a.replay(3)
+    for _ in range(3):
+        b.run_fused(4)
+    _same(a.obs, b.obs, "obs")
+    for name in ("x", "ret", "emit_t"):
+        _same(getattr(a, name), getattr(b, name), name)
+    assert a.step_index == b.step_index == 14
+    for r in (a, b):
+        r.close()
+    env_a.close(); env_b.close()
+
+
+def test_fused_actor_refuses_what_it_does_not_carry():
+    from rl_collision_avoidance_amd import _lib
+    env, _, _, roll = _make(64, 4, 1, False, rvo_enabled=1)
+    assert not roll.fused_available
+    with pytest.raises(RuntimeError):
+        roll.run_fused(2)
+    # straight at the C ABI: a code, not a crash
+    b = roll._actor_buffers()
+    import ctypes as C
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = _lib.lib().cavoid_actor_run(env._h, roll.policy._h, roll._h, C.byref(b), p(roll._obs_buffers[0]), p(roll._obs_buffers[1]),
+                                     p(env.rewards), p(env.done), p(env.game_over), p(roll._act_out), p(roll._val_out), 2, 0, None)
+    assert rc == -4
+    rc = _lib.lib().cavoid_actor_run(env._h, roll.policy._h, roll._h, C.byref(b), p(roll._obs_buffers[0]), p(roll._obs_buffers[0]),
+                                     p(env.rewards), p(env.done), p(env.game_over), p(roll._act_out), p(roll._val_out), 2, 0, None)
+    assert rc == -1
+    roll.close(); env.close()

@@ -692,13 +692,45 @@ def test_box_generator_through_the_pool_and_refresh():
     assert torch.equal(env.obs, twin.obs) and torch.equal(env.episode, twin.episode)
     for x, y in zip(env.get_state(), twin.get_state()):
         assert torch.equal(x, y)
-    # without a pool GEN v2 cannot restart inside the step, and 16-agent worlds have no room for the ORCA scratch: codes, not crashes
+    # 16-agent worlds have no room for the ORCA scratch: a code, not a crash
     from rl_collision_avoidance_amd import _lib
     with pytest.raises(_lib.CavoidError):
         _env(8, 16, rvo_enabled=1)
-    bare = _env(8, N, gen_mode=1, gen_pool_size=0)
-    bare.reset()
-    with pytest.raises(_lib.CavoidError):
-        bare.step_autoreset(torch.zeros((8, N), dtype=torch.int32, device="cuda"))
-    for e in (env, twin, bare):
+    for e in (env, twin):
         e.close()
+
+
+@pytest.mark.parametrize("N,nonl,rvo", [(4, 0.0, 0.0), (4, 0.5, 0.4), (10, 0.3, 0.0), (7, 0.4, 0.3)])
+def test_box_scenarios_generated_inside_the_step(N, nonl, rvo):
+    """GEN v2 with gen_pool_size = 0: a world that ends restarts INSIDE the auto-reset step with a freshly generated box
+    scenario (the wavefront that owns the world places its agents cooperatively) -- the reference's fresh test case per
+    episode (TEST_CASE_FN, run-ws/config.yaml:281-283).  HIP vs the oracle, single steps and the in-launch step loop."""
+    W, steps, seed = 300, 150, 41
+    ocfg, _ = _oracle(N)
+    ogen = co.default_gen(2, N, nonl, 0.3, mode=1, rvo_fraction=rvo, pool_size=0)
+    env = _env(W, N, seed=seed, gen_min_agents=2, gen_mode=1, gen_pool_size=0, gen_nonlearning_fraction=nonl, gen_static_fraction=0.3,
+               gen_rvo_fraction=rvo, rvo_enabled=1 if rvo > 0 else 0)
+    env.reset()
+    st = co.State.empty(W, N)
+    ep = np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    _push(env, st)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = _goal_seeking_actions(rng, W, N)
+        out = env.step_autoreset(torch.from_numpy(acts).cuda())
+        _compare_step(("box-in-step", N, t), out, co.step_autoreset(ocfg, ogen, seed, st, ep, acts), env, st)
+        assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep)
+    assert (ep >= 1).mean() > 0.5
+    K = 30
+    acts = np.stack([_goal_seeking_actions(rng, W, N) for _ in range(K)])
+    slots = env.new_step_slots(K)
+    obs, rew, done, go = env.step_autoreset_n(torch.from_numpy(acts).cuda(), slots=slots)
+    for t in range(K):
+        oobs, orew, odone, ogo = co.step_autoreset(ocfg, ogen, seed, st, ep, acts[t])
+        assert np.array_equal(done[t].cpu().numpy(), odone) and np.array_equal(go[t].cpu().numpy(), ogo), t
+        d = np.abs(obs[t].cpu().numpy() - oobs)
+        d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2 * np.pi))
+        assert d.max() <= OBS_TOL, (t, d.max())
+    assert np.array_equal(_pull(env)[2], st.flags) and np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep)
+    env.close()

@@ -135,6 +135,76 @@ def test_graph_replay_equals_eager_steps():
     assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(a0, a1) and len(r0) > 0
 
 
+def test_rollout_with_rvo_and_frozen_network_agents_on_box_scenarios():
+    """SURVEY section 8f-N3 reached from the GA3C loop: box scenarios generated inside the step, a scripted mix of static / RVO /
+    frozen-network / non-cooperative agents.  The frozen-network agents act by THEIR network's argmax (checked row by row against
+    a direct forward pass of the frozen weights), never record experiences, and the step-by-step loop equals its hipGraph."""
+    from rl_collision_avoidance_amd import _lib
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.ga3c.network import NetworkVP_rnn
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    W, N = 384, 4
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            self.TEST_CASE_GENERATOR = "box"
+            self.SCRIPTED_AGENT_FRACTION = 0.7
+            self.SCRIPTED_STATIC_FRACTION = 0.2
+            self.SCRIPTED_RVO_FRACTION = 0.3
+            self.SCRIPTED_FROZEN_NET_FRACTION = 0.3
+            EnvConfig.__init__(self)
+    outs = []
+    for graphed in (False, True):
+        cfg = Cfg()
+        env = BatchedCollisionAvoidanceEnv(W, cfg, seed=9, gen_min_agents=2, gen_pool_size=0)
+        assert env.cfg.rvo_enabled == 1 and env.cfg.gen_mode == 1
+        net, frozen_net = NetworkVP_rnn(cfg, seed=1).cuda(), NetworkVP_rnn(cfg, seed=2).cuda()
+        pol, frozen = FusedPolicy(net, seed=5), FusedPolicy(frozen_net, seed=0)
+        with pytest.raises(ValueError):
+            BatchedRollout(env, pol)                          # the env generates frozen-network agents: their network is required
+        roll = BatchedRollout(env, pol, reflush_done=False, frozen_policy=frozen, ring_len=64)
+        assert not roll.fused_available                       # (ORCA agents: the step-by-step kernels carry them)
+        roll.reset()
+        if not graphed:
+            # one step by hand: the frozen rows carry the frozen network's argmax, the others the learner's draw
+            obs = roll.obs.clone()
+            flags = env.get_state()[2].view(W, N)
+            pol4 = ((flags >> _lib.F_POLICY_SHIFT) & _lib.F_POLICY_MASK) == _lib.POLICY_FROZEN_NET
+            assert pol4.sum().item() > 20 and ((flags >> 8) & 7 == 3).sum().item() > 20
+            actions, _ = roll.act(obs)
+            with torch.no_grad():
+                p_frozen = frozen_net.predict_p_and_v(obs.view(W * N, -1)[:, 1:].contiguous())[0].view(W, N, -1)
+            top2 = p_frozen.topk(2, dim=-1).values
+            clear = pol4 & ((top2[..., 0] - top2[..., 1]) > 1e-4)          # (skip numerical near-ties between the two kernels)
+            assert torch.equal(actions[clear].long(), p_frozen.argmax(dim=-1)[clear])
+            assert (obs[..., 0][pol4] == 0).all()
+            # (that act() consumed one policy launch; start over so that both runs see the same random stream)
+            roll.close(); env.close()
+            env = BatchedCollisionAvoidanceEnv(W, cfg, seed=9, gen_min_agents=2, gen_pool_size=0)
+            pol, frozen = FusedPolicy(net, seed=5), FusedPolicy(frozen_net, seed=0)
+            roll = BatchedRollout(env, pol, reflush_done=False, frozen_policy=frozen, ring_len=64)
+            roll.reset()
+            for _ in range(2 + 40):
+                roll.step()
+        else:
+            roll.capture(steps_per_graph=4)
+            roll.replay(10)
+        b = roll.drain(flush_all=True)
+        assert b.dropped == 0 and roll.lost_blocks == 0 and len(b) > 0
+        order = torch.argsort(b.src[:, 0].long() * 10**9 + b.src[:, 1].long() * 10**7 + b.src[:, 3].long() * 10**3 + b.src[:, 2].long() % 1000)
+        outs.append((roll.obs.clone(), [t.clone() for t in env.get_state()], b.x[order], b.r[order], b.a_index[order], env.episode.clone()))
+        # nothing a scripted agent did became a training row
+        flags = env.get_state()[2]
+        roll.close(); env.close()
+    (o0, s0, x0, r0, a0, e0), (o1, s1, x1, r1, a1, e1) = outs
+    assert torch.equal(o0, o1) and all(torch.equal(u, v) for u, v in zip(s0, s1)) and torch.equal(e0, e1)
+    assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(a0, a1)
+    assert e0.max().item() >= 1
+
+
 def test_rollout_with_policy_and_one_hot():
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
     W, N = 256, 4
