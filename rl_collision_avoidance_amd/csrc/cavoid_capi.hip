@@ -212,10 +212,8 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.gen_nonlearning = cfg->gen_nonlearning_fraction; k.gen_static = cfg->gen_static_fraction;
     k.gen_goal_jitter = cfg->gen_goal_jitter; k.gen_angle_jitter = cfg->gen_angle_jitter;
     k.gen_rvo = cfg->gen_rvo_fraction; k.gen_min_trip = cfg->gen_min_trip; k.gen_frozen = cfg->gen_frozen_fraction;
-    k.wrap_hi = cfg->wrap_closed_end ? std::nextafter(kPi, 4.0) : kPi;          /* a > pi  <=>  a >= next(pi) */
-    k.wrap_lo = cfg->wrap_closed_end ? std::nextafter(-kPi, 0.0) : -kPi;        /* a <= -pi <=>  a < next(-pi) */
     k.switches = (cfg->done_agents_collide ? 0u : kSwSkipDonePairs) | (cfg->sort_round_gap ? 0u : kSwExactGap) |
-                 (cfg->sort_tie_lateral ? 0u : kSwIndexTie);
+                 (cfg->sort_tie_lateral ? 0u : kSwIndexTie) | (cfg->wrap_closed_end ? kSwWrapClosed : 0u);
     k.gen_box_small_lo = cfg->gen_box_small[0]; k.gen_box_small_hi = cfg->gen_box_small[1];
     k.gen_box_large_lo = cfg->gen_box_large[0]; k.gen_box_large_hi = cfg->gen_box_large[1];
     k.gen_mode = cfg->gen_mode; k.gen_box_large_from = cfg->gen_box_large_from; k.pool_epoch = cfg->gen_pool_epoch;

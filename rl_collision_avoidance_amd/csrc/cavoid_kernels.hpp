@@ -58,8 +58,6 @@ struct KCfg {
     double gen_nonlearning, gen_static, gen_goal_jitter, gen_angle_jitter;
     double gen_rvo, gen_box_small_lo, gen_box_small_hi, gen_box_large_lo, gen_box_large_hi, gen_min_trip;
     double rvo_inv_horizon, rvo_collab, rvo_radius_scale, rvo_max_dh;
-    double wrap_hi, wrap_lo;     // U2: an angle a folds down when a >= wrap_hi, up when a < wrap_lo: (pi, -pi) for [-pi, pi); the next
-                                 // doubles above them for (-pi, pi]
     double gen_frozen;           // P(frozen-network agent) among the scripted ones
     int32_t max_other, width, sort_method, dynamics, actions_fp32, timeout_enabled, num_actions;
     int32_t gen_min_agents, gen_max_agents;
@@ -72,9 +70,9 @@ struct KCfg {
     int32_t rvo_lds_floats;      // per-wavefront LDS floats of the ORCA line scratch (0 unless rvo_enabled)
     int32_t park_floats;         // N >= kParkFromN: the obs tile region is at least this large (it parks the sort keys / gaps)
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
-    uint32_t switches;           // kSw* bits: the rarely flipped U-switches, ONE scalar (every kernel loads and pins it, with wrap_hi /
-                                 // wrap_lo, before its first wait: a lazily loaded kernel argument costs a scalar-memory round trip on
-                                 // the step's dependent chain -- five of them were 1.3 us of the 6.8 us one-step launch)
+    uint32_t switches;           // kSw* bits: the rarely flipped U-switches in ONE word, tested by uniform branches that sit OUTSIDE the
+                                 // unrolled hot loops (measured on the one-step launch at 4 x 8192, same box: separate scalars tested
+                                 // per neighbour 7.4 us; pinned in scalar registers at the top 7.0; this form 6.3 -- round 2: 6.5)
     uint32_t seed_lo, seed_hi;
     int64_t num_worlds, world_offset;
     const double *action_table;  // [num_actions][2]
@@ -84,6 +82,7 @@ enum : uint32_t {
     kSwSkipDonePairs = 1u,       // U4 flipped: a pair with an agent that was done before the step takes no part in E6
     kSwExactGap = 2u,            // U7a flipped: neighbours ordered by the exact gap (default: rounded to centimetres)
     kSwIndexTie = 4u,            // U7b flipped: ties by agent index alone (default: lateral offset, then index)
+    kSwWrapClosed = 8u,          // U2 flipped: angles wrap to (-pi, pi] (default: [-pi, pi))
 };
 struct KState {
     double *px, *py, *heading, *t_rem;
@@ -123,21 +122,27 @@ struct KIO {
 // wrap to [-pi, pi) by repeated +-2*pi, exactly the oracle's `while` loops: one branch-free fold each way covers every
 // table action (|heading + delta| < 3*pi); anything still outside (huge continuous actions) takes the loops, as a
 // wave-uniform branch.  A fold that does not apply leaves the value untouched, so the results are bit-identical.
-// U2: [-pi, pi) by default (hi = pi, lo = -pi); (-pi, pi] with hi / lo = the next doubles above pi / -pi (a > pi <=> a >= next(pi)).
-__device__ __forceinline__ double wrap_angle(double a, double hi, double lo) {
-    a = a >= hi ? a - 2.0 * kPi : a;
-    a = a < lo ? a + 2.0 * kPi : a;
-    if (CAVOID_RARE(__ballot(a >= hi || a < lo) != 0ull)) {
-        while (a >= hi) a -= 2.0 * kPi;
-        while (a < lo) a += 2.0 * kPi;
-    }
+// U2: the two conventions -- [-pi, pi) (default) and (-pi, pi] -- differ at ONE point: what the first calls -pi the second calls
+// pi (pi - 2 pi and -pi + 2 pi are exact).  So the closed-end form is the default fold (literal constants on the step's dependent
+// chain) plus a fix-up of that one value behind a uniform, rarely taken branch.
+__device__ __forceinline__ double wrap_closed_fixup(double a, uint32_t switches) {
+    if (CAVOID_RARE(switches & kSwWrapClosed)) a = a == -kPi ? kPi : a;
     return a;
 }
+__device__ __forceinline__ double wrap_angle(double a, uint32_t switches) {
+    a = a >= kPi ? a - 2.0 * kPi : a;
+    a = a < -kPi ? a + 2.0 * kPi : a;
+    if (CAVOID_RARE(__ballot(a >= kPi || a < -kPi) != 0ull)) {
+        while (a >= kPi) a -= 2.0 * kPi;
+        while (a < -kPi) a += 2.0 * kPi;
+    }
+    return wrap_closed_fixup(a, switches);
+}
 // one fold each way: enough for a difference of two angles of magnitude <= pi
-__device__ __forceinline__ double wrap_once(double h, double hi, double lo) {
-    h = h >= hi ? h - 2.0 * kPi : h;
-    h = h < lo ? h + 2.0 * kPi : h;
-    return h;
+__device__ __forceinline__ double wrap_once(double h, uint32_t switches) {
+    h = h >= kPi ? h - 2.0 * kPi : h;
+    h = h < -kPi ? h + 2.0 * kPi : h;
+    return wrap_closed_fixup(h, switches);
 }
 
 // wave-private LDS hand-off: LDS ops of one wavefront execute in order; the fences only stop the
@@ -322,7 +327,7 @@ __device__ __forceinline__ Ego ego_frame_exact(const KCfg &c, const Agent &a) {
     const double inv = e.dist > 1e-8 ? 1.0 / e.dist : 1.0;
     e.prll_x = e.tx * inv;
     e.prll_y = e.ty * inv;
-    e.heading_ego = wrap_once(a.heading - atan2(e.prll_y, e.prll_x), c.wrap_hi, c.wrap_lo);   // |heading|, |atan2| <= pi: one fold each way
+    e.heading_ego = wrap_once(a.heading - atan2(e.prll_y, e.prll_x), c.switches);   // |heading|, |atan2| <= pi: one fold each way
     return e;
 }
 
@@ -343,7 +348,7 @@ __device__ __forceinline__ Ego ego_from(const KCfg &c, double tx, double ty, dou
     const double inv = tiny ? 1.0 : y;
     e.prll_x = e.tx * inv;
     e.prll_y = e.ty * inv;
-    e.heading_ego = wrap_once(heading - (double)atan2f((float)e.ty, (float)e.tx), c.wrap_hi, c.wrap_lo);
+    e.heading_ego = wrap_once(heading - (double)atan2f((float)e.ty, (float)e.tx), c.switches);
     return e;
 }
 __device__ __forceinline__ Ego ego_frame_obs(const KCfg &c, const Agent &a) { return ego_from(c, (double)a.gx - a.px, (double)a.gy - a.py, a.heading); }
@@ -984,8 +989,9 @@ __device__ __forceinline__ void rvo_action(const KCfg &c, const Agent &a, int i,
     double delta = 0.0;
     if (speed > 0.0) {
         delta = atan2(vy, vx) - a.heading;
-        while (delta >= c.wrap_hi) delta -= 2.0 * kPi;
-        while (delta < c.wrap_lo) delta += 2.0 * kPi;
+        while (delta >= kPi) delta -= 2.0 * kPi;
+        while (delta < -kPi) delta += 2.0 * kPi;
+        delta = wrap_closed_fixup(delta, c.switches);
     }
     if (fabs(delta) > c.rvo_max_dh) { delta = copysign(c.rvo_max_dh, delta); speed = 0.0; }
     a0 = speed; a1 = delta;
@@ -1192,7 +1198,7 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
                 const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
                 dh = rate * c.dt;
             }
-            nh = wrap_angle(dh + a.heading, c.wrap_hi, c.wrap_lo);
+            nh = wrap_angle(dh + a.heading, c.switches);
             double sn, cs;
             sincos_bounded(nh, &sn, &cs);
             npx = a.px + a0 * cs * c.dt; npy = a.py + a0 * sn * c.dt;
@@ -1339,10 +1345,6 @@ template <int N, int MODE, bool RVO>
 //  pin them to 4 wavefronts/SIMD -- the LDS tile admits no more anyway -- at the price of a 1-register spill)
 __global__ void __launch_bounds__(256, (MODE == MODE_STEP_AUTORESET_PF ? 2 : (N <= CAVOID_OCC4_MAX_N ? 4 : CAVOID_OCC_LARGE_N)))
 env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
-    // the switches and the wrap limits: loaded with the first burst, not on the chain.  (Inputs of an empty asm -- NOT a local copy
-    // of the struct: a copy keeps every field it ever uses live in scalar registers, which then spill into vector registers,
-    // N = 10 one step per launch: 159 -> 181 VGPRs = 3 -> 2 wavefronts per SIMD.)
-    asm volatile("" ::"s"(c.switches), "s"(c.wrap_hi), "s"(c.wrap_lo));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ostride = io.obs ? io.obs_stride : c.width;
@@ -1383,7 +1385,6 @@ __host__ __device__ constexpr size_t pipe_lds_fixed_bytes() {
 
 template <int N, bool RVO>
 __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
-    asm volatile("" ::"s"(c.switches), "s"(c.wrap_hi), "s"(c.wrap_lo));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds_tab = reinterpret_cast<double *>(smem);
     PipeStage *stage = reinterpret_cast<PipeStage *>(smem + lds_floats_block() * sizeof(float));
@@ -1484,7 +1485,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                     const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
                     dh = rate * c.dt;
                 }
-                const double nh = wrap_angle(dh + a.heading, c.wrap_hi, c.wrap_lo);
+                const double nh = wrap_angle(dh + a.heading, c.switches);
                 double sn, cs;
                 sincos_bounded(nh, &sn, &cs);
                 const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;

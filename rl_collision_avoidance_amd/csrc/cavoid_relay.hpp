@@ -172,7 +172,7 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &t
         const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
         dh = rate * c.dt;
     }
-    const double nh = wrap_angle(dh + a.heading, c.wrap_hi, c.wrap_lo);
+    const double nh = wrap_angle(dh + a.heading, c.switches);
     double sn, cs;
     relay_sincos(trig, nh, &sn, &cs);
     const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         __builtin_amdgcn_s_setprio(3);
         KCfg cd = c;                                        // this role's constants, pinned in scalar registers (see P)
         asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.max_turn_rate), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
-                     "+s"(cd.timeout_enabled), "+s"(cd.wrap_hi), "+s"(cd.wrap_lo));
+                     "+s"(cd.timeout_enabled), "+s"(cd.switches));
         const RelayTrig trig = relay_trig_constants();
         Agent a;
         a.px = a.py = a.heading = a.t_rem = a.vx = a.vy = 0.0;
@@ -540,8 +540,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     } else {
         // ================================================ C: observation of every NC-th step ===================================
         __builtin_amdgcn_s_setprio(0);
-        KCfg cc = c;                                        // this role's switches / wrap limits, pinned (see KCfg::switches)
-        asm volatile("" : "+s"(cc.switches), "+s"(cc.wrap_hi), "+s"(cc.wrap_lo));
+        KCfg cc = c;                                        // this role's switch word, pinned like the other roles' constants
+        asm volatile("" : "+s"(cc.switches));
         const int cid = role - 2;
         float *tile = tiles + (size_t)cid * tile_floats;
         __syncthreads();
