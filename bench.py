@@ -130,7 +130,7 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
     from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedA3CTrainer, FusedPolicy
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
-    per_graph = int(os.environ.get("CAVOID_STEPS_PER_GRAPH", "8"))   # env steps per hipGraph replay (even): one drain (a host sync) per replay
+    per_graph = int(os.environ.get("CAVOID_STEPS_PER_GRAPH", "16"))  # env steps per hipGraph replay (even): one drain (a host sync) per replay
 
     def regime(fused: bool, train: bool, fused_trainer: bool = False, actor_kernel: bool = False):
         env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
@@ -139,7 +139,10 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         # a policy replica per GPU and NO collective in this extra: ranks drain different row counts, so the number of
         # optimiser steps differs between them
         trainer = FusedA3CTrainer(net, pol, distributed=False) if fused_trainer else A3CTrainer(net, distributed=False)
-        roll = BatchedRollout(env, pol if fused else net.predict_p_and_v, reflush_done=False)
+        # ring: every block from 'final' (older than TIME_MAX + 2 steps) back to the last drain = one replay, plus slack
+        time_max = int(getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
+        roll = BatchedRollout(env, pol if fused else net.predict_p_and_v, reflush_done=False,
+                              ring_len=max(2 * (time_max + 2) + 8, (time_max + 2) + per_graph + 10))
         roll.reset()
         if actor_kernel:                                     # the same per_graph steps as ONE launch of the fused actor kernel
             roll.capture_fused(steps_per_graph=per_graph)

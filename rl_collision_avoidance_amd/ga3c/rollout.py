@@ -51,7 +51,7 @@ class BatchedRollout(object):
         # NON-learning agent driven by a frozen NetworkVP_rnn, /root/reference/ga3c/GA3C/Server.py:36): a FusedPolicy whose argmax
         # action replaces the learner's sample on exactly those rows (cavoid_policy_rows lists them on the device)
         self.frozen_policy = frozen_policy
-        if frozen_policy is None and float(env.cfg.gen_frozen_fraction) > 0.0 and float(env.cfg.gen_nonlearning_fraction) > 0.0:
+        if policy is not None and frozen_policy is None and float(env.cfg.gen_frozen_fraction) > 0.0 and float(env.cfg.gen_nonlearning_fraction) > 0.0:
             raise ValueError("the env generates frozen-network agents: pass frozen_policy (a FusedPolicy)")
         cfg = env.config
         self.time_max = int(time_max if time_max is not None else getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))

@@ -147,9 +147,11 @@ def main(argv=None) -> None:
     episodes_before = 0
     if args.load:
         episodes_before = load_checkpoint(args.load, net, trainer, device)
-    # the network behind the frozen-network agents: its own weights (a checkpoint, or a copy of the starting ones), never trained
-    frozen = None
-    if args.scripted_fraction > 0 and args.frozen_fraction > 0:
+    def make_frozen():
+        """the network behind the frozen-network agents: its own weights (a checkpoint, or a copy of the weights RL starts from --
+        loaded or regressed), never trained"""
+        if not (args.scripted_fraction > 0 and args.frozen_fraction > 0):
+            return None
         if net.arch != "rnn":
             raise SystemExit("--frozen-fraction needs the rnn architecture (FusedPolicy)")
         import copy
@@ -158,8 +160,9 @@ def main(argv=None) -> None:
             load_checkpoint(args.frozen_policy, frozen_net, A3CTrainer(frozen_net, distributed=False), device)
         for prm in frozen_net.parameters():
             prm.requires_grad_(False)
-        frozen = FusedPolicy(frozen_net, seed=0)
+        return FusedPolicy(frozen_net, seed=0)
     if args.evaluate:
+        frozen = make_frozen()
         from .evaluate import evaluate
         if fused is not None:
             fused.refresh()
@@ -180,6 +183,7 @@ def main(argv=None) -> None:
         if rank == 0:
             print("[Regression] done: %s" % info, flush=True)
     steps_before = trainer.training_step
+    frozen = make_frozen()
     if fused is not None:
         fused.refresh(with_backward=isinstance(trainer, FusedA3CTrainer))      # weights may have come from a checkpoint
     if args.steps_per_graph < 2 or args.steps_per_graph % 2:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: kernel-trace --stats of the bench commands (N = 4 and N = 10, default and the driver's
 # K = 20 form, the full loop), PMC traffic, and the sweep.  usage: bash tools/profile_round.sh <tag>   (on the GPU box)
-tag=${1:-r02_a}; out=$PWD/gpurun_out/prof_$tag; mkdir -p $out; repo=$PWD
+tag=${1:-r03_a}; out=$PWD/gpurun_out/prof_$tag; mkdir -p $out; repo=$PWD
 export TMPDIR=/tmp
 prof() {   # prof <name> <bench args...>
   name=$1; shift
@@ -13,22 +13,23 @@ prof() {   # prof <name> <bench args...>
 prof kernel_trace_stats --no-cpu-baseline --no-full-loop --no-configs3 --no-pmc
 prof kernel_trace_stats_k20 --steps 20 --warmup 5 --no-cpu-baseline --no-full-loop --no-configs3 --no-pmc
 prof kernel_trace_stats_n10 --agents 10 --no-cpu-baseline --no-full-loop --no-pmc
-prof kernel_trace_stats_w1048576 --worlds 1048576 --steps 256 --warmup 64 --no-cpu-baseline --no-full-loop --no-configs3 --no-pmc
-prof kernel_trace_stats_n10_w262144 --agents 10 --worlds 262144 --steps 256 --warmup 64 --no-cpu-baseline --no-full-loop --no-pmc
+prof kernel_trace_stats_w1048576 --worlds 1048576 --slices 16 --steps 128 --warmup 32 --no-cpu-baseline --no-full-loop --no-configs3 --no-pmc
+prof kernel_trace_stats_n10_w262144 --agents 10 --worlds 262144 --slices 16 --steps 128 --warmup 32 --no-cpu-baseline --no-full-loop --no-pmc
 prof full_loop_kernel_trace_stats --steps 256 --warmup 64 --no-cpu-baseline --no-configs3 --no-pmc
 # PMC traffic (separate passes per counter, --kernel-trace only beside --pmc)
-for spec in "4 8192" "10 8192" "4 1048576" "10 262144"; do set -- $spec
-  python - <<PY > $out/${tag}_pmc_traffic_n$1_w$2.json 2>> $out/errors.txt
+for spec in "4 8192 64" "4 8192 1" "10 8192 64" "10 8192 1" "4 1048576 16" "10 262144 16"; do set -- $spec
+  python - <<PY > $out/${tag}_pmc_traffic_n$1_w$2_k$3.json 2>> $out/errors.txt
 import json, sys
 sys.path.insert(0, "$repo")
 import bench
-r = bench.measure_traffic($1, $2, 64, 256, timeout_s=400.0)
+r = bench.measure_traffic($1, $2, $3, max(4 * $3, 64), timeout_s=400.0, min_agents=2 if $1 == 10 else 0)
 M = $1 - 1
 if r is not None:
     per_step = r["traffic"] / r["steps_per_launch"]
-    r.update({"round": 2, "agents": $1, "worlds": $2, "traffic_bytes_per_step": per_step,
-              "algorithmic_bytes_per_step": bench.algorithmic_bytes_per_agent_step(M) * $1 * $2,
-              "real_bytes_per_step_expected": "action 4 + obs %d + reward 4 + done 1 per agent (state stays in registers)" % (4 * (6 + 7 * M))})
+    moved = bench.moved_bytes_per_agent_step(M, $1, $3 == 1) * $1 * $2
+    r.update({"round": 3, "agents": $1, "worlds": $2, "steps_per_launch": $3, "outputs": "per-step slots [K,W,N,.]" if $3 > 1 else "one step per launch",
+              "traffic_bytes_per_step": per_step, "moved_bytes_per_step_expected": moved, "traffic_over_moved": per_step / moved,
+              "contract_bytes_per_step": bench.algorithmic_bytes_per_agent_step(M) * $1 * $2})
 print(json.dumps(r, indent=1))
 PY
 done
@@ -36,4 +37,4 @@ timeout 1500 python bench.py --sweep --full-loop > $out/${tag}_bench.json 2>> $o
 timeout 900 python bench.py --agents 10 --sweep --no-full-loop > $out/${tag}_bench_n10.json 2>> $out/errors.txt
 timeout 300 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_k20.json 2>> $out/errors.txt   # the driver's command line
 ls -la $out; cat $out/errors.txt 2>/dev/null | tail -5
-head -c 1500 $out/${tag}_kernel_trace_stats.csv; head -c 900 $out/${tag}_pmc_traffic_n4_w8192.json
+head -c 1500 $out/${tag}_kernel_trace_stats.csv; head -c 900 $out/${tag}_pmc_traffic_n4_w8192_k64.json
