@@ -142,7 +142,7 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         # ring: every block from 'final' (older than TIME_MAX + 2 steps) back to the last drain = one replay, plus slack
         time_max = int(getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
         roll = BatchedRollout(env, pol if fused else net.predict_p_and_v, reflush_done=False,
-                              ring_len=max(2 * (time_max + 2) + 8, (time_max + 2) + per_graph + 10))
+                              ring_len=max(2 * (time_max + 2) + 8, (time_max + 2) + 2 * per_graph + 10))
         roll.reset()
         if actor_kernel:                                     # the same per_graph steps as ONE launch of the fused actor kernel
             roll.capture_fused(steps_per_graph=per_graph)
@@ -151,17 +151,26 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         rows = [0]
 
         def run(n_replays):
-            for _ in range(n_replays):
-                roll.replay(1)
-                b = roll.drain(provenance=False)             # hand-over of the rows that became training rows (the PPS numerator)
+            # the hand-over of replay k is collected while replay k+1 runs (drain_begin / drain_end): the GPU goes from launch to
+            # launch, the host's read-back of the row count is off the critical path
+            pending = None
+
+            def consume(b):
                 rows[0] += len(b)
                 if not train:
-                    continue
+                    return
                 for lo in range(0, len(b), train_rows):
                     trainer.train(b.x[lo:lo + train_rows], b.r[lo:lo + train_rows],
                                   b.a_index[lo:lo + train_rows] if fused_trainer else b.a[lo:lo + train_rows])
                 if pol is not None and len(b) and not fused_trainer:
                     pol.refresh()
+            for _ in range(n_replays):
+                roll.replay(1)
+                h = roll.drain_begin()                       # rows that became training rows (the PPS numerator): compaction enqueued
+                if pending is not None:
+                    consume(roll.drain_end(pending))
+                pending = h
+            consume(roll.drain_end(pending))
             return n_replays * per_graph * W * N
         run(8)
         rows[0] = 0
@@ -202,8 +211,8 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         torch_us = timed(lambda: net.predict_p_and_v(obs.contiguous()), 30)
         lens = obs[:, 0].clamp(0, M)
         # The inference kernel computes the float32 GEMMs by error-free bf16 splitting (csrc/cavoid_policy_split.hpp): every
-        # float32 product is five bf16 partial products accumulated in float32.  Reported: the bf16 MFMA work really issued
-        # (32-wide K chunks x 5 partial products; LSTM step 0 needs the input chunk only; a 64-row tile runs as many LSTM
+        # float32 product is three (CAVOID_POLICY_PRODUCTS: 3..5) bf16 partial products accumulated in float32.  Reported: the bf16
+        # MFMA work really issued (32-wide K chunks x the partial products; LSTM step 0 needs the input chunk only; a 64-row tile runs as many LSTM
         # steps as its longest row needs) against the dense bf16 peak -- or, with CAVOID_POLICY_F32=1, the float32-MFMA kernel's
         # issued work against the float32-MFMA peak.
         steps = lens.view(-1, 64).max(dim=1).values.mean().item() if (W * N) % 64 == 0 else float(M)
@@ -211,12 +220,13 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         flop = W * N * chunks * 16 * 256 * 2
         split = os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0")
         chunks32 = (1 + 3 * max(steps - 1, 0)) + 3 + 8 + 8
-        flop_bf16 = W * N * 5 * 32 * 2 * (chunks32 * 256 + 8 * 16)
+        products = int(os.environ.get("CAVOID_POLICY_PRODUCTS", "3"))   # bf16 partial products per float32 product (csrc/cavoid_policy_split.hpp)
+        flop_bf16 = W * N * products * 32 * 2 * (chunks32 * 256 + 8 * 16)
         env.close()
         out = {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us}
         if split:
             out.update({"issued_TFLOPs": flop_bf16 / fused_us * 1e-6, "peak_TFLOPs": 2500.0, "frac": flop_bf16 / fused_us * 1e-6 / 2500.0,
-                        "bound": "mfma", "dtype": "f32 in/out; bf16 x 5 error-free split products, f32 accumulate",
+                        "bound": "mfma", "dtype": "f32 in/out; bf16 split, %d partial products per float32 product, f32 accumulate" % products,
                         "kernel": "cavoid::policy_forward_split_kernel"})
         else:
             out.update({"issued_TFLOPs": flop / fused_us * 1e-6, "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3,
@@ -502,31 +512,45 @@ def main() -> None:
     gather_in_metric = world_size > 1 and not args.no_gather
     slots = None if (args.overwrite_outputs or gather_in_metric) else env.new_step_slots(min(args.slices, max(args.steps, 1)))
     sh = None
+    extra = {}
     if gather_in_metric:
-        # configs[2]: this rank's shard of a (world_size x W)-world env; every launch writes packed records into per-step slots
-        # and their gather to every rank is begun on the communicator's stream -- launch t+1 runs while gather t is on the wire.
-        # nccl: cavoid_gather* (RCCL); gloo dry run (CPU tests / --share-device): the same records through torch.distributed.
-        from rl_collision_avoidance_amd.sharding import ShardedEnv
-        env.close()
-        sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7)
-        sh.reset()
-        env = sh.env
-        native = args.backend == "nccl"
-        # launches of `spl` steps: the largest divisor of K that fits the action slices, so that K steps are whole launches
-        spl = max(d for d in range(1, min(args.slices, args.steps) + 1) if args.steps % d == 0)
-        acts_l = acts[:spl].contiguous()
-        gslots = None if native else env.new_step_slots(spl, packed=True)
+        try:
+            # configs[2]: this rank's shard of a (world_size x W)-world env; every launch writes packed records into per-step slots
+            # and their gather to every rank is begun on the communicator's stream -- launch t+1 runs while gather t is on the wire.
+            # nccl: cavoid_gather* (RCCL); gloo dry run (CPU tests / --share-device): the same records through torch.distributed.
+            from rl_collision_avoidance_amd.sharding import ShardedEnv
+            env.close()
+            sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7)
+            sh.reset()
+            env = sh.env
+            native = args.backend == "nccl"
+            # launches of `spl` steps: the largest divisor of K that fits the action slices, so that K steps are whole launches
+            spl = max(d for d in range(1, min(args.slices, args.steps) + 1) if args.steps % d == 0)
+            acts_l = acts[:spl].contiguous()
+            gslots = None if native else env.new_step_slots(spl, packed=True)
 
-        def run_steps_gather(k):
-            for _ in range(-(-k // spl)):
-                if native:
-                    sh.gathered(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))
-                else:
-                    from rl_collision_avoidance_amd.sharding import gather_step_outputs
-                    env.step_autoreset_packed(acts_l, gslots)
-                    gather_step_outputs(gslots.packed.transpose(0, 1).contiguous(), world_size * W)
-        run_steps_gather(args.warmup)
-    else:
+            def run_steps_gather(k):
+                for _ in range(-(-k // spl)):
+                    if native:
+                        sh.gathered(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))
+                    else:
+                        from rl_collision_avoidance_amd.sharding import gather_step_outputs
+                        env.step_autoreset_packed(acts_l, gslots)
+                        gather_step_outputs(gslots.packed.transpose(0, 1).contiguous(), world_size * W)
+            run_steps_gather(args.warmup)
+            sync_all()
+        except Exception as exc:      # noqa: BLE001 -- a broken exchange must not cost the shard-only number: say so and time that
+            extra["configs2_gather"] = {"error": repr(exc), "note": "the gather failed before the timed region: value is the SHARD-ONLY rate"}
+            gather_in_metric = False
+            if sh is not None:
+                try:
+                    sh.close()
+                except Exception:      # noqa: BLE001
+                    pass
+                sh = None
+            env, acts = make(W)
+            slots = None if args.overwrite_outputs else env.new_step_slots(min(args.slices, max(args.steps, 1)))
+    if not gather_in_metric:
         run_steps(env, acts, args.warmup, slots)
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks -------
@@ -550,7 +574,6 @@ def main() -> None:
         slots = env.new_step_slots(min(args.slices, max(args.steps, 1)))
     roofline = kernel_figures(env, acts, N, W, args.steps, slots)
 
-    extra = {}
     if gather_in_metric:
         # the same K steps WITHOUT the gather (every rank its own shard, per-step slots, a barrier only): what the exchange costs
         try:

@@ -43,8 +43,10 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
         r->c.obs_width != e->k.width || h->in_size != e->k.width - 1 || h->max_other != e->cfg.max_other)
         return CAVOID_EINVAL;
     // what the fused kernel does not carry (the step-by-step entry points do): ORCA agents, velocity actions, the float32-MFMA
-    // inference kernel, box scenarios generated inside the step (with a pool they are fine)
-    if (e->cfg.rvo_enabled || e->cfg.dynamics == CAVOID_DYN_HOLONOMIC || !h->use_split || (e->cfg.gen_mode == 1 && e->pool_size <= 0))
+    // inference kernel or a non-default number of split products (the kernel carries the default form of cavoid_policy_forward, so
+    // that both stay bit-identical), box scenarios generated inside the step (with a pool they are fine)
+    if (e->cfg.rvo_enabled || e->cfg.dynamics == CAVOID_DYN_HOLONOMIC || !h->use_split || h->split_products != kSpDefaultProducts ||
+        (e->cfg.gen_mode == 1 && e->pool_size <= 0))
         return CAVOID_EUNSUPPORTED;
     const KCfg &k = e->k;
     int tile = (k.tile_rows * k.width + 3) & ~3;

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
                         if (4 * g + r == A) io.values[row] = logit[r];
                 }
             };
-            policy_split_tile(sa, planes, len_f, wave_max, rows, tid, load, emit);
+            policy_split_tile<kSpDefaultProducts>(sa, planes, len_f, wave_max, rows, tid, load, emit);
         }
         __syncthreads();                                     // the tile's actions / values are in memory; the planes are idle
 

@@ -38,6 +38,7 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     h->frags = reinterpret_cast<f32x4 *>(b + o_frag); h->bias = reinterpret_cast<float *>(b + o_bias);
     h->sfrags = reinterpret_cast<uint4 *>(b + o_sfrag);
     if (const char *ov = std::getenv("CAVOID_POLICY_F32")) h->use_split = std::atoi(ov) == 0;
+    if (const char *ov = std::getenv("CAVOID_POLICY_PRODUCTS")) { const int v = std::atoi(ov); if (v >= 3 && v <= 5) h->split_products = v; }
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
     h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
@@ -48,7 +49,11 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
                             (int)policy_lds_bytes(4)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_backward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_lds_bytes(4)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_split_lds_bytes()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_split_lds_bytes()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_split_lds_bytes()) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP;
     }
@@ -120,7 +125,10 @@ static int policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_
     if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
     if (h->use_split) {
         SplitArgs sa{a, h->sfrags};
-        hipLaunchKernelGGL(policy_forward_split_kernel, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), static_cast<hipStream_t>(stream), sa);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (h->split_products == 5) hipLaunchKernelGGL(policy_forward_split_kernel<5>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
+        else if (h->split_products == 4) hipLaunchKernelGGL(policy_forward_split_kernel<4>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
+        else hipLaunchKernelGGL(policy_forward_split_kernel<3>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
     } else {
         hipLaunchKernelGGL((policy_forward_kernel<4, false>), dim3((unsigned)blocks), dim3(256), policy_lds_bytes(4), static_cast<hipStream_t>(stream), a);
     }

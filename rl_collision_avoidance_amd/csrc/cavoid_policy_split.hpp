@@ -1,17 +1,16 @@
 // cavoid_policy_split.hpp -- the actors' NetworkVP_rnn inference (predict_p_and_v + select_action, see cavoid_policy.hpp for
-// the graph and its citations) on the bf16 matrix pipe WITHOUT giving up float32 accuracy: error-free splitting.
+// the graph and its citations) on the bf16 matrix pipe with float32 inputs, outputs and accumulation: operand splitting.
 //
 //   Every float32 operand is written as a sum of bf16 pieces (8 significant bits each):
 //       weight  w = w1 + w2 + w3   (24 bits: exact)            -- split once, at cavoid_policy_load time
 //       activation a = a1 + a2     (16 bits + rounding: |a - a1 - a2| <= 2^-17 |a|)  -- split in each layer's epilogue
-//   and a product is the sum of the five partial products that matter, accumulated in float32 by the MFMA:
-//       w*a ~= w1*a1 + w1*a2 + w2*a1 + w2*a2 + w3*a1            (dropped: w3*a2 ~ 2^-25)
-//   v_mfma_f32_16x16x32_bf16 runs at 16x the rate of v_mfma_f32_16x16x4_f32 per unit of K, so five of them cost 5/16
-//   of the float32 instruction's time: 3.2x less matrix time.  The result differs from a float32 GEMM by the activation
-//   rounding (relative 4e-6 per element before the sqrt(K) averaging).  Measured against the network in float64
-//   (tests/test_gpu_policy.py::test_both_inference_kernels_against_a_float64_yardstick): |dp| <= 1.3e-6, where the
-//   float32 PyTorch graph loses 1e-7 -- an order above float32 rounding, an order inside the 2e-5 / 2e-4 bar the
-//   float32 kernel is held to.  CAVOID_POLICY_F32=1 keeps inference on the float32-MFMA kernel.
+//   and a product is the sum of its P largest partial products, accumulated in float32 by the MFMA:
+//       w*a ~= w1*a1 + w1*a2 + w2*a1 [+ w3*a1 [+ w2*a2]]         P = 3 (default) [4 [5]]; w3*a2 ~ 2^-26 is never formed
+//   v_mfma_f32_16x16x32_bf16 runs at 16x the rate of v_mfma_f32_16x16x4_f32 per unit of K, so P of them cost P/16 of the
+//   float32 instruction's time.  The result differs from a float32 GEMM by the activation rounding (relative 2^-17 per
+//   product, every P) plus the dropped products; the table below (kSpDefaultProducts) has the measured errors against the network
+//   in float64 -- 3.4e-6 on p / 2.5e-5 on v at worst with P = 3, inside the 2e-5 / 2e-4 bar the float32 kernel is held to by
+//   a factor 6 / 8.  CAVOID_POLICY_F32=1 keeps inference on the float32-MFMA kernel.
 //
 // Layout.  One workgroup = 64 rows x 4 wavefronts; the GEMMs are computed TRANSPOSED, D[m][n] = sum_k W[k][m] * act[n][k]:
 //   * MFMA operand A = weights (lane: output column m = l%16 of a 16-column tile, k = 8*(l/16) .. +7), operand B =
@@ -38,6 +37,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// How many of the partial products w_i * a_j are formed (largest first) is a template parameter P of the kernels.  With
+// |w2| <= 2^-9 |w|, |w3| <= 2^-17 |w|, |a2| <= 2^-9 |a| and the activation split's own rounding |a - a1 - a2| <= 2^-17 |a| (which
+// every variant carries), per product:
+//   P = 5: w1a1 + w1a2 + w2a1 + w2a2 + w3a1   dropped: w3a2 (2^-26)                                      error ~2^-17
+//   P = 4: w1a1 + w1a2 + w2a1 + w3a1          dropped: + w2a2 (2^-18)                                    ~1.5 x 2^-17
+//   P = 3: w1a1 + w1a2 + w2a1                 dropped: + w3a1 (2^-17); the third weight plane is never read   ~2.5 x 2^-17
+// Measured against the network in float64 (tools/split_products_ab.py; 3 seeds x 32 768 rows; M = 3 / M = 9 / inputs x 4):
+//   P = 5: |dp| 3.6e-7 / 3.6e-7 / 2.1e-6, |dv| 3.3e-6 / 2.6e-6 / 1.3e-5;  76.7 us per 32 768 rows
+//   P = 4: |dp| 4.6e-7 / 5.1e-7 / 2.8e-6, |dv| 4.1e-6 / 3.8e-6 / 1.7e-5;  70.2 us
+//   P = 3: |dp| 6.2e-7 / 6.8e-7 / 3.4e-6, |dv| 4.9e-6 / 4.3e-6 / 2.5e-5;  58.8 us      (float32 PyTorch graph: ~1e-7 / ~1e-6)
+// i.e. the two smallest products buy less than a factor 2 of an error that the 16-bit activation pieces set anyway, for a third
+// more matrix time: P = 3 is the default (still 6x inside the 2e-5 bar on p, 8x inside 2e-4 on v, with saturating inputs);
+// CAVOID_POLICY_PRODUCTS=5 (or 4) selects the others at cavoid_policy_create time.
+constexpr int kSpDefaultProducts = 3;
 constexpr int kSpStrideB = 528;                 // bytes per LDS row of one plane (264 bf16)
 constexpr int kSpPlaneB = 64 * kSpStrideB;      // 33 792 B
 constexpr int kSpSlotCol = 64;                  // first input-slot column
@@ -129,9 +142,10 @@ __device__ __forceinline__ void split_load_w1(uint4 (&w)[4], const uint4 *layer,
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) w[mt] = p[mt * 64];
 }
+template <int P>
 __device__ __forceinline__ void split_load_w(SplitW &f, const uint4 *layer, int wave, int lane, int c) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) split_load_w1(f.w[pl], layer, pl, wave, lane, c);
+    for (int pl = 0; pl < (P >= 4 ? 3 : 2); ++pl) split_load_w1(f.w[pl], layer, pl, wave, lane, c);
 }
 
 // activation fragments (ONE plane) of the k-range starting at LDS column `col` (32 wide); `slot`: the input chunk --
@@ -162,6 +176,7 @@ __device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4
 // cycles, L2) resp. >= 16 MFMAs (256 cycles, LDS) to land:
 //     w1*a_lo   w1*a_hi   [w1 <- next]   w2*a_lo   [a_lo <- next]   w2*a_hi   [w2 <- next]   w3*a_hi   [w3, a_hi <- next]
 // 144 live registers (64 accumulators, 48 weight, 32 activation) instead of 240 for a double-buffered pipeline.
+template <int P>
 __device__ __forceinline__ void split_gemm(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4]) {
     uint4 a_hi[4], a_lo[4];
@@ -176,15 +191,19 @@ __device__ __forceinline__ void split_gemm(const unsigned char *planes, const ui
         split_mfma_term(w.w[0], a_hi, acc);
         __builtin_amdgcn_sched_barrier(0);
         split_load_w1(w.w[0], layer, 0, wave, lane, n);
-        split_mfma_term(w.w[1], a_lo, acc);
-        __builtin_amdgcn_sched_barrier(0);
+        if (P >= 5) {
+            split_mfma_term(w.w[1], a_lo, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
         split_mfma_term(w.w[1], a_hi, acc);
         __builtin_amdgcn_sched_barrier(0);
         split_load_w1(w.w[1], layer, 1, wave, lane, n);
-        split_mfma_term(w.w[2], a_hi, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        split_load_w1(w.w[2], layer, 2, wave, lane, n);
+        if (P >= 4) {
+            split_mfma_term(w.w[2], a_hi, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_w1(w.w[2], layer, 2, wave, lane, n);
+        }
         split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -267,7 +286,7 @@ __device__ __forceinline__ int split_select_action(const float (&pj)[4], int g, 
 //   emit(trow, g, pj, logit) is called by every lane of the heads' layout: tile row trow = 16 wave + lane%16, columns 4g..4g+3 --
 //                  pj = softmax probabilities incl. MIN_POLICY, logit[r] = raw head output (column A = the value).
 // planes / len_f / wave_max: the workgroup's LDS (policy_split_lds_bytes()).  Contains workgroup barriers: every thread calls it.
-template <class Load, class Emit>
+template <int P, class Load, class Emit>
 __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned char *planes, float *len_f, int *wave_max, int rows_here,
                                                   int tid, Load load, Emit emit) {
     const PolicyArgs &p = sa.p;
@@ -275,7 +294,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     const int M = p.max_other, A = p.num_actions;
     const uint4 *w_lstm = sa.sfrags + kSpOffLstm;
     SplitW f0;
-    split_load_w(f0, w_lstm, wave, lane, 2);               // first LSTM step: h == 0, only the input chunk contributes
+    split_load_w<P>(f0, w_lstm, wave, lane, 2);               // first LSTM step: h == 0, only the input chunk contributes
 
     // ---- input tile: gather + normalise + split into the slot columns ---------------------------------------------
     {
@@ -334,9 +353,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         f32x4 acc[4][4];
         split_init_acc(p.bias + kBiasLstm, wave, lane, acc);
         if (t == 1) POLICY_STAMP(8);
-        split_gemm(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc);
+        split_gemm<P>(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc);
         if (t == 1) POLICY_STAMP(9);
-        split_load_w(f0, w_lstm, wave, lane, 0);           // the next step's first weight fragments
+        split_load_w<P>(f0, w_lstm, wave, lane, 0);           // the next step's first weight fragments
         __syncthreads();                                   // every wavefront has read h
         if (t == 1) POLICY_STAMP(10);
 #pragma unroll
@@ -362,10 +381,10 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     // ---- layer1 on [h | host] -------------------------------------------------------------------------------------
     {
         f32x4 acc[4][4];
-        split_load_w(f0, sa.sfrags + kSpOffL1, wave, lane, 0);
+        split_load_w<P>(f0, sa.sfrags + kSpOffL1, wave, lane, 0);
         split_init_acc(p.bias + kBiasL1, wave, lane, acc);
-        split_gemm(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc);
-        split_load_w(f0, sa.sfrags + kSpOffL2, wave, lane, 0);
+        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc);
+        split_load_w<P>(f0, sa.sfrags + kSpOffL2, wave, lane, 0);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -375,8 +394,8 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     {
         f32x4 acc[4][4];
         split_init_acc(p.bias + kBiasL2, wave, lane, acc);
-        split_gemm(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
-        split_load_w(f0, sa.sfrags + kSpOffFc1, wave, lane, 0);
+        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
+        split_load_w<P>(f0, sa.sfrags + kSpOffFc1, wave, lane, 0);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -386,7 +405,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     {
         f32x4 acc[4][4];
         split_init_acc(p.bias + kBiasFc1, wave, lane, acc);
-        split_gemm(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
+        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
 #pragma unroll
         for (int c = 0; c < kSpChWide / 2; ++c)
 #pragma unroll
@@ -409,8 +428,8 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
 #pragma unroll
         for (int c = 0; c < kSpChWide; ++c) {
             const uint4 a1 = *reinterpret_cast<const uint4 *>(arow + c * 64), a2 = *reinterpret_cast<const uint4 *>(arow + kSpPlaneB + c * 64);
-            acc[4] = mfma_bf16(hw[c][2], a1, acc[4]);
-            acc[3] = mfma_bf16(hw[c][1], a2, acc[3]);
+            if (P >= 4) acc[4] = mfma_bf16(hw[c][2], a1, acc[4]);
+            if (P >= 5) acc[3] = mfma_bf16(hw[c][1], a2, acc[3]);
             acc[2] = mfma_bf16(hw[c][1], a1, acc[2]);
             acc[1] = mfma_bf16(hw[c][0], a2, acc[1]);
             acc[0] = mfma_bf16(hw[c][0], a1, acc[0]);
@@ -436,7 +455,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     POLICY_STAMP(4);
 }
 
-#ifdef CAVOID_POLICY_KERNELS
+template <int P>
 __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const SplitArgs sa) {
     const PolicyArgs &p = sa.p;
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // plane 1 (hi), plane 2 (lo)
@@ -490,13 +509,11 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
             if (row < p.rows && g == 0) p.actions_out[row] = action;
         }
     };
-    policy_split_tile(sa, planes, len_f, wave_max, rows_here, tid, load, emit);
+    policy_split_tile<P>(sa, planes, len_f, wave_max, rows_here, tid, load, emit);
 #ifdef CAVOID_TRACE
     if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
 #endif
     if (p.actions_out) policy_finish(p, step, tid);
 }
-
-#endif
 
 }  // namespace cavoid

@@ -355,13 +355,23 @@ __global__ void __launch_bounds__(256) rollout_compact_kernel(const RolloutCfg c
     if (take) lane_of_rank[wave][rank] = lane;
     __builtin_amdgcn_wave_barrier();                       // wave-private table: LDS operations of a wavefront are in order
     const int64_t wave_row0 = row - lane;                  // ring row of this wavefront's lane 0
-    const float inv_d = 1.0f / (float)D;
-    for (int e = lane; e < fit * D; e += 64) {
-        int r = (int)((float)e * inv_d);
-        r -= (r * D > e) ? 1 : 0;
-        r += ((r + 1) * D <= e) ? 1 : 0;
-        const int k = e - r * D;
-        a.out_x[(int64_t)base * D + e] = a.x[(wave_row0 + lane_of_rank[wave][r]) * D + k];
+    const uint32_t inv_d = (uint32_t)((1ull << 32) / (uint32_t)D) + 1u;      // e / D by multiply-shift (e < 2^16)
+    const float *__restrict__ src = a.x + wave_row0 * D;
+    float *__restrict__ dstx = a.out_x + (int64_t)base * D;
+    const int total = fit * D;
+    for (int e0 = lane; e0 < total; e0 += 64 * 8) {        // 8 loads in flight per lane, then 8 stores (one load -> store round
+        float v[8];                                        // trip at a time made this launch 63 us for 8 x 32 768 slots)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 64 * u;
+            const int r = (int)(((uint64_t)(uint32_t)e * inv_d) >> 32), k = e - r * D;
+            v[u] = e < total ? src[lane_of_rank[wave][r] * D + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 64 * u;
+            if (e < total) dstx[e] = v[u];
+        }
     }
     if (!take || rank >= fit) return;
     const int64_t dst = (int64_t)base + rank;

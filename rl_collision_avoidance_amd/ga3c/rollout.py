@@ -57,6 +57,7 @@ class BatchedRollout(object):
         self.time_max = int(time_max if time_max is not None else getattr(cfg, "TIME_MAX", int(4 / cfg.DT)))
         self.discount = float(getattr(cfg, "DISCOUNT", discount))
         self.greedy = greedy                     # PLAY_MODE / EVALUATE_MODE: argmax instead of sampling (:98-103)
+        self._reflush = bool(reflush_done)
         # fused policy only: no forward pass for absent agents and for agents that have finished and wait for their world to
         # end (the env ignores their action, nothing of theirs is recorded; ~30 % of the rows in the TrainPhase1 workload).
         # Never in the faithful re-flush mode, whose quirk rows carry V(s) of exactly those agents.  Default: only when the
@@ -321,6 +322,42 @@ class BatchedRollout(object):
             self.dup_count.zero_()
         cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts)
         batch = TrainingBatch(cat(xs), cat(rs), cat(as_), cat(srcs) if provenance else None, self.env.num_actions, dropped + 0)
+        self.frames += len(batch)
+        return batch
+
+    # -- the same hand-over, split in two so that the host never waits for the launch it has just enqueued --------------------
+    def drain_begin(self, provenance: bool = False) -> dict:
+        """First half of ``drain()``: enqueue the compaction of the final blocks and an asynchronous read-back of the row
+        count; returns a handle for ``drain_end``.  Between the two calls the caller enqueues the NEXT replay, so the GPU goes
+        from one launch to the next while the host collects the previous batch (cleaned mode only: the re-flush quirk's append
+        buffer is read synchronously by ``drain()``)."""
+        if self._reflush:
+            raise RuntimeError("drain_begin / drain_end serve reflush_done=False; use drain()")
+        lo, hi = self.pending_final_steps()
+        if hi - lo > 65535:
+            raise RuntimeError("too many undrained steps for one compaction launch: call drain()")
+        S, D, dev = self.slots, self.env.obs_width - 1, self.env.device
+        cap = max(hi - lo, 0) * S
+        h = {"x": torch.empty((cap, D), dtype=torch.float32, device=dev), "r": torch.empty((cap,), dtype=torch.float32, device=dev),
+             "a": torch.empty((cap,), dtype=torch.int32, device=dev),
+             "src": torch.empty((cap, 4), dtype=torch.int32, device=dev) if provenance else None,
+             "counts": torch.zeros((2,), dtype=torch.int32, device=dev), "host": torch.zeros((2,), dtype=torch.int32).pin_memory(),
+             "event": torch.cuda.Event()}
+        p = BatchedCollisionAvoidanceEnv._ptr
+        if hi > lo:
+            _lib.check(self._lib.cavoid_rollout_compact(self._h, lo, hi, 0, p(self.x), p(self.ret), p(self.act_ring), p(self.emit_t),
+                                                        p(h["x"]), p(h["r"]), p(h["a"]), p(h["src"]) if provenance else None, p(h["counts"]), cap,
+                                                        self.env._stream()), "cavoid_rollout_compact")
+        h["host"].copy_(h["counts"], non_blocking=True)
+        h["event"].record(torch.cuda.current_stream(dev))
+        self.drained_until = max(hi, lo)
+        return h
+
+    def drain_end(self, h: dict) -> TrainingBatch:
+        h["event"].synchronize()                              # (waits for THIS hand-over's count only, not for what was enqueued since)
+        n = int(h["host"][0])                                 # (cleaned mode: no append buffer, nothing can be dropped)
+        batch = TrainingBatch(h["x"][:n], h["r"][:n], h["a"][:n], h["src"][:n] if h["src"] is not None else None,
+                              self.env.num_actions, 0)
         self.frames += len(batch)
         return batch
 

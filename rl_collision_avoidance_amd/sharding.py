@@ -175,9 +175,9 @@ class ShardedEnv(object):
     # -- the native path: packed records straight from the kernel, ncclAllGather behind the C ABI, overlapped ---------
     def _native_setup(self, steps: int = 1, root: int = -1):
         """Buffers of the native hand-over: per slot a send buffer of `steps` packed records of this shard and, on the
-        receiving ranks, a recv buffer [steps, total_worlds, N, width+2].  Equal shards of one step go through ONE
-        ncclAllGather; ragged shards, several steps per launch (the per-rank blocks are then not contiguous in world order) or a
-        single receiving rank (`root`) go through the point-to-point gather (`cavoid_gatherv_begin`)."""
+        receiving ranks, a recv buffer of rank-major blocks [rank][steps, count_r, N, width+2].  Equal shards to every rank go
+        through ONE ncclAllGather; ragged shards or a single receiving rank (`root`) through the point-to-point gather
+        (`cavoid_gatherv_begin`)."""
         from .batched_env import StepSlots
         e = self.env
         self._native = NativeGather(e.device, self.group)
@@ -210,7 +210,7 @@ class ShardedEnv(object):
             self.env.step_autoreset_packed(actions, sl.packed[0])
         else:
             self.env.step_autoreset_packed(actions, sl)
-        if self._even and steps == 1 and root < 0:
+        if self._even and root < 0:                 # equal shards to every rank: ONE ncclAllGather (rank-major blocks of K steps)
             self._native.begin(slot, sl.packed, self._recv[slot])
         else:
             self._native.begin_v(slot, sl.packed, self._recv[slot], self._floats, root)

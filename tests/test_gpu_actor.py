@@ -137,3 +137,32 @@ def test_fused_actor_refuses_what_it_does_not_carry():
                                      p(env.rewards), p(env.done), p(env.game_over), p(roll._act_out), p(roll._val_out), 2, 0, None)
     assert rc == -1
     roll.close(); env.close()
+
+
+def test_pipelined_hand_over_equals_drain():
+    """`drain_begin` / `drain_end` (the count of hand-over k is read while launch k+1 runs) deliver the rows `drain()` delivers."""
+    W, N, seed = 512, 4, 9
+    env_a, _, _, a = _make(W, N, seed, False)
+    env_b, _, _, b = _make(W, N, seed, False)
+    rows_a, rows_b, pending = [], [], None
+    for _ in range(12):
+        a.run_fused(8)
+        rows_a.append(a.drain(provenance=True))
+        b.run_fused(8)
+        h = b.drain_begin(provenance=True)
+        if pending is not None:
+            rows_b.append(b.drain_end(pending))
+        pending = h
+    rows_b.append(b.drain_end(pending))
+    assert a.frames == b.frames > 0
+    for name in ("x", "r", "a_index", "src"):
+        xa = torch.cat([getattr(r, name) for r in rows_a]).cpu().numpy()
+        xb = torch.cat([getattr(r, name) for r in rows_b]).cpu().numpy()
+        sa = torch.cat([r.src for r in rows_a]).cpu().numpy()
+        sb = torch.cat([r.src for r in rows_b]).cpu().numpy()
+        assert np.array_equal(xa[np.lexsort(sa.T[::-1])], xb[np.lexsort(sb.T[::-1])]), name
+    with pytest.raises(RuntimeError):
+        _make(64, 4, 1, True)[3].drain_begin()
+    for r in (a, b):
+        r.close()
+    env_a.close(); env_b.close()
