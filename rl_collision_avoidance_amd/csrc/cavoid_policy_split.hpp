@@ -176,9 +176,69 @@ __device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4
 // cycles, L2) resp. >= 16 MFMAs (256 cycles, LDS) to land:
 //     w1*a_lo   w1*a_hi   [w1 <- next]   w2*a_lo   [a_lo <- next]   w2*a_hi   [w2 <- next]   w3*a_hi   [w3, a_hi <- next]
 // 144 live registers (64 accumulators, 48 weight, 32 activation) instead of 240 for a double-buffered pipeline.
+//
+// P = 3 reads only two weight planes, so the third register group double-buffers plane 1 (the plane both of whose products come
+// first): chunk c+1's w1 is requested at the START of chunk c into the idle buffer (48 MFMAs = 768 cycles to land instead of 16),
+// w2 is re-loaded right after its one product (32 MFMAs), and the LAST chunk requests the first chunk of the layer that follows
+// (`next_layer`, chunk `next_c`) into w.w[0] / w.w[1], which is where every call expects its first chunk.
+__device__ __forceinline__ void split_gemm3(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
+                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c) {
+    uint4 a_hi[4], a_lo[4];
+    auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
+    split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
+    split_load_a(a_hi, planes, 0, lane, col_of(c0), c0 == slot_chunk);
+    int c = c0;
+#pragma unroll 1
+    for (;;) {
+        {                                                  // chunk c with w1 in w.w[0]; w.w[2] is idle
+            const bool last = c + 1 >= c1;
+            const int n = last ? c : c + 1;
+            const uint4 *wl = last ? next_layer : layer;
+            const int wc = last ? next_c : n;
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) split_load_w1(w.w[2], layer, 0, wave, lane, n);
+            split_mfma_term(w.w[0], a_lo, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
+            split_mfma_term(w.w[1], a_hi, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_w1(w.w[1], wl, 1, wave, lane, wc);
+            split_mfma_term(w.w[0], a_hi, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
+            if (last) { split_load_w1(w.w[0], next_layer, 0, wave, lane, next_c); break; }
+        }
+        ++c;
+        {                                                  // chunk c with w1 in w.w[2]; w.w[0] is idle
+            const bool last = c + 1 >= c1;
+            const int n = last ? c : c + 1;
+            const uint4 *wl = last ? next_layer : layer;
+            const int wc = last ? next_c : n;
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_w1(w.w[0], wl, 0, wave, lane, wc);
+            split_mfma_term(w.w[2], a_lo, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
+            split_mfma_term(w.w[1], a_hi, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_w1(w.w[1], wl, 1, wave, lane, wc);
+            split_mfma_term(w.w[2], a_hi, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
+            if (last) break;
+        }
+        ++c;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int P>
 __device__ __forceinline__ void split_gemm(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
-                                           int wave, int lane, SplitW &w, f32x4 (&acc)[4][4]) {
+                                           int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c) {
+    if constexpr (P == 3) {
+        split_gemm3(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c);
+        return;
+    }
     uint4 a_hi[4], a_lo[4];
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
     split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
@@ -207,6 +267,7 @@ __device__ __forceinline__ void split_gemm(const unsigned char *planes, const ui
         split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
     }
     __builtin_amdgcn_sched_barrier(0);
+    split_load_w<P>(w, next_layer, wave, lane, next_c);    // the first weight fragments of the layer that follows
 }
 
 // acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
@@ -315,16 +376,21 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         for (int it = tid; it < items; it += 256) {
             const int r = it & 63, s = it >> 6;
             const int n_in = s == 0 ? kPolHost : kPolOther, sc0 = s == 0 ? 1 : 1 + kPolHost + kPolOther * (s - 1);
-            float v[8];
+            // all eight loads (and the sixteen of avg / std) are issued before the first use: unused elements re-read element 0
+            // of the slot and rows past the end re-read row 0 -- valid addresses, selected away below -- so nothing is conditional
+            const bool row_ok = r < rows_here;
+            const int rr = row_ok ? r : 0;
+            float v[8], av[8], sd[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = 0.0f;
-                if (e < n_in && r < rows_here) {
-                    x = load(r, sc0 + e);
-                    if (p.avg) x = (x - p.avg[sc0 + e]) / p.std[sc0 + e];
-                }
-                v[e] = x;
+            for (int e = 0; e < 8; ++e) v[e] = load(rr, e < n_in ? sc0 + e : sc0);
+            if (p.avg) {                                   // uniform
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { av[e] = p.avg[e < n_in ? sc0 + e : sc0]; sd[e] = p.std[e < n_in ? sc0 + e : sc0]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] - av[e]) / sd[e];
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (row_ok && e < n_in) ? v[e] : 0.0f;
             uint32_t hi[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
@@ -353,9 +419,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         f32x4 acc[4][4];
         split_init_acc(p.bias + kBiasLstm, wave, lane, acc);
         if (t == 1) POLICY_STAMP(8);
-        split_gemm<P>(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc);
+        split_gemm<P>(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
+                      t + 1 < steps ? w_lstm : sa.sfrags + kSpOffL1, 0);    // (requests the next step's / layer1's first fragments)
         if (t == 1) POLICY_STAMP(9);
-        split_load_w<P>(f0, w_lstm, wave, lane, 0);           // the next step's first weight fragments
         __syncthreads();                                   // every wavefront has read h
         if (t == 1) POLICY_STAMP(10);
 #pragma unroll
@@ -381,10 +447,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     // ---- layer1 on [h | host] -------------------------------------------------------------------------------------
     {
         f32x4 acc[4][4];
-        split_load_w<P>(f0, sa.sfrags + kSpOffL1, wave, lane, 0);
+        if (steps == 0) split_load_w<P>(f0, sa.sfrags + kSpOffL1, wave, lane, 0);    // (else the last LSTM step asked for them)
         split_init_acc(p.bias + kBiasL1, wave, lane, acc);
-        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc);
-        split_load_w<P>(f0, sa.sfrags + kSpOffL2, wave, lane, 0);
+        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, sa.sfrags + kSpOffL2, 0);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -394,8 +459,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     {
         f32x4 acc[4][4];
         split_init_acc(p.bias + kBiasL2, wave, lane, acc);
-        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
-        split_load_w<P>(f0, sa.sfrags + kSpOffFc1, wave, lane, 0);
+        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, 0);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -405,7 +469,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     {
         f32x4 acc[4][4];
         split_init_acc(p.bias + kBiasFc1, wave, lane, acc);
-        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc);
+        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, kSpChWide - 1);
 #pragma unroll
         for (int c = 0; c < kSpChWide / 2; ++c)
 #pragma unroll
@@ -481,9 +545,7 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
         g_pol_trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #endif
-    if (listed) {
-        if (tid < 64) tile_row[tid] = tid < rows_here ? p.row_index[row0 + tid] : 0;
-    }
+    if (tid < 64) tile_row[tid] = listed ? (tid < rows_here ? p.row_index[row0 + tid] : 0) : tid;   // row of `src` behind each tile row
     if (tid == 0) {                                        // arrival parity on the CU -> static priority (see cavoid_policy.hpp)
         const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         const uint32_t key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
@@ -492,7 +554,7 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
     __syncthreads();
     if (ticket & 1) __builtin_amdgcn_s_setprio(1);
     const float *src = listed ? p.x : p.x + row0 * p.stride;
-    auto load = [&](int r, int k) -> float { return src[(int64_t)(listed ? tile_row[r] : r) * p.stride + k]; };
+    auto load = [&](int r, int k) -> float { return src[(int64_t)tile_row[r] * p.stride + k]; };
     auto emit = [&](int trow, int g, const float (&pj)[4], const f32x4 &logit) {
         const bool in_tile = trow < rows_here;
         const int64_t row = listed ? (in_tile ? (int64_t)tile_row[trow] : p.rows) : row0 + trow;

@@ -329,43 +329,62 @@ struct CompactArgs {
     int64_t capacity;
 };
 
-// One lane per (step block, slot); a wavefront appends its emitted rows with one atomic (ballot + prefix count) and
-// then copies them together: the destination is one contiguous run of rows, the sources are (mostly adjacent) rows of
-// the wavefront's 64 slots, so both sides of the copy are coalesced.  Row order inside the batch is unspecified (the
-// A3C loss is a sum over rows).
+// A wavefront takes kCompactSpan groups of 64 consecutive slots of one step block (one lane per slot and group); the workgroup
+// appends its emitted rows with ONE atomic (ballots, per-wavefront counts through LDS) -- one returning atomic per wavefront on
+// the single counter cost 8192 of them per 16-step hand-over at 4 x 8192, ~90 per microsecond: 110 us for a 109 MB copy -- and
+// each wavefront then copies its rows together: the destination is one contiguous run of rows, the sources are (mostly adjacent)
+// rows of the wavefront's slots, so both sides of the copy are coalesced.  Row order inside the batch is unspecified (the A3C
+// loss is a sum over rows).
+constexpr int kCompactSpan = 4;
 __global__ void __launch_bounds__(256) rollout_compact_kernel(const RolloutCfg c, const CompactArgs a) {
-    __shared__ int lane_of_rank[4][64];
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int step = a.step_lo + (int)blockIdx.y;
+    __shared__ int slot_of_rank[4][64 * kCompactSpan];
+    __shared__ int wave_count[4];
+    __shared__ int block_base;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, D = c.obs_width - 1;
+    const int step = a.step_lo + (int)blockIdx.y;
+    const int64_t span0 = ((int64_t)blockIdx.x * 4 + wave) * (64 * kCompactSpan);     // first slot of this wavefront's span
     const int64_t block_row0 = (int64_t)(step % c.ring_len) * c.num_slots;
-    const int64_t row = block_row0 + slot;
-    int32_t emitted = -1;
-    if (slot < c.num_slots) emitted = a.emit_t[row];
-    const bool take = emitted >= 0;
-    const unsigned long long mask = __ballot(take);
-    if (mask == 0ull) return;
-    const int count = __popcll(mask), rank = __popcll(mask & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(a.out_count, count);
-    base = __shfl(base, leader, 64);
-    int fit = (int64_t)base + count <= a.capacity ? count : (int)(a.capacity > base ? a.capacity - base : 0);
-    if (lane == leader && fit < count) atomicAdd(a.out_count + 1, count - fit);
-    if (take) lane_of_rank[wave][rank] = lane;
+    int32_t emitted[kCompactSpan];
+    int rank[kCompactSpan];
+    int count = 0;
+#pragma unroll
+    for (int g = 0; g < kCompactSpan; ++g) {
+        const int64_t slot = span0 + 64 * g + lane;
+        emitted[g] = slot < c.num_slots ? a.emit_t[block_row0 + slot] : -1;
+    }
+#pragma unroll
+    for (int g = 0; g < kCompactSpan; ++g) {
+        const unsigned long long mask = __ballot(emitted[g] >= 0);
+        rank[g] = count + __popcll(mask & ((1ull << lane) - 1ull));
+        count += __popcll(mask);
+    }
+    if (lane == 0) wave_count[wave] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        block_base = total ? atomicAdd(a.out_count, total) : 0;
+    }
+    __syncthreads();
+    if (count == 0) return;                                // (wave-uniform)
+    int64_t base = block_base;
+    for (int w = 0; w < wave; ++w) base += wave_count[w];
+    const int fit = base + count <= a.capacity ? count : (int)(a.capacity > base ? a.capacity - base : 0);
+    if (lane == 0 && fit < count) atomicAdd(a.out_count + 1, count - fit);
+#pragma unroll
+    for (int g = 0; g < kCompactSpan; ++g)
+        if (emitted[g] >= 0) slot_of_rank[wave][rank[g]] = 64 * g + lane;
     __builtin_amdgcn_wave_barrier();                       // wave-private table: LDS operations of a wavefront are in order
-    const int64_t wave_row0 = row - lane;                  // ring row of this wavefront's lane 0
     const uint32_t inv_d = (uint32_t)((1ull << 32) / (uint32_t)D) + 1u;      // e / D by multiply-shift (e < 2^16)
-    const float *__restrict__ src = a.x + wave_row0 * D;
-    float *__restrict__ dstx = a.out_x + (int64_t)base * D;
+    const float *__restrict__ src = a.x + (block_row0 + span0) * D;
+    float *__restrict__ dstx = a.out_x + base * D;
     const int total = fit * D;
-    for (int e0 = lane; e0 < total; e0 += 64 * 8) {        // 8 loads in flight per lane, then 8 stores (one load -> store round
-        float v[8];                                        // trip at a time made this launch 63 us for 8 x 32 768 slots)
+    for (int e0 = lane; e0 < total; e0 += 64 * 8) {        // 8 loads in flight per lane, then 8 stores
+        float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + 64 * u;
             const int r = (int)(((uint64_t)(uint32_t)e * inv_d) >> 32), k = e - r * D;
-            v[u] = e < total ? src[lane_of_rank[wave][r] * D + k] : 0.f;
+            v[u] = e < total ? src[slot_of_rank[wave][r] * D + k] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -373,17 +392,20 @@ __global__ void __launch_bounds__(256) rollout_compact_kernel(const RolloutCfg c
             if (e < total) dstx[e] = v[u];
         }
     }
-    if (!take || rank >= fit) return;
-    const int64_t dst = (int64_t)base + rank;
-    a.out_r[dst] = a.ret[row];
-    a.out_a[dst] = (int32_t)a.act[row];
-    if (a.out_src) {
-        a.out_src[4 * dst + 0] = (int32_t)(slot / c.max_agents);
-        a.out_src[4 * dst + 1] = (int32_t)(slot % c.max_agents);
-        a.out_src[4 * dst + 2] = step;
-        a.out_src[4 * dst + 3] = emitted;
+#pragma unroll
+    for (int g = 0; g < kCompactSpan; ++g) {
+        if (emitted[g] < 0 || rank[g] >= fit) continue;
+        const int64_t slot = span0 + 64 * g + lane, row = block_row0 + slot, dst = base + rank[g];
+        a.out_r[dst] = a.ret[row];
+        a.out_a[dst] = (int32_t)a.act[row];
+        if (a.out_src) {
+            a.out_src[4 * dst + 0] = (int32_t)(slot / c.max_agents);
+            a.out_src[4 * dst + 1] = (int32_t)(slot % c.max_agents);
+            a.out_src[4 * dst + 2] = step;
+            a.out_src[4 * dst + 3] = emitted[g];
+        }
+        if (a.mark_taken) a.emit_t[row] = -2;
     }
-    if (a.mark_taken) a.emit_t[row] = -2;
 }
 
 #endif

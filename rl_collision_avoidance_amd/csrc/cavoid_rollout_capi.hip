@@ -92,7 +92,9 @@ extern "C" int cavoid_rollout_compact(cavoid_rollout *r, int32_t step_lo, int32_
     CompactArgs a{};
     a.step_lo = step_lo; a.step_hi = step_hi; a.mark_taken = mark_taken ? 1 : 0; a.x = x; a.ret = ret; a.act = act; a.emit_t = emit_t;
     a.out_x = out_x; a.out_r = out_r; a.out_a = out_a; a.out_src = out_src; a.out_count = out_count; a.capacity = capacity;
-    const dim3 grid((unsigned)((r->c.num_slots + 255) / 256), (unsigned)(step_hi - step_lo));
+    if ((int64_t)(r->c.obs_width - 1) * 64 * kCompactSpan > 65535) return CAVOID_EUNSUPPORTED;   // (the copy loop's e / D trick)
+    const int per_block = 256 * kCompactSpan;
+    const dim3 grid((unsigned)((r->c.num_slots + per_block - 1) / per_block), (unsigned)(step_hi - step_lo));
     hipLaunchKernelGGL(rollout_compact_kernel, grid, dim3(256), 0, s, r->c, a);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
