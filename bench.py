@@ -532,15 +532,22 @@ def main() -> None:
             def run_steps_gather(k):
                 for _ in range(-(-k // spl)):
                     if native:
-                        sh.gathered(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))
+                        sh.gathered_blocks(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))   # (waits for it; rank-major views, no copy)
                     else:
                         from rl_collision_avoidance_amd.sharding import gather_step_outputs
                         env.step_autoreset_packed(acts_l, gslots)
                         gather_step_outputs(gslots.packed.transpose(0, 1).contiguous(), world_size * W)
             run_steps_gather(args.warmup)
             sync_all()
+            failed = None
         except Exception as exc:      # noqa: BLE001 -- a broken exchange must not cost the shard-only number: say so and time that
-            extra["configs2_gather"] = {"error": repr(exc), "note": "the gather failed before the timed region: value is the SHARD-ONLY rate"}
+            failed = repr(exc)
+        # every rank takes the same branch: one rank's failure sends all of them to the shard-only measurement
+        flag = torch.tensor([0 if failed is None else 1], dtype=torch.int32, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            extra["configs2_gather"] = {"error": failed or "another rank failed",
+                                        "note": "the gather failed before the timed region: value is the SHARD-ONLY rate"}
             gather_in_metric = False
             if sh is not None:
                 try:

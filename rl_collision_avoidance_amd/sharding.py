@@ -216,21 +216,30 @@ class ShardedEnv(object):
             self._native.begin_v(slot, sl.packed, self._recv[slot], self._floats, root)
         return slot
 
-    def gathered(self, slot: int) -> Optional[torch.Tensor]:
-        """[total_worlds, N, width+2] (one step per launch) or [K, total_worlds, N, width+2]; None on a rank that does not
-        receive.  Valid until the slot's next use."""
+    def gathered_blocks(self, slot: int) -> Optional[list]:
+        """The gather as it arrives: one view [K, worlds of rank r, N, width+2] per rank, in rank order (no copy); None on a rank
+        that does not receive.  Valid until the slot's next use."""
         self._native.wait(slot)
         recv = self._recv[slot]
         if recv is None:
             return None
         e, K = self.env, self._steps
-        if K == 1:
-            return recv.view(self.total_worlds, e.max_agents, e.packed_width)
-        # rank-major blocks -> [K, total_worlds, ...] (a view when there is one rank, else one gather-side copy per rank block)
         blocks, off = [], 0
         for c, f in zip(self._counts, self._floats):
             blocks.append(recv[off:off + f].view(K, c, e.max_agents, e.packed_width))
             off += f
+        return blocks
+
+    def gathered(self, slot: int) -> Optional[torch.Tensor]:
+        """[total_worlds, N, width+2] (one step per launch) or [K, total_worlds, N, width+2]; None on a rank that does not
+        receive.  Valid until the slot's next use."""
+        blocks = self.gathered_blocks(slot)
+        if blocks is None:
+            return None
+        e, K = self.env, self._steps
+        if K == 1:
+            return self._recv[slot].view(self.total_worlds, e.max_agents, e.packed_width)
+        # rank-major blocks -> [K, total_worlds, ...] (a view when there is one rank, else one gather-side copy per rank block)
         return blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)
 
     def close(self) -> None:
