@@ -169,6 +169,16 @@ __device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16(w[mt], a[nt], acc[mt][nt]);
 }
 
+// acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
+__device__ __forceinline__ void split_init_acc(const float *bias, int wave, int lane, f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = b;
+    }
+}
+
 // acc += W(chunks c0..c1-1 of `layer`) x act.  Chunk c reads LDS columns 32c.., except `slot_chunk`, which reads the
 // 8-wide input slot at column `slot_col`.  w must already hold chunk c0's weights (issued before the barrier that
 // publishes the activations).  ONE set of weight registers and ONE set of activation registers: every fragment group is
@@ -181,13 +191,20 @@ __device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4
 // first): chunk c+1's w1 is requested at the START of chunk c into the idle buffer (48 MFMAs = 768 cycles to land instead of 16),
 // w2 is re-loaded right after its one product (32 MFMAs), and the LAST chunk requests the first chunk of the layer that follows
 // (`next_layer`, chunk `next_c`) into w.w[0] / w.w[1], which is where every call expects its first chunk.
+// The accumulators are not initialised: the very first product takes the layer's bias (this lane's four columns per column
+// tile, 16 registers) as its C operand -- 64 register moves per GEMM less than broadcasting the bias into acc first.
 __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
-                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c) {
+                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
+                                            const float *bias) {
     uint4 a_hi[4], a_lo[4];
+    f32x4 b4[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) b4[mt] = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
     split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
     split_load_a(a_hi, planes, 0, lane, col_of(c0), c0 == slot_chunk);
     int c = c0;
+    bool first = true;
 #pragma unroll 1
     for (;;) {
         {                                                  // chunk c with w1 in w.w[0]; w.w[2] is idle
@@ -197,7 +214,15 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
             const int wc = last ? next_c : n;
             __builtin_amdgcn_sched_barrier(0);
             if (!last) split_load_w1(w.w[2], layer, 0, wave, lane, n);
-            split_mfma_term(w.w[0], a_lo, acc);
+            if (first) {                                   // (uniform) acc = bias + w1 * a_lo
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16(w.w[0][mt], a_lo[nt], b4[mt]);
+                first = false;
+            } else {
+                split_mfma_term(w.w[0], a_lo, acc);
+            }
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
             split_mfma_term(w.w[1], a_hi, acc);
@@ -234,11 +259,13 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
 
 template <int P>
 __device__ __forceinline__ void split_gemm(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
-                                           int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c) {
+                                           int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
+                                           const float *bias) {
     if constexpr (P == 3) {
-        split_gemm3(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c);
+        split_gemm3(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, bias);
         return;
     }
+    split_init_acc(bias, wave, lane, acc);
     uint4 a_hi[4], a_lo[4];
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
     split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
@@ -268,16 +295,6 @@ __device__ __forceinline__ void split_gemm(const unsigned char *planes, const ui
     }
     __builtin_amdgcn_sched_barrier(0);
     split_load_w<P>(w, next_layer, wave, lane, next_c);    // the first weight fragments of the layer that follows
-}
-
-// acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
-__device__ __forceinline__ void split_init_acc(const float *bias, int wave, int lane, f32x4 (&acc)[4][4]) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = b;
-    }
 }
 
 // four consecutive columns of one row -> both planes, 8 bytes each
@@ -417,10 +434,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     for (int nt = 0; nt < 4; ++nt) cell[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < steps; ++t) {
         f32x4 acc[4][4];
-        split_init_acc(p.bias + kBiasLstm, wave, lane, acc);
         if (t == 1) POLICY_STAMP(8);
         split_gemm<P>(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
-                      t + 1 < steps ? w_lstm : sa.sfrags + kSpOffL1, 0);    // (requests the next step's / layer1's first fragments)
+                      t + 1 < steps ? w_lstm : sa.sfrags + kSpOffL1, 0, p.bias + kBiasLstm);    // (requests the next step's / layer1's first fragments)
         if (t == 1) POLICY_STAMP(9);
         __syncthreads();                                   // every wavefront has read h
         if (t == 1) POLICY_STAMP(10);
@@ -448,8 +464,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     {
         f32x4 acc[4][4];
         if (steps == 0) split_load_w<P>(f0, sa.sfrags + kSpOffL1, wave, lane, 0);    // (else the last LSTM step asked for them)
-        split_init_acc(p.bias + kBiasL1, wave, lane, acc);
-        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, sa.sfrags + kSpOffL2, 0);
+        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, sa.sfrags + kSpOffL2, 0, p.bias + kBiasL1);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -458,8 +473,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     // ---- layer2, fullyconnected1 ----------------------------------------------------------------------------------
     {
         f32x4 acc[4][4];
-        split_init_acc(p.bias + kBiasL2, wave, lane, acc);
-        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, 0);
+        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, 0, p.bias + kBiasL2);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -468,8 +482,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     const uint4 *hp = sa.sfrags + kSpOffHead + lane;
     {
         f32x4 acc[4][4];
-        split_init_acc(p.bias + kBiasFc1, wave, lane, acc);
-        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, kSpChWide - 1);
+        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, kSpChWide - 1, p.bias + kBiasFc1);
 #pragma unroll
         for (int c = 0; c < kSpChWide / 2; ++c)
 #pragma unroll

@@ -282,6 +282,8 @@ def test_native_gather_of_multi_step_blocks_and_to_a_root_single_rank():
                 assert torch.equal(sh.gathered(prev[0]), prev[1]), r - 1
             prev = (slot, rs.packed.clone())
         assert torch.equal(sh.gathered(prev[0]), prev[1])
+        blocks = sh.gathered_blocks(prev[0])                 # the gather as it arrives: one [K, worlds of rank r, N, .] view per rank
+        assert len(blocks) == 1 and torch.equal(blocks[0], prev[1]) and blocks[0].data_ptr() == sh._recv[prev[0]].data_ptr()
         sh.close(); ref.close()
 
 

@@ -1,0 +1,30 @@
+import sys, time, os
+sys.path.insert(0, os.getcwd())
+import torch
+from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+from rl_collision_avoidance_amd.config import EnvConfig
+env = BatchedCollisionAvoidanceEnv(8192, EnvConfig(), seed=1)
+env.reset()
+acts = torch.randint(0, 11, (20, 8192, 4), device="cuda", dtype=torch.int32)
+slots = env.new_step_slots(20)
+x = torch.zeros(8, device="cuda")
+def t(fn, n=200):
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
+    a = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); fn(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        a.append((t1 - t0, t2 - t1))
+    a.sort(key=lambda p: p[0] + p[1])
+    m = a[len(a) // 2]
+    return round(m[0] * 1e6, 1), round(m[1] * 1e6, 1)
+print("empty torch op (x.add_): call, sync us", t(lambda: x.add_(1)))
+print("20-step launch: call, sync us", t(lambda: env.step_autoreset_n(acts, 20, slots=slots)))
+print("1-step launch: call, sync us", t(lambda: env.step_autoreset(acts[0])))
+print("kernel-only us per 20-step launch", env.kernel_time_ms(acts, 20, 20, slots=slots) * 1e3 if hasattr(env, "kernel_time_ms") else None)
+ev = torch.cuda.Event()
+def spin():
+    env.step_autoreset_n(acts, 20, slots=slots); ev.record()
+    while not ev.query(): pass
+print("20-step launch + event spin: call(total), sync us", t(spin))
