@@ -292,8 +292,12 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
  *   rewards / done / game_over / actions int32 [W,N] / values float [W,N]: per-step outputs, holding the LAST step's afterwards.
  *   buffers: the experience store of cavoid_rollout_push.  The policy's launch counter and the rollout's step counter advance
  *   by n_steps on the device (the call can sit in a hipGraph).
- * CAVOID_EUNSUPPORTED (use the step-by-step entry points): rvo_enabled, holonomic dynamics, CAVOID_POLICY_F32, GEN v2 without
- * a scenario pool. */
+ * Worlds with ORCA agents (rvo_enabled) and GEN v2 scenarios generated inside the step run over the env step's ORCA instantiation,
+ * as in cavoid_step_autoreset.
+ * CAVOID_EUNSUPPORTED (use the step-by-step entry points): holonomic dynamics, CAVOID_POLICY_F32 / a non-default
+ * CAVOID_POLICY_PRODUCTS, rvo_enabled with so many agents per world (> 12) that the ORCA lines do not fit into the LDS the
+ * policy lends the env step.  Frozen-network agents (CAVOID_POLICY_FROZEN_NET) take the action the CALLER supplies, which this
+ * entry point does not do: run those worlds through the step-by-step entry points. */
 typedef struct cavoid_rollout_buffers {
     int32_t struct_size;             /* sizeof(cavoid_rollout_buffers) */
     int32_t reserved;

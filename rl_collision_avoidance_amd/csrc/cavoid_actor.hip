@@ -1,31 +1,12 @@
 // cavoid_actor.hip -- C ABI (include/cavoid.h, cavoid_actor_run) over actor_kernel<N> (cavoid_actor.hpp): K closed-loop GA3C actor
 // steps -- policy forward, action selection, env.step, experience bookkeeping -- in ONE launch.  Own translation unit (the
 // kernel carries the policy's GEMM loops and the env step; instantiated per agent count).
-#include <hip/hip_runtime.h>
-
-#include "cavoid.h"
-#include "cavoid_actor.hpp"
-#include "cavoid_host.hpp"
-#include "cavoid_launch.hpp"
+#define CAVOID_ACTOR_KERNELS
+#include "cavoid_actor_host.hpp"
 #include "cavoid_policy_host.hpp"
 #include "cavoid_rollout_host.hpp"
 
 using namespace cavoid;
-
-template <int N>
-static int launch_actor(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
-                        hipStream_t s) {
-    static bool opted_in = false;                            // > 64 KiB of dynamic LDS: opted into once per instantiation
-    if (!opted_in) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(actor_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)policy_split_lds_bytes()));
-        opted_in = true;
-    }
-    const int64_t tiles = (e->W + e->k.wpw - 1) / e->k.wpw;
-    hipLaunchKernelGGL((actor_kernel<N>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, e->k, e->st, e->pool, sa, rc, rs, rio, io);
-    HIP_TRY(hipGetLastError());
-    return CAVOID_OK;
-}
 
 extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout *r, const cavoid_rollout_buffers *b, float *obs_cur, float *obs_next,
                                 float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values, int32_t n_steps,
@@ -42,16 +23,17 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     if (h->device != e->device || r->device != e->device || r->c.num_slots != e->A || r->c.max_agents != e->cfg.max_agents ||
         r->c.obs_width != e->k.width || h->in_size != e->k.width - 1 || h->max_other != e->cfg.max_other)
         return CAVOID_EINVAL;
-    // what the fused kernel does not carry (the step-by-step entry points do): ORCA agents, velocity actions, the float32-MFMA
-    // inference kernel or a non-default number of split products (the kernel carries the default form of cavoid_policy_forward, so
-    // that both stay bit-identical), box scenarios generated inside the step (with a pool they are fine)
-    if (e->cfg.rvo_enabled || e->cfg.dynamics == CAVOID_DYN_HOLONOMIC || !h->use_split || h->split_products != kSpDefaultProducts ||
-        (e->cfg.gen_mode == 1 && e->pool_size <= 0))
-        return CAVOID_EUNSUPPORTED;
+    // what the fused kernel does not carry (the step-by-step entry points do): velocity actions, the float32-MFMA inference kernel
+    // or a non-default number of split products (the kernel carries the default form of cavoid_policy_forward, so that both stay
+    // bit-identical); frozen-network agents need a second network (BatchedRollout keeps those on the step-by-step path)
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC || !h->use_split || h->split_products != kSpDefaultProducts) return CAVOID_EUNSUPPORTED;
     const KCfg &k = e->k;
+    // ORCA agents / box scenarios generated inside the step: the env step's RVO instantiation (as cavoid_step_autoreset routes them)
+    const bool rvo_form = e->cfg.rvo_enabled || (e->cfg.gen_mode == 1 && e->pool_size <= 0);
     int tile = (k.tile_rows * k.width + 3) & ~3;
     if (tile < k.park_floats) tile = k.park_floats;
-    if (actor_env_lds_bytes(tile) > (size_t)2 * kSpPlaneB) return CAVOID_EUNSUPPORTED;
+    // the env step borrows the (idle) activation planes: staging arrays + obs tile (+ the ORCA lines, 64 (N-1) x 16 floats: N <= 12)
+    if (actor_env_lds_bytes(tile, k.rvo_lds_floats) > (size_t)2 * kSpPlaneB) return CAVOID_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     PolicyArgs a{};
@@ -70,19 +52,7 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     ActorIO io{};
     io.obs[0] = obs_cur; io.obs[1] = obs_next; io.rewards = rewards; io.done = done; io.game_over = game_over;
     io.actions = actions; io.values = values; io.rollout_step = r->s.step_counter; io.n_steps = n_steps; io.greedy = greedy ? 1 : 0;
-    int rc_launch = CAVOID_EUNSUPPORTED;
-#define CAVOID_ACTOR_CASE(NN) case NN: rc_launch = launch_actor<NN>(e, sa, rc, r->s, rio, io, s); break;
-    switch (e->cfg.max_agents) {
-#ifdef CAVOID_DEV_ONLY_N
-        CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(10)
-#else
-        CAVOID_ACTOR_CASE(1) CAVOID_ACTOR_CASE(2) CAVOID_ACTOR_CASE(3) CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(5) CAVOID_ACTOR_CASE(6)
-        CAVOID_ACTOR_CASE(7) CAVOID_ACTOR_CASE(8) CAVOID_ACTOR_CASE(9) CAVOID_ACTOR_CASE(10) CAVOID_ACTOR_CASE(11) CAVOID_ACTOR_CASE(12)
-        CAVOID_ACTOR_CASE(13) CAVOID_ACTOR_CASE(14) CAVOID_ACTOR_CASE(15) CAVOID_ACTOR_CASE(16)
-#endif
-        default: break;
-    }
-#undef CAVOID_ACTOR_CASE
+    const int rc_launch = rvo_form ? cavoid_launch_actor_rvo(e, sa, rc, r->s, rio, io, s) : launch_actor_any<false>(e, sa, rc, r->s, rio, io, s);
     if (rc_launch != CAVOID_OK) return rc_launch;
     hipLaunchKernelGGL(actor_finish_kernel, dim3(1), dim3(1), 0, s, r->s.step_counter, h->step_counter, n_steps);
     HIP_TRY(hipGetLastError());

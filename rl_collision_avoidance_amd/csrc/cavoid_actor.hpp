@@ -1,4 +1,4 @@
-// cavoid_actor.hpp -- actor_kernel<N>: the GA3C actor's CLOSED loop, K env steps in ONE launch.
+// cavoid_actor.hpp -- actor_kernel<N, RVO>: the GA3C actor's CLOSED loop, K env steps in ONE launch.
 //
 // What one reference ProcessAgent does per env step (ga3c/GA3C/ProcessAgent.py:116-211): observe -> predict (RPC to
 // ThreadPredictor, ThreadPredictor.py:61-75) -> select_action -> env.step -> Experience bookkeeping / n-step returns.  Here, for
@@ -41,11 +41,13 @@ struct ActorIO {
 
 // LDS the env step of a tile needs inside the (idle) activation planes: the action table + one wavefront's staging arrays and
 // obs tile
-__host__ __device__ inline size_t actor_env_lds_bytes(int tile_floats) {
-    return (size_t)(lds_floats_block() + lds_floats_fixed() + tile_floats) * sizeof(float);
+__host__ __device__ inline size_t actor_env_lds_bytes(int tile_floats, int rvo_floats = 0) {
+    return (size_t)(lds_floats_block() + lds_floats_fixed() + tile_floats + rvo_floats) * sizeof(float);
 }
 
-template <int N>
+// RVO = true: the env step's ORCA instantiation (scripted RVO agents; it is also the one that generates box scenarios inside the
+// step) -- its line scratch comes out of the activation planes too (cavoid_actor_rvo.hip)
+template <int N, bool RVO>
 __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KState s, const PoolRec *pool, const SplitArgs sa,
                                                        const RolloutCfg rc, const RolloutState rs, const RolloutIO rio_arg, const ActorIO io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // the policy's activation planes ...
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
             k.actions = io.actions; k.obs = obs_n; k.rew = io.rewards; k.done = io.done; k.game_over = io.game_over;
             k.obs_stride = ow; k.n_steps = 1;
             StepOut so{0.0f, true, false};
-            env_tile<N, MODE_STEP_AUTORESET, false>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
+            env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
             // ---- Experience bookkeeping of the tile's slots (one lane per slot, the env step's lane mapping) --------------
             const int lw = lane / N, i = lane - lw * N;
             const int64_t w = w0 + lw, a = w * N + i;
@@ -138,10 +140,13 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
     }
 }
 
+#ifdef CAVOID_ACTOR_KERNELS      /* the non-template kernel is compiled by cavoid_actor.hip only */
 // after the actor launch: advance the two device-side counters the next launch (or a hipGraph replay of this one) starts from
 __global__ void actor_finish_kernel(int32_t *rollout_step, int32_t *policy_step, int32_t n_steps) {
     *rollout_step += n_steps;
     *policy_step += n_steps;
 }
+#endif
 
 }  // namespace cavoid
+

@@ -1,0 +1,50 @@
+// cavoid_actor_host.hpp -- launch of actor_kernel<N, RVO> (cavoid_actor.hpp), shared by the two translation units that instantiate
+// it: cavoid_actor.hip (RVO = false) and cavoid_actor_rvo.hip (RVO = true: ORCA agents, box scenarios generated inside the step).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cavoid.h"
+#include "cavoid_actor.hpp"
+#include "cavoid_host.hpp"
+#include "cavoid_launch.hpp"
+
+namespace cavoid {
+
+template <int N, bool RVO>
+static int launch_actor(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
+                        hipStream_t s) {
+    static bool opted_in = false;                            // > 64 KiB of dynamic LDS: opted into once per instantiation
+    if (!opted_in) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(actor_kernel<N, RVO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)policy_split_lds_bytes()));
+        opted_in = true;
+    }
+    const int64_t tiles = (e->W + e->k.wpw - 1) / e->k.wpw;
+    hipLaunchKernelGGL((actor_kernel<N, RVO>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, e->k, e->st, e->pool, sa, rc, rs, rio, io);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}
+
+template <bool RVO>
+static int launch_actor_any(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
+                            hipStream_t s) {
+#define CAVOID_ACTOR_CASE(NN) case NN: return launch_actor<NN, RVO>(e, sa, rc, rs, rio, io, s);
+    switch (e->cfg.max_agents) {
+#ifdef CAVOID_DEV_ONLY_N
+        CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(10)
+#else
+        CAVOID_ACTOR_CASE(1) CAVOID_ACTOR_CASE(2) CAVOID_ACTOR_CASE(3) CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(5) CAVOID_ACTOR_CASE(6)
+        CAVOID_ACTOR_CASE(7) CAVOID_ACTOR_CASE(8) CAVOID_ACTOR_CASE(9) CAVOID_ACTOR_CASE(10) CAVOID_ACTOR_CASE(11) CAVOID_ACTOR_CASE(12)
+        CAVOID_ACTOR_CASE(13) CAVOID_ACTOR_CASE(14) CAVOID_ACTOR_CASE(15) CAVOID_ACTOR_CASE(16)
+#endif
+        default: break;
+    }
+#undef CAVOID_ACTOR_CASE
+    return CAVOID_EUNSUPPORTED;
+}
+
+}  // namespace cavoid
+
+// cavoid_actor_rvo.hip
+int cavoid_launch_actor_rvo(cavoid_env *e, const cavoid::SplitArgs &sa, const cavoid::RolloutCfg &rc, const cavoid::RolloutState &rs,
+                            const cavoid::RolloutIO &rio, const cavoid::ActorIO &io, hipStream_t s);

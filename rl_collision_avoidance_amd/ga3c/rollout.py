@@ -187,12 +187,14 @@ class BatchedRollout(object):
     # -- the fused actor: K closed-loop steps in ONE launch -------------------------------------------------------
     @property
     def fused_available(self) -> bool:
-        """``run_fused`` applies: a ``FusedPolicy`` on the bf16-split kernel, no ORCA agents / velocity actions / row lists."""
+        """``run_fused`` applies: a ``FusedPolicy`` on the bf16-split kernel, no velocity actions / row lists / second (frozen)
+        network; ORCA agents up to 12 agents per world (their line scratch must fit beside the env step's tile in the LDS the
+        policy lends it)."""
         import os
         cfg = self.env.cfg
-        return (getattr(self.policy, "accepts_strided_obs", False) and not self.skip_finished and not cfg.rvo_enabled
-                and self.frozen_policy is None
-                and cfg.dynamics != 2 and not (cfg.gen_mode == 1 and cfg.gen_pool_size <= 0)
+        return (getattr(self.policy, "accepts_strided_obs", False) and not self.skip_finished
+                and not (cfg.rvo_enabled and cfg.max_agents > 12)
+                and self.frozen_policy is None and cfg.dynamics != 2
                 and os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0"))
 
     def _actor_buffers(self):

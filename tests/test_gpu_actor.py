@@ -48,6 +48,9 @@ def _same(a, b, what):
     (10, 300, False, False, dict(gen_min_agents=2, gen_nonlearning_fraction=0.2)),   # configs[3] shape (6 worlds per tile, 4 idle rows)
     (3, 130, False, True, dict(gen_pool_size=0)),                       # greedy (PLAY_MODE), in-kernel scenario generator
     (2, 64, False, False, dict(gen_mode=1, gen_pool_size=200)),         # box scenarios from the pool
+    (4, 700, False, False, dict(rvo_enabled=1, gen_rvo_fraction=0.5, gen_nonlearning_fraction=0.5, gen_min_agents=2)),   # ORCA agents (actor_kernel<N, true>)
+    (3, 200, True, False, dict(gen_mode=1, gen_pool_size=0)),           # box scenarios generated inside the step
+    (10, 100, False, False, dict(rvo_enabled=1, gen_mode=1, gen_pool_size=0, gen_rvo_fraction=0.5, gen_nonlearning_fraction=0.4, gen_min_agents=3)),
 ])
 def test_fused_actor_equals_step_by_step(N, W, reflush, greedy, over):
     seed = 21
@@ -122,7 +125,7 @@ def test_fused_actor_graph_replay_equals_eager_calls():
 
 def test_fused_actor_refuses_what_it_does_not_carry():
     from rl_collision_avoidance_amd import _lib
-    env, _, _, roll = _make(64, 4, 1, False, rvo_enabled=1)
+    env, _, _, roll = _make(64, 4, 1, False, dynamics=2)               # velocity (holonomic) actions: the step-by-step entry points carry them
     assert not roll.fused_available
     with pytest.raises(RuntimeError):
         roll.run_fused(2)

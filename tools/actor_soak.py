@@ -44,8 +44,11 @@ def main():
         W = int(rng.choice([1, int(rng.integers(2, 4 * wpw + 2)), int(rng.integers(50, 3000)), 512 * wpw]))
         kw = dict(gen_min_agents=int(rng.integers(1, N + 1)), gen_nonlearning_fraction=float(rng.choice([0.0, 0.3, 0.7])) if N > 1 else 0.0,
                   gen_pool_size=int(rng.choice([0, 5, 400, 20000])))
-        if rng.random() < 0.3 and kw["gen_pool_size"] > 0:
-            kw["gen_mode"] = 1                                # box scenarios (from the pool: the kernel does not generate them in the step)
+        if rng.random() < 0.3:
+            kw["gen_mode"] = 1                                # box scenarios (from the pool, or generated inside the step)
+        if rng.random() < 0.3 and 1 < N <= 12:
+            kw.update(rvo_enabled=1, gen_rvo_fraction=float(rng.choice([0.3, 1.0])))    # ORCA agents among the scripted ones
+            kw["gen_nonlearning_fraction"] = max(kw["gen_nonlearning_fraction"], 0.3)
         if rng.random() < 0.25:
             kw["sort_method"] = int(rng.integers(0, 3))
         if rng.random() < 0.2:
