@@ -37,6 +37,8 @@ done
 timeout 900 python tools/pmc.py policy_forward_split $out/${tag}_policy_pmc.json "SQ_BUSY_CYCLES SQ_WAVE_CYCLES,SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY,SQ_INSTS_MFMA SQ_INSTS_VALU,SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU,GRBM_GUI_ACTIVE SQ_WAIT_ANY,SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT,SQ_INSTS_SALU SQ_INSTS_VMEM_RD" -- python tools/polbench.py 32768 3 > /dev/null 2>> $out/errors.txt
 timeout 900 python tools/pmc.py actor_kernel $out/${tag}_actor_pmc.json "SQ_BUSY_CYCLES SQ_WAVE_CYCLES,SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY,SQ_INSTS_MFMA SQ_INSTS_VALU,SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU,GRBM_GUI_ACTIVE SQ_WAIT_ANY,SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT,SQ_INSTS_SALU SQ_INSTS_VMEM_RD" -- python tools/actbench.py 8192 4 16 6 > /dev/null 2>> $out/errors.txt
 (hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/mfma_valu_overlap.hip -o /tmp/mvo 2>/dev/null && /tmp/mvo > $out/${tag}_mfma_valu_overlap.txt) 2>> $out/errors.txt
+(hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/cu_scaling.hip -o /tmp/cus 2>/dev/null && /tmp/cus > $out/${tag}_cu_scaling.txt) 2>> $out/errors.txt
+(hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/wave_placement.hip -o /tmp/wp 2>/dev/null && /tmp/wp > $out/${tag}_wave_placement.txt) 2>> $out/errors.txt
 for n in 16384 32768; do CAVOID_LIB=rl_collision_avoidance_amd/libcavoid_hip_trace.so python tools/trace_policy.py $n 2>&1 | grep -v "amdgpu.ids\|pair " ; done > $out/${tag}_policy_phase_trace.txt
 timeout 1500 python bench.py --sweep --full-loop > $out/${tag}_bench.json 2>> $out/errors.txt
 timeout 900 python bench.py --agents 10 --sweep --no-full-loop > $out/${tag}_bench_n10.json 2>> $out/errors.txt
