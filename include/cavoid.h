@@ -309,6 +309,15 @@ int cavoid_actor_run(cavoid_env *env, cavoid_policy *policy, cavoid_rollout *rol
                      float *obs_cur, float *obs_next, float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values,
                      int32_t n_steps, int32_t greedy, void *stream);
 
+/* cavoid_step_autoreset + cavoid_rollout_push as ONE launch: the env step of every world and the Experience bookkeeping of its slots
+ * (ProcessAgent.py:149-211) -- the fused actor's env phase for actors whose policy is a launch of its own (frozen-network agents,
+ * a caller-supplied policy).  obs_cur [W,N,1+D]: the observation `actions` / `values` (V(s_t)) were computed on; the step writes the
+ * next one into obs_next (a different buffer) and rewards / done / game_over; buffers: the experience store of cavoid_rollout_push;
+ * step as there (< 0: the handle's device-side counter, advanced by the call).  Bit-identical to the two calls it replaces.
+ * CAVOID_EUNSUPPORTED: holonomic dynamics. */
+int cavoid_step_push(cavoid_env *env, cavoid_rollout *rollout, const cavoid_rollout_buffers *buffers, const float *obs_cur, float *obs_next,
+                     const int32_t *actions, const float *values, float *rewards, uint8_t *done, uint8_t *game_over, int32_t step, void *stream);
+
 /* hand-over to the trainer (`training_q.put((x_, r_, a_))`, ProcessAgent.py:238): append the training rows (emit_t >= 0) of
  * the step blocks [step_lo, step_hi) to one batch -- out_x float [capacity, D], out_r float [capacity] (n-step returns),
  * out_a int32 [capacity], out_src int32 [capacity, 4] (world, agent, recorded-at, emitted-at; may be NULL),

@@ -58,3 +58,34 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }
+
+extern "C" int cavoid_step_push(cavoid_env *e, cavoid_rollout *r, const cavoid_rollout_buffers *b, const float *obs_cur, float *obs_next,
+                                const int32_t *actions, const float *values, float *rewards, uint8_t *done, uint8_t *game_over, int32_t step,
+                                void *stream) {
+    if (!e || !r || !b || b->struct_size != (int32_t)sizeof(cavoid_rollout_buffers) || !obs_cur || !obs_next || obs_cur == obs_next ||
+        !actions || !values || !rewards || !done || !game_over)
+        return CAVOID_EINVAL;
+    if (!b->x || !b->val || !b->ret || !b->act || !b->emit_t || !b->dup_x || !b->dup_r || !b->dup_a || !b->dup_src || !b->dup_count ||
+        !b->ep_out || !b->ep_count || b->dup_capacity < 1 || b->ep_capacity < 1)
+        return CAVOID_EINVAL;
+    if (r->device != e->device || r->c.num_slots != e->A || r->c.max_agents != e->cfg.max_agents || r->c.obs_width != e->k.width) return CAVOID_EINVAL;
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EUNSUPPORTED;       // (velocity actions: cavoid_step_continuous + cavoid_rollout_push)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RolloutCfg rc = r->c;
+    rc.dup_capacity = b->dup_capacity; rc.ep_capacity = b->ep_capacity;
+    RolloutIO rio{};
+    rio.step = step; rio.x = b->x; rio.val = b->val; rio.ret = b->ret; rio.act = b->act; rio.emit_t = b->emit_t;
+    rio.dup_x = b->dup_x; rio.dup_r = b->dup_r; rio.dup_a = b->dup_a; rio.dup_src = b->dup_src; rio.dup_count = b->dup_count;
+    rio.ep_out = b->ep_out; rio.ep_count = b->ep_count;
+    ActorIO io{};
+    io.obs[0] = const_cast<float *>(obs_cur); io.obs[1] = obs_next; io.rewards = rewards; io.done = done; io.game_over = game_over;
+    io.actions = const_cast<int32_t *>(actions); io.values = const_cast<float *>(values); io.rollout_step = r->s.step_counter; io.n_steps = 1;
+    const bool rvo_form = e->cfg.rvo_enabled || (e->cfg.gen_mode == 1 && e->pool_size <= 0);
+    const int rc_launch = rvo_form ? cavoid_launch_step_push_rvo(e, rc, r->s, rio, io, step, s) : launch_step_push_any<false>(e, rc, r->s, rio, io, step, s);
+    if (rc_launch != CAVOID_OK) return rc_launch;
+    if (step < 0) {                                          // the device-side step counter moves on (hipGraph replays)
+        hipLaunchKernelGGL(actor_finish_kernel, dim3(1), dim3(1), 0, s, r->s.step_counter, static_cast<int32_t *>(nullptr), 1);
+        HIP_TRY(hipGetLastError());
+    }
+    return CAVOID_OK;
+}

@@ -45,6 +45,40 @@ __host__ __device__ inline size_t actor_env_lds_bytes(int tile_floats, int rvo_f
     return (size_t)(lds_floats_block() + lds_floats_fixed() + tile_floats + rvo_floats) * sizeof(float);
 }
 
+// env.step of ONE tile by ONE wavefront + the Experience bookkeeping of the tile's slots (the env step's lane mapping: one lane
+// per slot): the statements of env_kernel<MODE_STEP_AUTORESET>, rollout_push_kernel and rollout_episode_kernel.  obs_t: the
+// observation the actions were chosen on; the step writes the next one into obs_n.
+template <int N, bool RVO>
+__device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState &s, const PoolRec *pool, const RolloutCfg &rc, const RolloutState &rs,
+                                                    const RolloutIO &rio_arg, const ActorIO &io, const float *obs_t, float *obs_n, double *lds_tab,
+                                                    float *wbase, int lane, int64_t tile, int32_t step, int blk) {
+    const int wpw = c.wpw, ow = c.width;
+    const int64_t w0 = tile * wpw;
+    KIO k{};
+    k.actions = io.actions; k.obs = obs_n; k.rew = io.rewards; k.done = io.done; k.game_over = io.game_over;
+    k.obs_stride = ow; k.n_steps = 1;
+    StepOut so{0.0f, true, false};
+    env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
+    const int lw = lane / N, i = lane - lw * N;
+    const int64_t w = w0 + lw, a = w * N + i;
+    const bool in_range = lane < wpw * N && w < c.num_worlds;
+    const bool learning = in_range && obs_t[a * ow] > 0.5f;          // is_learning of the state acted on (ProcessAgent.py:130)
+    const int base = lane < wpw * N ? lw * N : 0;
+    const int n_learning = __popcll(__ballot(learning) & (((1ull << N) - 1ull) << base));
+    float value = 0.0f;
+    int action = 0;
+    if (in_range) { value = io.values[a]; action = io.actions[a]; }
+    RolloutIO rio = rio_arg;
+    rollout_push_slot(rc, rs, rio, a, in_range ? w : 0, i, in_range, learning, n_learning, so.done, so.game_over, so.reward, value,
+                      action, step, blk);
+    // episode_log_q.put: the totals above were accumulated with atomics by this wavefront's own lanes -- drain them;
+    // rollout_close_episode reads the sums at the cache the atomics went to
+    if (__ballot(in_range && so.game_over) != 0ull) {
+        __builtin_amdgcn_s_waitcnt(0);                       // (vmcnt 0: the atomics have been performed at the L2)
+        if (in_range && i == 0 && so.game_over) rollout_close_episode(rc, rs, rio, w);
+    }
+}
+
 // RVO = true: the env step's ORCA instantiation (scripted RVO agents; it is also the one that generates box scenarios inside the
 // step) -- its line scratch comes out of the activation planes too (cavoid_actor_rvo.hip)
 template <int N, bool RVO>
@@ -107,31 +141,8 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
         __syncthreads();                                     // the tile's actions / values are in memory; the planes are idle
 
         if (wave_in_block == 0) {
-            // ---- env.step of the tile ------------------------------------------------------------------------------------
-            KIO k{};
-            k.actions = io.actions; k.obs = obs_n; k.rew = io.rewards; k.done = io.done; k.game_over = io.game_over;
-            k.obs_stride = ow; k.n_steps = 1;
-            StepOut so{0.0f, true, false};
-            env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
-            // ---- Experience bookkeeping of the tile's slots (one lane per slot, the env step's lane mapping) --------------
-            const int lw = lane / N, i = lane - lw * N;
-            const int64_t w = w0 + lw, a = w * N + i;
-            const bool in_range = lane < wpw * N && w < c.num_worlds;
-            const bool learning = in_range && obs_t[a * ow] > 0.5f;          // is_learning of the state acted on (ProcessAgent.py:130)
-            const int base = lane < wpw * N ? lw * N : 0;
-            const int n_learning = __popcll(__ballot(learning) & (((1ull << N) - 1ull) << base));
-            float value = 0.0f;
-            int action = 0;
-            if (in_range) { value = io.values[a]; action = io.actions[a]; }
-            RolloutIO rio = rio_arg;
-            rollout_push_slot(rc, rs, rio, a, in_range ? w : 0, i, in_range, learning, n_learning, so.done, so.game_over, so.reward, value,
-                              action, step, blk);
-            // episode_log_q.put: the totals above were accumulated with atomics by this wavefront's own lanes -- drain them;
-            // rollout_close_episode reads the sums at the cache the atomics went to
-            if (__ballot(in_range && so.game_over) != 0ull) {
-                __builtin_amdgcn_s_waitcnt(0);               // (vmcnt 0: the atomics have been performed at the L2)
-                if (in_range && i == 0 && so.game_over) rollout_close_episode(rc, rs, rio, w);
-            }
+            // ---- env.step of the tile, then the Experience bookkeeping of its slots ---------------------------------------
+            actor_env_push_tile<N, RVO>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, lds_tab, wbase, lane, tile, step, blk);
         } else {
             // ---- meanwhile: the step's state rows -> the time-major experience store -----------------------------------------
             rollout_copy_rows(rc, obs_t, rio_arg.x, a0, rows, blk, tid - 64, 192);
@@ -140,11 +151,36 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
     }
 }
 
+// One auto-reset step of every world + its Experience bookkeeping in ONE launch (cavoid_step_push): the env phase of the loop
+// above as a kernel of its own -- one wavefront per tile, env_kernel's launch shape -- for actors whose policy runs as its own
+// launch (frozen-network agents, row lists, a caller-supplied policy): three launches (env, push, episode log) become one, the
+// step's rewards / done flags go from the env step to the bookkeeping in registers.
+template <int N, bool RVO>
+__global__ void __launch_bounds__(256) step_push_kernel(const KCfg c, const KState s, const PoolRec *pool, const RolloutCfg rc, const RolloutState rs,
+                                                        const RolloutIO rio_arg, const ActorIO io, const int32_t step_arg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile_need = (c.tile_rows * c.width + 3) & ~3;
+    const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
+    const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
+    double *lds_tab = reinterpret_cast<double *>(smem);
+    float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const int32_t step = step_arg >= 0 ? step_arg : *io.rollout_step;
+    const int blk = step % rc.ring_len;
+    actor_env_push_tile<N, RVO>(c, s, pool, rc, rs, rio_arg, io, io.obs[0], io.obs[1], lds_tab, wbase, lane, tile, step, blk);
+    // the step's state rows -> the time-major experience store
+    const int64_t a0 = tile * c.wpw * N;
+    int64_t worlds_here = c.num_worlds - tile * c.wpw;
+    worlds_here = worlds_here > c.wpw ? c.wpw : (worlds_here < 0 ? 0 : worlds_here);
+    rollout_copy_rows(rc, io.obs[0], rio_arg.x, a0, (int)worlds_here * N, blk, lane, 64);
+}
+
 #ifdef CAVOID_ACTOR_KERNELS      /* the non-template kernel is compiled by cavoid_actor.hip only */
 // after the actor launch: advance the two device-side counters the next launch (or a hipGraph replay of this one) starts from
 __global__ void actor_finish_kernel(int32_t *rollout_step, int32_t *policy_step, int32_t n_steps) {
     *rollout_step += n_steps;
-    *policy_step += n_steps;
+    if (policy_step) *policy_step += n_steps;
 }
 #endif
 

@@ -43,8 +43,39 @@ static int launch_actor_any(cavoid_env *e, const SplitArgs &sa, const RolloutCfg
     return CAVOID_EUNSUPPORTED;
 }
 
+template <int N, bool RVO>
+static int launch_step_push(cavoid_env *e, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io, int32_t step, hipStream_t s) {
+    const KCfg &k = e->k;
+    int tile = (k.tile_rows * k.width + 3) & ~3;
+    if (tile < k.park_floats) tile = k.park_floats;
+    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed() + k.rvo_lds_floats + tile)) * sizeof(float);
+    hipLaunchKernelGGL((step_push_kernel<N, RVO>), dim3((unsigned)e->grid), dim3(64 * e->waves_per_block), lds, s, k, e->st, e->pool, rc, rs, rio, io, step);
+    HIP_TRY(hipGetLastError());
+    return CAVOID_OK;
+}
+
+template <bool RVO>
+static int launch_step_push_any(cavoid_env *e, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io, int32_t step,
+                                hipStream_t s) {
+#define CAVOID_ACTOR_CASE(NN) case NN: return launch_step_push<NN, RVO>(e, rc, rs, rio, io, step, s);
+    switch (e->cfg.max_agents) {
+#ifdef CAVOID_DEV_ONLY_N
+        CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(10)
+#else
+        CAVOID_ACTOR_CASE(1) CAVOID_ACTOR_CASE(2) CAVOID_ACTOR_CASE(3) CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(5) CAVOID_ACTOR_CASE(6)
+        CAVOID_ACTOR_CASE(7) CAVOID_ACTOR_CASE(8) CAVOID_ACTOR_CASE(9) CAVOID_ACTOR_CASE(10) CAVOID_ACTOR_CASE(11) CAVOID_ACTOR_CASE(12)
+        CAVOID_ACTOR_CASE(13) CAVOID_ACTOR_CASE(14) CAVOID_ACTOR_CASE(15) CAVOID_ACTOR_CASE(16)
+#endif
+        default: break;
+    }
+#undef CAVOID_ACTOR_CASE
+    return CAVOID_EUNSUPPORTED;
+}
+
 }  // namespace cavoid
 
 // cavoid_actor_rvo.hip
+int cavoid_launch_step_push_rvo(cavoid_env *e, const cavoid::RolloutCfg &rc, const cavoid::RolloutState &rs, const cavoid::RolloutIO &rio,
+                                const cavoid::ActorIO &io, int32_t step, hipStream_t s);
 int cavoid_launch_actor_rvo(cavoid_env *e, const cavoid::SplitArgs &sa, const cavoid::RolloutCfg &rc, const cavoid::RolloutState &rs,
                             const cavoid::RolloutIO &rio, const cavoid::ActorIO &io, hipStream_t s);

@@ -9,3 +9,8 @@ int cavoid_launch_actor_rvo(cavoid_env *e, const SplitArgs &sa, const RolloutCfg
                             hipStream_t s) {
     return launch_actor_any<true>(e, sa, rc, rs, rio, io, s);
 }
+
+int cavoid_launch_step_push_rvo(cavoid_env *e, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io, int32_t step,
+                                hipStream_t s) {
+    return launch_step_push_any<true>(e, rc, rs, rio, io, step, s);
+}

@@ -58,6 +58,10 @@ class BatchedRollout(object):
         self.discount = float(getattr(cfg, "DISCOUNT", discount))
         self.greedy = greedy                     # PLAY_MODE / EVALUATE_MODE: argmax instead of sampling (:98-103)
         self._reflush = bool(reflush_done)
+        # step(): env.step and the Experience bookkeeping in one launch (cavoid_step_push) instead of three (env, push, episode log);
+        # CAVOID_FUSE_ENV_PUSH=0 keeps the three launches (the form the goldens pin; both are compared bitwise in the tests)
+        import os
+        self.fuse_env_push = os.environ.get("CAVOID_FUSE_ENV_PUSH", "1") not in ("0", "")
         # fused policy only: no forward pass for absent agents and for agents that have finished and wait for their world to
         # end (the env ignores their action, nothing of theirs is recorded; ~30 % of the rows in the TrainPhase1 workload).
         # Never in the faithful re-flush mode, whose quirk rows carry V(s) of exactly those agents.  Default: only when the
@@ -173,8 +177,15 @@ class BatchedRollout(object):
         actions = env._want(actions, (env.num_worlds, env.max_agents), torch.int32, "actions")
         values = env._want(values, (env.num_worlds, env.max_agents), torch.float32, "values")
         nxt = self._obs_buffers[1 - self._cur]
-        _, rew, done, game_over = env.step_autoreset(actions, obs_out=nxt)
         p = BatchedCollisionAvoidanceEnv._ptr
+        if self.fuse_env_push and env.cfg.dynamics != 2:
+            # env.step + Experience bookkeeping as ONE launch (cavoid_step_push: the fused actor's env phase as a kernel of its own)
+            _lib.check(self._lib.cavoid_step_push(self._h_env(), self._h, C.byref(self._actor_buffers()), p(obs), p(nxt), p(actions), p(values),
+                                                  p(env.rewards), p(env.done), p(env.game_over), -1, env._stream()), "cavoid_step_push")
+            self._cur = 1 - self._cur
+            self.step_index += 1
+            return env.rewards, env.done, env.game_over
+        _, rew, done, game_over = env.step_autoreset(actions, obs_out=nxt)
         _lib.check(self._lib.cavoid_rollout_push(
             self._h, p(obs), p(actions), p(values), p(rew), p(done), p(game_over), -1,      # -1: device-side step counter
             p(self.x), p(self.val), p(self.ret), p(self.act_ring), p(self.emit_t),
@@ -196,6 +207,9 @@ class BatchedRollout(object):
                 and not (cfg.rvo_enabled and cfg.max_agents > 12)
                 and self.frozen_policy is None and cfg.dynamics != 2
                 and os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0"))
+
+    def _h_env(self):
+        return self.env._h
 
     def _actor_buffers(self):
         if getattr(self, "_bufs", None) is None:

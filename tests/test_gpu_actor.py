@@ -169,3 +169,62 @@ def test_pipelined_hand_over_equals_drain():
     for r in (a, b):
         r.close()
     env_a.close(); env_b.close()
+
+
+@pytest.mark.parametrize("N,W,reflush,over", [
+    (4, 1000, True, dict(gen_min_agents=2, gen_nonlearning_fraction=0.3)),
+    (10, 300, False, dict(gen_min_agents=2, gen_nonlearning_fraction=0.2)),
+    (4, 500, False, dict(rvo_enabled=1, gen_rvo_fraction=0.5, gen_nonlearning_fraction=0.5, gen_mode=1, gen_pool_size=0)),
+    (1, 200, False, dict()),
+])
+def test_step_push_equals_step_then_push(N, W, reflush, over):
+    """`cavoid_step_push` (env.step + Experience bookkeeping in ONE launch, BatchedRollout.step's default) against the three launches
+    it replaces (`cavoid_step_autoreset`, `cavoid_rollout_push`: push + episode log), bitwise; scripted actions / values (N = 1 has
+    no policy to run) and, for N > 1, the policy in the loop."""
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+    rolls = []
+    for fuse in (True, False):
+        if N > 1:
+            env, _, _, roll = _make(W, N, 17, reflush, False, **over)
+        else:
+            env = BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=17, **over)
+            roll = BatchedRollout(env, None, reflush_done=reflush, time_max=5)
+            roll.reset()
+        roll.fuse_env_push = fuse
+        rolls.append((env, roll))
+    (ea, a), (eb, b) = rolls
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(150):
+        if N > 1 and t % 3:
+            a.step(); b.step()                               # policy in the loop
+        else:
+            acts = torch.randint(0, 11, (W, N), generator=g, device="cuda", dtype=torch.int32)
+            vals = torch.randn((W, N), generator=g, device="cuda")
+            a.step(acts, vals); b.step(acts, vals)
+        if t % 10 == 9 or t < 5:
+            _same(a.obs, b.obs, ("obs", t))
+            for x, y in zip(ea.get_state(), eb.get_state()):
+                _same(x, y, ("state", t))
+            for name in ("rewards", "done", "game_over", "episode"):
+                _same(getattr(ea, name), getattr(eb, name), (name, t))
+            for name in ("x", "val", "ret", "act_ring", "emit_t", "dup_count"):
+                _same(getattr(a, name), getattr(b, name), (name, t))
+    ba, bb = a.drain(flush_all=True), b.drain(flush_all=True)
+    assert len(ba) == len(bb) > 0 and ba.dropped == bb.dropped == 0
+    ka, kb = np.lexsort(ba.src.cpu().numpy().T[::-1]), np.lexsort(bb.src.cpu().numpy().T[::-1])
+    for name in ("src", "x", "r", "a_index"):
+        assert np.array_equal(getattr(ba, name).cpu().numpy()[ka], getattr(bb, name).cpu().numpy()[kb]), name
+    epa, epb = a.drain_episodes().cpu().numpy(), b.drain_episodes().cpu().numpy()
+    assert len(epa) == len(epb) > 0
+    epa, epb = epa[np.lexsort(epa.T[::-1])], epb[np.lexsort(epb.T[::-1])]
+    assert np.array_equal(epa[:, 0], epb[:, 0]) and np.array_equal(epa[:, 2], epb[:, 2])
+    np.testing.assert_allclose(epa[:, 1], epb[:, 1], rtol=1e-6, atol=1e-6)
+    for e, r in rolls:
+        r.close(); e.close()
