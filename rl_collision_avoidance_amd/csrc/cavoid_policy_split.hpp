@@ -187,19 +187,23 @@ __device__ __forceinline__ void split_init_acc(const float *bias, int wave, int 
 //     w1*a_lo   w1*a_hi   [w1 <- next]   w2*a_lo   [a_lo <- next]   w2*a_hi   [w2 <- next]   w3*a_hi   [w3, a_hi <- next]
 // 144 live registers (64 accumulators, 48 weight, 32 activation) instead of 240 for a double-buffered pipeline.
 //
+// this lane's four bias values per column tile (columns 16*(4*wave+mt) + 4*(lane/16) + r)
+__device__ __forceinline__ void split_load_bias(f32x4 (&b4)[4], const float *bias, int wave, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) b4[mt] = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
+}
+
 // P = 3 reads only two weight planes, so the third register group double-buffers plane 1 (the plane both of whose products come
 // first): chunk c+1's w1 is requested at the START of chunk c into the idle buffer (48 MFMAs = 768 cycles to land instead of 16),
 // w2 is re-loaded right after its one product (32 MFMAs), and the LAST chunk requests the first chunk of the layer that follows
 // (`next_layer`, chunk `next_c`) into w.w[0] / w.w[1], which is where every call expects its first chunk.
 // The accumulators are not initialised: the very first product takes the layer's bias (this lane's four columns per column
-// tile, 16 registers) as its C operand -- 64 register moves per GEMM less than broadcasting the bias into acc first.
+// tile, 16 registers: b4) as its C operand -- 64 register moves per GEMM less than broadcasting the bias into acc first.  b4 is
+// loaded one GEMM ahead, like the first weight fragments: the last chunk requests `next_bias` into it.
 __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
                                             int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
-                                            const float *bias) {
+                                            f32x4 (&b4)[4], const float *next_bias) {
     uint4 a_hi[4], a_lo[4];
-    f32x4 b4[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) b4[mt] = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
     split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
     split_load_a(a_hi, planes, 0, lane, col_of(c0), c0 == slot_chunk);
@@ -223,6 +227,7 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
             } else {
                 split_mfma_term(w.w[0], a_lo, acc);
             }
+            if (last) split_load_bias(b4, next_bias, wave, lane);   // (b4 was consumed by the first product: free since then)
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
             split_mfma_term(w.w[1], a_hi, acc);
@@ -242,6 +247,7 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[0], wl, 0, wave, lane, wc);
             split_mfma_term(w.w[2], a_lo, acc);
+            if (last) split_load_bias(b4, next_bias, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
             split_mfma_term(w.w[1], a_hi, acc);
@@ -260,9 +266,9 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
 template <int P>
 __device__ __forceinline__ void split_gemm(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
-                                           const float *bias) {
+                                           const float *bias, f32x4 (&b4)[4], const float *next_bias) {
     if constexpr (P == 3) {
-        split_gemm3(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, bias);
+        split_gemm3(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, b4, next_bias);
         return;
     }
     split_init_acc(bias, wave, lane, acc);
@@ -314,7 +320,11 @@ __device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 z;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = fmaxf(acc[mt][nt][r], 0.0f);
+            for (int r = 0; r < 4; ++r) {                  // relu as ONE integer max on the bit pattern (negative floats are negative
+                const float v = acc[mt][nt][r];            // integers; fmaxf costs a canonicalising max more).  (Through a scalar:
+                const int bits = __float_as_int(v);        // __builtin_bit_cast straight on the vector element reads element 0.)
+                z[r] = __int_as_float(bits > 0 ? bits : 0);
+            }
             split_store4(planes, 16 * nt + (lane & 15), 16 * (4 * wave + mt) + 4 * (lane >> 4), z);
         }
 }
@@ -372,7 +382,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     const int M = p.max_other, A = p.num_actions;
     const uint4 *w_lstm = sa.sfrags + kSpOffLstm;
     SplitW f0;
+    f32x4 b4[4];                                           // the bias of the GEMM that comes next (P = 3: its first product's C operand)
     split_load_w<P>(f0, w_lstm, wave, lane, 2);               // first LSTM step: h == 0, only the input chunk contributes
+    split_load_bias(b4, p.bias + kBiasLstm, wave, lane);
 
     // ---- input tile: gather + normalise + split into the slot columns ---------------------------------------------
     {
@@ -436,7 +448,8 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         f32x4 acc[4][4];
         if (t == 1) POLICY_STAMP(8);
         split_gemm<P>(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
-                      t + 1 < steps ? w_lstm : sa.sfrags + kSpOffL1, 0, p.bias + kBiasLstm);    // (requests the next step's / layer1's first fragments)
+                      t + 1 < steps ? w_lstm : sa.sfrags + kSpOffL1, 0, p.bias + kBiasLstm, b4,
+                      p.bias + (t + 1 < steps ? kBiasLstm : kBiasL1));      // (requests the next step's / layer1's first fragments and bias)
         if (t == 1) POLICY_STAMP(9);
         __syncthreads();                                   // every wavefront has read h
         if (t == 1) POLICY_STAMP(10);
@@ -463,8 +476,12 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     // ---- layer1 on [h | host] -------------------------------------------------------------------------------------
     {
         f32x4 acc[4][4];
-        if (steps == 0) split_load_w<P>(f0, sa.sfrags + kSpOffL1, wave, lane, 0);    // (else the last LSTM step asked for them)
-        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, sa.sfrags + kSpOffL2, 0, p.bias + kBiasL1);
+        if (steps == 0) {                                  // (else the last LSTM step asked for them)
+            split_load_w<P>(f0, sa.sfrags + kSpOffL1, wave, lane, 0);
+            split_load_bias(b4, p.bias + kBiasL1, wave, lane);
+        }
+        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, sa.sfrags + kSpOffL2, 0, p.bias + kBiasL1, b4,
+                      p.bias + kBiasL2);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -473,7 +490,8 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     // ---- layer2, fullyconnected1 ----------------------------------------------------------------------------------
     {
         f32x4 acc[4][4];
-        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, 0, p.bias + kBiasL2);
+        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, 0, p.bias + kBiasL2, b4,
+                      p.bias + kBiasFc1);
         __syncthreads();
         split_store_relu(planes, wave, lane, acc);
         __syncthreads();
@@ -482,7 +500,8 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     const uint4 *hp = sa.sfrags + kSpOffHead + lane;
     {
         f32x4 acc[4][4];
-        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, kSpChWide - 1, p.bias + kBiasFc1);
+        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, kSpChWide - 1, p.bias + kBiasFc1, b4,
+                      p.bias + kBiasFc1);
 #pragma unroll
         for (int c = 0; c < kSpChWide / 2; ++c)
 #pragma unroll
