@@ -74,6 +74,8 @@ def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1, slots=False, po
 
 
 def main():
+    """usage: python tests/parity_stress.py [seed offset ...]   (one pass over the case list per offset; default: one pass, offset 0)"""
+    offsets = [int(x) for x in sys.argv[1:]] or [0]
     t0 = time.time()
     total = {"obs": 0.0, "rew": 0.0, "state": 0.0, "flag_mismatch": 0, "done_mismatch": 0, "episode_mismatch": 0, "agent_steps": 0}
     cases = [(4, 4096, 400, s, 0.0, 0) for s in range(6)] + [(4, 2048, 300, 100 + s, 0.4, 1) for s in range(3)] + \
@@ -93,7 +95,8 @@ def main():
              [(10, 1024, 256, 1040, 0.3, 0, 0, 0.0, 16, True, 4096, 0.0, U)]
     # (round 2: + step-loop launches with the packed record, + GEN v2 scenarios with RVO agents; the last three: env_relay_kernel
     #  with scripted agents in the tile, N = 3 / 4 / 5, 17 ... 64 steps per launch)
-    for c in cases:
+    for off, c in [(o, c) for o in offsets for c in cases]:
+        c = c[:3] + (c[3] + off,) + c[4:]                   # (N, W, steps, seed, ...)
         r = run(*c)
         for k in ("obs", "rew", "state"):
             total[k] = max(total[k], r[k])
@@ -101,6 +104,7 @@ def main():
             total[k] += r[k]
         print(c, r, flush=True)
     total["seconds"] = round(time.time() - t0, 1)
+    total["passes"] = len(offsets)
     print(json.dumps(total))
 
 
