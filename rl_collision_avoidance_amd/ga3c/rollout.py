@@ -203,7 +203,9 @@ class BatchedRollout(object):
         policy lends it)."""
         import os
         cfg = self.env.cfg
-        return (getattr(self.policy, "accepts_strided_obs", False) and not self.skip_finished
+        # (skip_finished -- the step-by-step path's row list of the agents that still need an action -- does not matter here: the
+        #  kernel runs every row of a tile anyway, and what finished agents are given as action / value is never used)
+        return (getattr(self.policy, "accepts_strided_obs", False)
                 and not (cfg.rvo_enabled and cfg.max_agents > 12)
                 and self.frozen_policy is None and cfg.dynamics != 2
                 and os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0"))

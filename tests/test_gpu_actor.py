@@ -15,7 +15,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def _make(W, N, seed, reflush, greedy=False, **over):
+def _make(W, N, seed, reflush, greedy=False, skip_finished=None, **over):
     from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
     from rl_collision_avoidance_amd.config import EnvConfig
     from rl_collision_avoidance_amd.ga3c.network import NetworkVP_rnn
@@ -33,7 +33,8 @@ def _make(W, N, seed, reflush, greedy=False, **over):
     pol = FusedPolicy(net, seed=77)
     # short chunks: many flushes; room for every duplicate row of the re-flush quirk (a full buffer drops rows in arrival order,
     # which legitimately differs between the two forms)
-    roll = BatchedRollout(env, pol, reflush_done=reflush, greedy=greedy, time_max=5, dup_capacity=600000 if reflush else None)
+    roll = BatchedRollout(env, pol, reflush_done=reflush, greedy=greedy, time_max=5, dup_capacity=600000 if reflush else None,
+                          skip_finished=skip_finished)
     roll.reset()
     return env, net, pol, roll
 
@@ -102,6 +103,34 @@ def test_fused_actor_equals_step_by_step(N, W, reflush, greedy, over):
         r.close()
     for e in (env_a, env_b):
         e.close()
+
+
+def test_fused_actor_equals_step_by_step_with_a_row_list():
+    """`skip_finished` (the step-by-step path runs the policy on the rows that still need an action only; batches above 65 536 rows
+    choose it by themselves) changes nothing the fused kernel could differ in: it stays available and equal."""
+    W, N, seed = 700, 4, 5
+    env_a, _, _, a = _make(W, N, seed, False, skip_finished=True, gen_min_agents=2, gen_nonlearning_fraction=0.3)
+    env_b, _, _, b = _make(W, N, seed, False, skip_finished=True, gen_min_agents=2, gen_nonlearning_fraction=0.3)
+    assert a.fused_available and b.skip_finished
+    for k in (3, 16, 16, 16, 16, 16, 16, 16, 16, 16, 5):
+        a.run_fused(k)
+        for _ in range(k):
+            b.step()
+        _same(a.obs, b.obs, "obs")
+        for x, y in zip(env_a.get_state(), env_b.get_state()):
+            _same(x, y, "state")
+        # (the action / value rings hold whatever the policy put out for EVERY slot; for agents that are finished and wait, the row
+        #  list leaves the previous entry -- never read -- so the rings are compared through what becomes a training row)
+        for name in ("x", "emit_t"):
+            _same(getattr(a, name), getattr(b, name), name)
+    ba, bb = a.drain(flush_all=True), b.drain(flush_all=True)
+    assert len(ba) == len(bb) > 0
+    ka, kb = np.lexsort(ba.src.cpu().numpy().T[::-1]), np.lexsort(bb.src.cpu().numpy().T[::-1])
+    for name in ("src", "x", "r", "a_index"):
+        assert np.array_equal(getattr(ba, name).cpu().numpy()[ka], getattr(bb, name).cpu().numpy()[kb]), name
+    for r in (a, b):
+        r.close()
+    env_a.close(); env_b.close()
 
 
 def test_fused_actor_graph_replay_equals_eager_calls():
