@@ -130,7 +130,9 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
     from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedA3CTrainer, FusedPolicy
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
-    per_graph = int(os.environ.get("CAVOID_STEPS_PER_GRAPH", "16"))  # env steps per hipGraph replay (even): one drain (a host sync) per replay
+    # env steps per launch of the fused actor kernel / per hipGraph replay (even), one hand-over of training rows per launch:
+    # 16 -> 405 M, 32 -> 450 M, 64 -> 480 M learning-agent-steps/s actors only (the hand-over and the launch gaps are per launch)
+    per_graph = int(os.environ.get("CAVOID_STEPS_PER_GRAPH", "32"))
 
     def regime(fused: bool, train: bool, fused_trainer: bool = False, actor_kernel: bool = False):
         env = env_cls(W, cfg, device=device, world_offset=rank * W, seed=11)
@@ -656,7 +658,7 @@ def main() -> None:
         # without any collective; rank 0 reports its own per-GPU figures.
         try:
             extra["full_ga3c_loop"] = full_loop(BatchedCollisionAvoidanceEnv, cfg_for(N), device, W, N, rank, world_size, sync_all,
-                                                brief=not args.full_loop, steps=240 if args.full_loop else 120)
+                                                brief=not args.full_loop, steps=512 if args.full_loop else 256)
         except Exception as exc:      # noqa: BLE001  (an extra must never cost the contract line)
             extra["full_ga3c_loop"] = {"error": repr(exc)}
 
