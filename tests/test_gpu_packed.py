@@ -190,6 +190,9 @@ def _oracle_run(env, N, seed, acts, gen_min=None, nonl=0.0, **cfg_over):
     (4, 40000, None, 2, 0.3),     # beyond latency mode: MODE_STEP_AUTORESET_N, on-demand pool gather
     (10, 300, None, 2, 0.3),      # configs[3] shape (pipeline)
     (3, 200, None, 2, 0.2),
+    (4, 8192, None, 4, 0.0),      # EXACTLY BASELINE configs[1]: 4 agents x 8192 worlds (512 tiles, env_relay_kernel) -- the bench's launch
+    (10, 8192, None, 2, 0.0),     # EXACTLY BASELINE configs[3]: 10 agents x 8192 worlds, 2..10 agents per world (1366 tiles)
+    (10, 8192, None, 2, 0.3),     # ... with scripted agents in the worlds
 ])
 def test_every_step_of_a_multi_step_launch_lands_in_its_slot_and_matches_the_oracle(N, W, pipe, gen_min, nonl, monkeypatch):
     """cavoid_step_autoreset_n with out_step_stride: slot t of the [K,W,N,.] outputs holds what env.step returned AT step t
