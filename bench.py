@@ -78,14 +78,10 @@ def cpu_baseline(N: int, W: int, budget_s: float, pool_size: int):
                       % (N, W, n, dt)}
 
 
-def cpu_baseline_all_cores(N: int, W: int, budget_s: float, pool_size: int, max_procs: int = 64):
-    """the same C oracle on many host cores at once (one process per core, the worlds split
-    evenly -- how the reference scales: one env per ProcessAgent process, ProcessAgent.py:221).  Plain
-    subprocesses (`bench.py --cpu-worker ...`): nothing is forked from the process that holds the HIP context."""
+def _fan_out(cmd, procs: int, budget_s: float):
+    """`procs` plain subprocesses of `cmd` (nothing is forked from the process that holds the HIP context); each prints its rate
+    on its last line.  A straggler is dropped, never waited for beyond the budget + 90 s."""
     import subprocess
-    procs = max(1, min(max_procs, os.cpu_count() or 1))
-    per = max(1, W // procs)
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(N), str(per), str(budget_s), str(pool_size)]
     children = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
     vals = []
     deadline = time.time() + budget_s + 90.0
@@ -95,8 +91,27 @@ def cpu_baseline_all_cores(N: int, W: int, budget_s: float, pool_size: int, max_
             vals.append(float(out.strip().splitlines()[-1]))
         except Exception:      # noqa: BLE001 -- a straggler must not cost the headline
             ch.kill()
-    return {"value": float(sum(vals)), "unit": "agent-steps/s", "cores": len(vals), "kind": "port",
+    return vals
+
+
+def cpu_baseline_all_cores(N: int, W: int, budget_s: float, pool_size: int, max_procs: int = 0):
+    """the same C oracle on EVERY host core at once (one process per core -- os.cpu_count() of them -- the
+    worlds split evenly: how the reference scales, one env per ProcessAgent process, ProcessAgent.py:221)."""
+    procs = max(1, min(max_procs, os.cpu_count() or 1)) if max_procs > 0 else max(1, os.cpu_count() or 1)
+    per = max(1, W // procs)
+    vals = _fan_out([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(N), str(per), str(budget_s), str(pool_size)], procs, budget_s)
+    return {"value": float(sum(vals)), "unit": "agent-steps/s", "cores": len(vals), "host_cpus": os.cpu_count(), "kind": "port",
             "sample": "C float64 oracle, %d processes x %d worlds x %d agents, %.1f s each" % (len(vals), per, N, budget_s)}
+
+
+def python_baseline_all_cores(N: int, budget_s: float, max_procs: int = 0):
+    """the reference-STYLE Python/NumPy oracle (one world object, per-agent objects, Python pair loop) under one
+    process per host core, one world per process -- the reference's own parallelism (1 env per ProcessAgent, ProcessAgent.py:221)."""
+    procs = max(1, min(max_procs, os.cpu_count() or 1)) if max_procs > 0 else max(1, os.cpu_count() or 1)
+    vals = _fan_out([sys.executable, os.path.abspath(__file__), "--py-worker", str(N), str(budget_s)], procs, budget_s)
+    return {"value": float(sum(vals)), "unit": "agent-steps/s", "cores": len(vals), "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "oracle/cavoid_oracle.py (reference-style Python objects), %d processes x 1 world x %d agents, %.1f s each"
+                      % (len(vals), N, budget_s)}
 
 
 def python_baseline(N: int, budget_s: float):
@@ -363,6 +378,9 @@ def main() -> None:
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":        # child of cpu_baseline_all_cores: no torch, no GPU
         print(cpu_baseline(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]))["value"])
         return
+    if len(sys.argv) >= 4 and sys.argv[1] == "--py-worker":         # child of python_baseline_all_cores
+        print(python_baseline(int(sys.argv[2]), float(sys.argv[3]))["value"])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -388,6 +406,8 @@ def main() -> None:
                     help="launch / rendezvous / collective check of the N>1 path without touching a GPU (CPU boxes, gloo)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--min-agents", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--reps", type=int, default=31, help="repetitions of the K-step timed region (value = the median one; capped at ~5 s of timed work)")
+    ap.add_argument("--no-preroll", action="store_true", help="skip the synchronised pre-roll that takes the batch past its first wave of restarts")
     ap.add_argument("--overwrite-outputs", action="store_true",
                     help="round-2 form: every step of a launch overwrites ONE output slot (only the last step's outputs survive)")
     args = ap.parse_args()
@@ -515,40 +535,47 @@ def main() -> None:
     slots = None if (args.overwrite_outputs or gather_in_metric) else env.new_step_slots(min(args.slices, max(args.steps, 1)))
     sh = None
     extra = {}
+    # Synchronised PRE-ROLL (untimed, before the W warm-up steps the contract names): every world starts its first episode at step 0
+    # and no episode can end on its time budget before ~40 steps, so a short --warmup would put a timed region in which NO world
+    # restarts in front of the clock.  The pre-roll takes the batch past the first wave of restarts, so that the in-kernel
+    # auto-reset (part of env.step's job here) is inside the number whatever --warmup is.
+    preroll = 0 if args.no_preroll else max(0, 256 - args.warmup)
+    comm_status = None
     if gather_in_metric:
         try:
             # configs[2]: this rank's shard of a (world_size x W)-world env; every launch writes packed records into per-step slots
             # and their gather to every rank is begun on the communicator's stream -- launch t+1 runs while gather t is on the wire.
-            # nccl: cavoid_gather* (RCCL); gloo dry run (CPU tests / --share-device): the same records through torch.distributed.
+            # nccl: cavoid_gather* (RCCL behind the C ABI); gloo dry run (CPU tests / --share-device): the same blocks through
+            # torch.distributed (ShardedEnv picks the transport from the process group's backend).
             from rl_collision_avoidance_amd.sharding import ShardedEnv
             env.close()
             sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7)
             sh.reset()
             env = sh.env
-            native = args.backend == "nccl"
             # launches of `spl` steps: the largest divisor of K that fits the action slices, so that K steps are whole launches
             spl = max(d for d in range(1, min(args.slices, args.steps) + 1) if args.steps % d == 0)
             acts_l = acts[:spl].contiguous()
-            gslots = None if native else env.new_step_slots(spl, packed=True)
 
             def run_steps_gather(k):
                 for _ in range(-(-k // spl)):
-                    if native:
-                        sh.gathered_blocks(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))   # (waits for it; rank-major views, no copy)
-                    else:
-                        from rl_collision_avoidance_amd.sharding import gather_step_outputs
-                        env.step_autoreset_packed(acts_l, gslots)
-                        gather_step_outputs(gslots.packed.transpose(0, 1).contiguous(), world_size * W)
+                    sh.gathered_blocks(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))   # (waits for it; rank-major views, no copy)
+            run_steps(env, acts, preroll, None)
             run_steps_gather(args.warmup)
             sync_all()
             failed = None
         except Exception as exc:      # noqa: BLE001 -- a broken exchange must not cost the shard-only number: say so and time that
             failed = repr(exc)
+        # what every rank's communicator set-up (ncclCommInitRank behind cavoid_comm_create, or the gloo stand-in) came to
+        comm_status = [None] * world_size
+        try:
+            dist.all_gather_object(comm_status, "ok" if failed is None else failed)
+        except Exception as exc:      # noqa: BLE001
+            comm_status = ["status exchange failed: %r" % (exc,)]
         # every rank takes the same branch: one rank's failure sends all of them to the shard-only measurement
         flag = torch.tensor([0 if failed is None else 1], dtype=torch.int32, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
-            extra["configs2_gather"] = {"error": failed or "another rank failed",
+            extra["configs2_gather"] = {"error": failed or "another rank failed", "comm_init_per_rank": comm_status,
                                         "note": "the gather failed before the timed region: value is the SHARD-ONLY rate"}
             gather_in_metric = False
             if sh is not None:
@@ -560,28 +587,86 @@ def main() -> None:
             env, acts = make(W)
             slots = None if args.overwrite_outputs else env.new_step_slots(min(args.slices, max(args.steps, 1)))
     if not gather_in_metric:
+        run_steps(env, acts, preroll, slots)
         run_steps(env, acts, args.warmup, slots)
 
-    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks -------
-    sync_all()
-    t0 = time.perf_counter()
-    if gather_in_metric:
-        run_steps_gather(args.steps)
-    else:
-        run_steps(env, acts, args.steps, slots)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks; REPEATED, value = the median ----------
+    def episodes_started():
+        return int(env.episode.to(torch.int64).sum().item())
+
+    def timed_once():
+        sync_all()
+        t0 = time.perf_counter()
+        if gather_in_metric:
+            run_steps_gather(args.steps)
+        else:
+            run_steps(env, acts, args.steps, slots)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world_size > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    times, restarts = [], []
+    reps = max(1, args.reps)
+    r = 0
+    while r < reps:
+        before = episodes_started()
+        times.append(timed_once())
+        restarts.append(episodes_started() - before)
+        if r == 0 and reps > 3:                              # bound the whole measurement to ~5 s of timed work (same count on every rank)
+            reps = max(3, min(reps, int(5.0 / max(times[0], 1e-9)) + 1))
+            if world_size > 1:
+                t = torch.tensor([reps], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                reps = int(t.item())
+        r += 1
+    order = sorted(range(len(times)), key=lambda i: times[i])
+    mid = order[len(order) // 2]
+    elapsed = times[mid]                                     # the MEDIAN repetition (an odd count: a repetition that really ran)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world_size * W * N * args.steps / elapsed
+    timing = {"timed_reps": len(times), "ms_per_step_median": ms_per_step, "ms_per_step_min": min(times) * 1e3 / args.steps,
+              "ms_per_step_max": max(times) * 1e3 / args.steps, "ms_per_step_first_rep": times[0] * 1e3 / args.steps,
+              "restarts_in_timed_region": restarts[mid], "restarts_per_rep_min_max": [min(restarts), max(restarts)],
+              "preroll_steps": preroll,
+              "note": "each repetition = the K timed steps bracketed by barrier + synchronize; value / ms_per_step = the median repetition; "
+                      "restarts = worlds of THIS rank whose episode ended and restarted inside that repetition (in-kernel auto-reset)"}
+
+    # host launch + completion round trip of an (almost) empty kernel on this box: what a K-step region issued as ONE launch pays on
+    # top of the kernel, whatever the kernel is
+    def null_roundtrip_us():
+        x = torch.zeros(1, device=device)
+        ts = []
+        for i in range(70):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            x.add_(1.0)
+            torch.cuda.synchronize(device)
+            if i >= 20:
+                ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2] * 1e6
 
     # ---- roofline of the dominant (only) kernel ------------------------------------------------------
     if slots is None and not args.overwrite_outputs:
         slots = env.new_step_slots(min(args.slices, max(args.steps, 1)))
     roofline = kernel_figures(env, acts, N, W, args.steps, slots)
+    launches = -(-args.steps // min(args.slices, max(args.steps, 1)))
+    null_us = null_roundtrip_us()
+    wall_us, kern_us = ms_per_step * 1e3, roofline["kernel_us_per_step"]
+    roofline["wall_clock"] = {
+        "us_per_step": wall_us, "kernel_us_per_step": kern_us, "wall_over_kernel": wall_us / kern_us, "launches_per_repetition": launches,
+        "null_launch_roundtrip_us": null_us,
+        "explained_us_per_step": kern_us + null_us / args.steps,
+        "note": ("within 15 % of the kernel time" if wall_us <= 1.15 * kern_us else
+                 "the K = %d timed steps are %d launch(es) bracketed by host synchronisation: the region pays one host launch + completion "
+                 "round trip (%.1f us for an empty kernel on this box) on top of %.1f us of kernel -- %.0f %% of the gap; use --steps >= 1000 "
+                 "(back-to-back launches) for a wall clock that is the kernel's" % (
+                     args.steps, launches, null_us, kern_us * args.steps,
+                     100.0 * min(1.0, null_us / max(1e-9, (wall_us - kern_us) * args.steps)))) if not gather_in_metric else
+                "with the gather inside the timed region the wall clock is step + exchange, not the step kernel alone"}
 
     if gather_in_metric:
         # the same K steps WITHOUT the gather (every rank its own shard, per-step slots, a barrier only): what the exchange costs
@@ -594,8 +679,7 @@ def main() -> None:
             t_shard = time.perf_counter() - tg
             rec = W * N * (env.obs_width + 2) * 4
             extra["configs2_gather"] = {
-                "path": ("cavoid_gather* (RCCL over xGMI, own stream, double-buffered; %s)" % ("ncclAllGather" if spl == 1 else "point-to-point gather of K-step blocks"))
-                        if args.backend == "nccl" else "torch.distributed (gloo dry run)",
+                "path": sh.gather_form, "transport": sh.transport, "comm_init_per_rank": comm_status,
                 "steps_per_launch": spl, "bytes_sent_per_rank_per_step": rec, "bytes_received_per_rank_per_step": (world_size - 1) * rec,
                 "agent_steps_per_s_with_gather": value, "ms_per_step_with_gather": ms_per_step,
                 "agent_steps_per_s_shard_only": world_size * W * N * args.steps / t_shard, "ms_per_step_shard_only": t_shard * 1e3 / args.steps,
@@ -697,7 +781,7 @@ def main() -> None:
                    "worlds_per_gpu": W, "agents_per_world": N, "obs_width": env.obs_width, "steps_per_launch": min(args.slices, args.steps),
                    "parallelism": ("worlds sharded over %d GPU(s), one gather of (obs|reward|done) per launch (RCCL over xGMI)" % world_size)
                                   if gather_in_metric else ("worlds sharded over %d GPU(s), no data-path collective" % world_size)},
-        "roofline": roofline,
+        "roofline": roofline, "timing": timing,
     }
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(N, W, args.cpu_seconds, int(env.cfg.gen_pool_size))
@@ -707,6 +791,10 @@ def main() -> None:
             extra["cpu_baseline_all_cores"] = cpu_baseline_all_cores(N, W, min(4.0, args.cpu_seconds), int(env.cfg.gen_pool_size))
         except Exception as exc:      # noqa: BLE001
             extra["cpu_baseline_all_cores"] = {"error": repr(exc)}
+        try:
+            extra["python_reference_style_baseline_all_cores"] = python_baseline_all_cores(N, min(3.0, args.cpu_seconds))
+        except Exception as exc:      # noqa: BLE001
+            extra["python_reference_style_baseline_all_cores"] = {"error": repr(exc)}
     if extra:
         line["extra"] = extra
     if sh is not None:

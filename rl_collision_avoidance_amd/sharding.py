@@ -70,6 +70,36 @@ def gather_step_outputs(packed: torch.Tensor, total_worlds: int, group=None) -> 
     return torch.cat([recv[r, :counts[r]] for r in range(size)], dim=0)
 
 
+def gather_blocks(send: torch.Tensor, world_counts, root: int = -1, group=None):
+    """The hand-over of `cavoid_gatherv_begin` through `torch.distributed` (any backend; gloo on CPU for the tests and for dry
+    runs of the N > 1 path on one device): rank r contributes ``send`` [K, world_counts[r], N, width+2] (K steps of its shard's packed
+    records); the receivers -- every rank, or only ``root`` -- get the list of all ranks' blocks in rank order (the wire layout of the
+    native path: rank-major blocks of K steps each), the others None.  Ragged shards are padded to the largest one for the
+    collective and trimmed after."""
+    size, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [int(c) for c in world_counts]
+    if len(counts) != size or send.dim() != 4 or send.shape[1] != counts[rank]:
+        raise ValueError("send must be [K, %d worlds of this rank, N, width+2]" % (counts[rank] if len(counts) == size else -1))
+    K, _, N, rec = send.shape
+    biggest = max(counts)
+    pad = send
+    if counts[rank] != biggest:
+        pad = torch.zeros((K, biggest, N, rec), dtype=send.dtype, device=send.device)
+        pad[:, :counts[rank]] = send
+    pad = pad.contiguous()
+    if root < 0:
+        recv = torch.empty((size,) + tuple(pad.shape), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(recv.view(size * K, biggest, N, rec), pad, group=group)
+        return [recv[r, :, :counts[r]] for r in range(size)]
+    dst = dist.get_global_rank(group, root) if group is not None else root
+    if rank == root:
+        parts = [torch.empty_like(pad) for _ in range(size)]
+        dist.gather(pad, parts, dst=dst, group=group)
+        return [parts[r][:, :counts[r]] for r in range(size)]
+    dist.gather(pad, None, dst=dst, group=group)
+    return None
+
+
 class NativeGather(object):
     """The all-gather behind the C ABI: one RCCL communicator per process (one process per GPU), created from a
     128-byte id that rank 0 makes and the process group hands round (any backend: only 128 bytes travel that way)."""
@@ -144,9 +174,18 @@ class NativeGather(object):
 class ShardedEnv(object):
     """This rank's shard of a `total_worlds`-world env (one process per GPU)."""
 
-    def __init__(self, total_worlds: int, config=None, device=None, seed: int = 0, group=None, **cfg_overrides):
+    def __init__(self, total_worlds: int, config=None, device=None, seed: int = 0, group=None, transport: Optional[str] = None,
+                 **cfg_overrides):
+        """transport: "native" = `cavoid_gather*` (RCCL behind the C ABI, own stream, overlapped) -- the default whenever the process
+        group runs on nccl or there is one rank; "torch" = the same hand-over through `torch.distributed` (`gather_blocks`:
+        synchronous; gloo dry runs of the N > 1 path on one device, and the only form a gloo group can carry)."""
         from .batched_env import BatchedCollisionAvoidanceEnv
         self.group = group
+        if transport is None:
+            transport = "torch" if (dist.is_initialized() and dist.get_world_size(group) > 1 and dist.get_backend(group) != "nccl") else "native"
+        if transport not in ("native", "torch"):
+            raise ValueError("transport must be 'native' or 'torch'")
+        self.transport = transport
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.total_worlds = int(total_worlds)
@@ -180,7 +219,7 @@ class ShardedEnv(object):
         (`cavoid_gatherv_begin`)."""
         from .batched_env import StepSlots
         e = self.env
-        self._native = NativeGather(e.device, self.group)
+        self._native = NativeGather(e.device, self.group) if self.transport == "native" else False
         self._steps, self._root = int(steps), int(root)
         self._counts = [shard_range(self.total_worlds, r, self.size)[1] for r in range(self.size)]
         self._even = all(c == self._counts[0] for c in self._counts)
@@ -188,9 +227,24 @@ class ShardedEnv(object):
         receiver = root < 0 or root == self.rank
         rec = e.max_agents * e.packed_width
         # wire layout: rank-major blocks, rank r's block = [steps, count_r, N, width+2]
-        self._recv = [torch.zeros((steps * self.total_worlds * rec,), dtype=torch.float32, device=e.device) if receiver else None
-                      for _ in range(NativeGather.SLOTS)]
+        self._recv = [torch.zeros((steps * self.total_worlds * rec,), dtype=torch.float32, device=e.device) if (receiver and self._native)
+                      else None for _ in range(NativeGather.SLOTS)]
+        self._blocks = [None] * NativeGather.SLOTS          # transport "torch": the received blocks of each slot
         self._floats = [steps * c * rec for c in self._counts]
+
+    @property
+    def gather_form(self) -> str:
+        """Which exchange `step_and_gather` issues (for logs and the bench line): decided by the shard sizes and the receiver set,
+        not by the number of steps per launch."""
+        if self._native is None:
+            return "not set up"
+        if self.transport == "torch":
+            return "torch.distributed %s (%s)" % ("all_gather_into_tensor" if self._root < 0 else "gather to rank %d" % self._root,
+                                                  dist.get_backend(self.group) if dist.is_initialized() else "single rank")
+        if self._even and self._root < 0:
+            return "ncclAllGather (cavoid_gather_begin: equal shards, every rank receives; blocks of %d step(s))" % self._steps
+        return "point-to-point RCCL group (cavoid_gatherv_begin: %s shards, %s)" % (
+            "equal" if self._even else "ragged", "every rank receives" if self._root < 0 else "rank %d receives" % self._root)
 
     def step_and_gather(self, actions: torch.Tensor, root: int = -1) -> int:
         """One auto-reset step (actions [Wl,N]) -- or K steps in ONE launch (actions [K,Wl,N], every step's records in its own
@@ -204,12 +258,18 @@ class ShardedEnv(object):
             raise ValueError("step_and_gather was set up for %d step(s) per launch, root %d" % (self._steps, self._root))
         slot = self._t % NativeGather.SLOTS
         self._t += 1
-        self._native.wait(slot)                     # gather(t-2) is done with send[slot] / recv[slot]
+        if self._native:
+            self._native.wait(slot)                 # gather(t-2) is done with send[slot] / recv[slot]
         sl = self._send[slot]
         if steps == 1:
             self.env.step_autoreset_packed(actions, sl.packed[0])
         else:
             self.env.step_autoreset_packed(actions, sl)
+        if not self._native:                        # transport "torch": the same blocks through the process group, synchronously
+            send = sl.packed if dist.get_backend(self.group) == "nccl" else sl.packed.cpu()
+            blocks = gather_blocks(send, self._counts, root, self.group)
+            self._blocks[slot] = None if blocks is None else [b.to(self.env.device) for b in blocks]
+            return slot
         if self._even and root < 0:                 # equal shards to every rank: ONE ncclAllGather (rank-major blocks of K steps)
             self._native.begin(slot, sl.packed, self._recv[slot])
         else:
@@ -219,6 +279,8 @@ class ShardedEnv(object):
     def gathered_blocks(self, slot: int) -> Optional[list]:
         """The gather as it arrives: one view [K, worlds of rank r, N, width+2] per rank, in rank order (no copy); None on a rank
         that does not receive.  Valid until the slot's next use."""
+        if not self._native:
+            return self._blocks[slot]
         self._native.wait(slot)
         recv = self._recv[slot]
         if recv is None:
@@ -237,14 +299,16 @@ class ShardedEnv(object):
         if blocks is None:
             return None
         e, K = self.env, self._steps
-        if K == 1:
+        if K == 1 and self._native:
             return self._recv[slot].view(self.total_worlds, e.max_agents, e.packed_width)
+        if K == 1:
+            return torch.cat(blocks, dim=1)[0]
         # rank-major blocks -> [K, total_worlds, ...] (a view when there is one rank, else one gather-side copy per rank block)
         return blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)
 
     def close(self) -> None:
-        if self._native is not None:
+        if self._native:
             torch.cuda.synchronize(self.env.device)
             self._native.close()
-            self._native = None
+        self._native = None
         self.env.close()

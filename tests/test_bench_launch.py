@@ -28,6 +28,12 @@ def test_bench_self_launches_two_ranks_and_they_rendezvous():
     assert line == {"rendezvous": "ok", "n_gpus": 2, "backend": "gloo"}
 
 
+def test_bench_self_launches_eight_ranks_and_they_rendezvous():
+    """The driver's 8-GPU launch shape (one rank per GPU of one node), GPU-free: rendezvous, barrier, MAX over ranks."""
+    line = _run(["--gpus", "8", "--backend", "gloo", "--rendezvous-only"], 600)
+    assert line == {"rendezvous": "ok", "n_gpus": 8, "backend": "gloo"}
+
+
 def test_bench_refuses_a_mismatched_launcher_environment():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], env=env, cwd=ROOT, timeout=120,
@@ -37,7 +43,7 @@ def test_bench_refuses_a_mismatched_launcher_environment():
 
 @pytest.mark.gpu
 def test_bench_two_rank_dry_run_on_one_device():
-    line = _run(["--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "40", "--warmup", "8", "--worlds", "2048",
+    line = _run(["--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "40", "--warmup", "8", "--worlds", "2048", "--reps", "5",
                  "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc"], 900)
     assert line["n_gpus"] == 2 and line["steps"] == 40 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 2 * 2048 * 4 * 40 / (line["ms_per_step"] * 40e-3)) / line["value"] < 1e-6
@@ -50,3 +56,20 @@ def test_bench_two_rank_dry_run_on_one_device():
     r = line["roofline"]
     assert r["bound"] in ("latency", "valu-issue", "hbm") and 0 < r["frac"] < r["frac_contract"]
     assert r["one_step_launch"]["steps_per_launch"] == 1 and 0 < r["one_step_launch"]["frac"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_rank_dry_run_on_one_device():
+    """BASELINE configs[2]'s launch shape -- 8 ranks, every rank its shard of an 8 x W-world env, the gather of the packed records
+    inside the timed region -- as a dry run on ONE device over gloo (no 8-GPU node is available to the builder: this is the
+    closest execution of the N = 8 code path; RCCL itself runs first on the driver's node)."""
+    line = _run(["--gpus", "8", "--backend", "gloo", "--share-device", "--steps", "20", "--warmup", "5", "--worlds", "1024", "--reps", "3",
+                 "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc"], 1500)
+    assert line["n_gpus"] == 8 and line["steps"] == 20 and line["scaling"] == "weak" and line["value"] > 0
+    g = line["extra"]["configs2_gather"]
+    assert "error" not in g, g
+    assert g["comm_init_per_rank"] == ["ok"] * 8 and g["transport"] == "torch" and "all_gather" in g["path"]
+    assert g["bytes_received_per_rank_per_step"] == 7 * 1024 * 4 * 29 * 4 and g["steps_per_launch"] == 20
+    t = line["timing"]
+    assert t["timed_reps"] == 3 and t["ms_per_step_min"] <= t["ms_per_step_median"] <= t["ms_per_step_max"]
+    assert t["preroll_steps"] == 251 and t["restarts_in_timed_region"] > 0      # the auto-reset path is inside the timed region

@@ -123,3 +123,100 @@ def test_two_rank_data_parallel_trainer_matches_single_trainer():
         tr.train(x, y, a)
     single = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
     np.testing.assert_allclose(ret[0], single, rtol=0, atol=2e-5)
+
+
+# ---- 4 and 8 ranks: every form of the hand-over (even / ragged shards, to every rank / to one trainer rank, one step or a
+# ---- block of K steps per exchange), in the wire layout of the native path (rank-major blocks) --------------------------------
+def _blocks_worker(rank, size, cases, N, seed, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        out = {}
+        for total, K, root in cases:
+            counts = [sharding.shard_range(total, r, size)[1] for r in range(size)]
+            offset, count = sharding.shard_range(total, rank, size)
+            outs = _oracle_run(total, offset, count, N, seed, K)
+            send = torch.stack([sharding.pack_step_outputs(torch.from_numpy(o), torch.from_numpy(r), torch.from_numpy(d)) for o, r, d in outs])
+            blocks = sharding.gather_blocks(send, counts, root)
+            if root >= 0 and rank != root:
+                assert blocks is None
+                out[(total, K, root)] = None
+            else:
+                assert len(blocks) == size and all(b.shape[:2] == (K, c) for b, c in zip(blocks, counts))
+                out[(total, K, root)] = torch.cat(blocks, dim=1).numpy().copy()           # [K, total, N, width+2] in global world order
+            # the one-step all-gather of round 1 is the K = 1, root < 0 case of the same exchange
+            if K == 1 and root < 0:
+                assert np.array_equal(sharding.gather_step_outputs(send[0], total).numpy(), out[(total, K, root)][0])
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("size", [4, 8])
+def test_four_and_eight_rank_gathers_equal_unsharded(size):
+    N, seed = 4, 9
+    # (total worlds, steps per exchange, receiving rank or -1): even and ragged shards, a rank with ZERO worlds (total < size)
+    cases = [(8 * size, 1, -1), (8 * size + 3, 1, -1), (8 * size, 3, -1), (8 * size + 5, 4, -1), (8 * size, 1, 0), (8 * size + 1, 2, size - 1),
+             (size - 1, 2, -1), (size - 1, 1, 1)]
+    port = 29100 + (os.getpid() % 700) + size
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_blocks_worker, args=(size, cases, N, seed, port, ret), nprocs=size, join=True)
+    for total, K, root in cases:
+        full = _oracle_run(total, 0, total, N, seed, K)
+        want = np.stack([sharding.pack_step_outputs(torch.from_numpy(o), torch.from_numpy(r), torch.from_numpy(d)).numpy() for o, r, d in full])
+        for rank in range(size):
+            got = ret[rank][(total, K, root)]
+            if root >= 0 and rank != root:
+                assert got is None
+            else:
+                assert got.shape == want.shape and np.array_equal(got, want), (total, K, root, rank)
+
+
+def _dp_ragged_worker(rank, size, rows, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        from rl_collision_avoidance_amd.config import EnvConfig
+        from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
+        net = NetworkVP_rnn(EnvConfig(), seed=4)
+        tr = A3CTrainer(net, learning_rate=1e-3)
+        x, y, a = _dp_batch(sum(rows))
+        lo = sum(rows[:rank])
+        mine = slice(lo, lo + rows[rank])
+        for _ in range(4):
+            tr.train(x[mine], y[mine], a[mine])                 # (a rank with NO rows still joins the all-reduce and takes the step)
+        ret[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_batch(n):
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(n, 26, generator=g); x[:, 0] = torch.randint(0, 4, (n,), generator=g).float()
+    y = torch.randn(n, generator=g)
+    a = torch.nn.functional.one_hot(torch.randint(0, 11, (n,), generator=g), 11).float()
+    return x, y, a
+
+
+def test_four_rank_data_parallel_trainer_with_unequal_row_counts():
+    """Ranks drain different numbers of training rows (one of them none at all): the A3C loss is a SUM over rows, so the summed
+    gradients -- and the replicas' Adam steps -- are those of a single trainer on the concatenated batch."""
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.ga3c.network import A3CTrainer, NetworkVP_rnn
+    rows = [40, 0, 17, 7]
+    port = 29850 + (os.getpid() % 100)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_ragged_worker, args=(4, rows, port, ret), nprocs=4, join=True)
+    for r in range(1, 4):
+        assert np.array_equal(ret[0], ret[r]), r                # replicas stay in lock step, the empty-handed one too
+    net = NetworkVP_rnn(EnvConfig(), seed=4)
+    tr = A3CTrainer(net, learning_rate=1e-3, distributed=False)
+    x, y, a = _dp_batch(sum(rows))
+    for _ in range(4):
+        tr.train(x, y, a)
+    single = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    np.testing.assert_allclose(ret[0], single, rtol=0, atol=2e-5)
