@@ -479,7 +479,7 @@ def main() -> None:
     def run_steps(env, acts, k, slots=None):
         """k auto-reset steps in launches of up to T = --slices steps (step t of a launch reads acts[t] and, with `slots`,
         writes its outputs into slot t)."""
-        T = acts.shape[0]
+        T = acts.shape[0] if slots is None else min(acts.shape[0], slots.steps)
         done = 0
         while done < k:
             n = min(T, k - done)
