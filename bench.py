@@ -237,13 +237,20 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         flop = W * N * chunks * 16 * 256 * 2
         split = os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0")
         chunks32 = (1 + 3 * max(steps - 1, 0)) + 3 + 8 + 8
-        products = int(os.environ.get("CAVOID_POLICY_PRODUCTS", "3"))   # bf16 partial products per float32 product (csrc/cavoid_policy_split.hpp)
+        # csrc/cavoid_policy_split.hpp: 16 (default) = float16 pieces, two per operand, THREE partial products per float32 product
+        # (float32-grade: |dp| <= 2e-7, |dv| <= 1.4e-6 against float64); 3 / 4 / 5 = bf16 pieces, that many products
+        form = int(os.environ.get("CAVOID_POLICY_PRODUCTS", "16"))
+        products = 3 if form == 16 else form
         flop_bf16 = W * N * products * 32 * 2 * (chunks32 * 256 + 8 * 16)
         env.close()
         out = {"rows": W * N, "kernel_us": fused_us, "pytorch_graph_us": torch_us}
         if split:
             out.update({"issued_TFLOPs": flop_bf16 / fused_us * 1e-6, "peak_TFLOPs": 2500.0, "frac": flop_bf16 / fused_us * 1e-6 / 2500.0,
-                        "bound": "mfma", "dtype": "f32 in/out; bf16 split, %d partial products per float32 product, f32 accumulate" % products,
+                        "bound": "mfma", "dtype": ("f32 in/out; float16 two-piece split (22-bit operands), %d partial products per float32 product, "
+                                                   "f32 accumulate: float32-grade" if form == 16 else
+                                                   "f32 in/out; bf16 split, %d partial products per float32 product, f32 accumulate") % products,
+                        "precision_vs_float64": ("|dp| <= 1.9e-7, |dv| <= 1.4e-6 incl. x4 inputs (float32-MFMA kernel: 1.8e-7 / 8.7e-7); "
+                                                 "profiles/r04_split_f16_vs_bf16.txt") if form == 16 else "|dp| <= 3.7e-6, |dv| <= 2.5e-5 (bf16 pieces)",
                         "kernel": "cavoid::policy_forward_split_kernel"})
         else:
             out.update({"issued_TFLOPs": flop / fused_us * 1e-6, "peak_TFLOPs": 157.3, "frac": flop / fused_us * 1e-6 / 157.3,
@@ -260,7 +267,8 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         res["full_loop_fused_policy_autograd_trainer"] = regime(True, True)
         res["full_loop_torch_policy_autograd_trainer"] = regime(False, True)
     res.update({
-           "steps_per_graph": per_graph, "train_rows_per_adam_step": train_rows, "policy_dtype": "f32",
+           "steps_per_graph": per_graph, "train_rows_per_adam_step": train_rows,
+           "policy_dtype": "f32 in/out, float16 two-piece operand split on the matrix pipe, f32 accumulate (float32-grade; the actor kernel carries this form)",
            "note": "one hipGraph per %d env steps (policy + action selection + env + experience store); every drained row "
                    "is trained on once; reference PPS datum: 563 (32 procs, laptop CPU)" % per_graph})
     return res

@@ -27,6 +27,9 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     // or a non-default number of split products (the kernel carries the default form of cavoid_policy_forward, so that both stay
     // bit-identical); frozen-network agents need a second network (BatchedRollout keeps those on the step-by-step path)
     if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC || !h->use_split || h->split_products != kSpDefaultProducts) return CAVOID_EUNSUPPORTED;
+    // frozen-network agents take the action the CALLER supplies; this entry point would hand them the learner's sample
+    if (e->cfg.gen_frozen_fraction > 0.0 && e->cfg.gen_nonlearning_fraction > 0.0) return CAVOID_EUNSUPPORTED;
+    HIP_TRY(hipSetDevice(e->device));
     const KCfg &k = e->k;
     // ORCA agents / box scenarios generated inside the step: the env step's RVO instantiation (as cavoid_step_autoreset routes them)
     const bool rvo_form = e->cfg.rvo_enabled || (e->cfg.gen_mode == 1 && e->pool_size <= 0);
@@ -70,6 +73,7 @@ extern "C" int cavoid_step_push(cavoid_env *e, cavoid_rollout *r, const cavoid_r
         return CAVOID_EINVAL;
     if (r->device != e->device || r->c.num_slots != e->A || r->c.max_agents != e->cfg.max_agents || r->c.obs_width != e->k.width) return CAVOID_EINVAL;
     if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EUNSUPPORTED;       // (velocity actions: cavoid_step_continuous + cavoid_rollout_push)
+    HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     RolloutCfg rc = r->c;
     rc.dup_capacity = b->dup_capacity; rc.ep_capacity = b->ep_capacity;

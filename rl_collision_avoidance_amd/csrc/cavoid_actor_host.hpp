@@ -13,11 +13,14 @@ namespace cavoid {
 template <int N, bool RVO>
 static int launch_actor(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
                         hipStream_t s) {
-    static bool opted_in = false;                            // > 64 KiB of dynamic LDS: opted into once per instantiation
-    if (!opted_in) {
+    // > 64 KiB of dynamic LDS: opted into once per instantiation AND device (the attribute belongs to the function on the current
+    // device; a process may drive several).  The flags are only ever set, and setting the attribute twice is harmless: no lock.
+    static bool opted_in[64] = {};
+    const int dev = e->device;
+    if (dev < 0 || dev >= 64 || !opted_in[dev]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(actor_kernel<N, RVO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)policy_split_lds_bytes()));
-        opted_in = true;
+        if (dev >= 0 && dev < 64) opted_in[dev] = true;
     }
     const int64_t tiles = (e->W + e->k.wpw - 1) / e->k.wpw;
     hipLaunchKernelGGL((actor_kernel<N, RVO>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, e->k, e->st, e->pool, sa, rc, rs, rio, io);

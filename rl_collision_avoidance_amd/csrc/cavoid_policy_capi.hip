@@ -38,7 +38,8 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     h->frags = reinterpret_cast<f32x4 *>(b + o_frag); h->bias = reinterpret_cast<float *>(b + o_bias);
     h->sfrags = reinterpret_cast<uint4 *>(b + o_sfrag);
     if (const char *ov = std::getenv("CAVOID_POLICY_F32")) h->use_split = std::atoi(ov) == 0;
-    if (const char *ov = std::getenv("CAVOID_POLICY_PRODUCTS")) { const int v = std::atoi(ov); if (v >= 3 && v <= 5) h->split_products = v; }
+    // 16 (default): two float16 pieces per operand, three products -- float32-grade; 3 / 4 / 5: bf16 pieces, that many products (A/B runs)
+    if (const char *ov = std::getenv("CAVOID_POLICY_PRODUCTS")) { const int v = std::atoi(ov); if ((v >= 3 && v <= 5) || v == kSpF16) h->split_products = v; }
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
     h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
@@ -54,6 +55,8 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_split_lds_bytes()) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_split_lds_bytes()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<kSpF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_split_lds_bytes()) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP;
     }
@@ -85,9 +88,11 @@ extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights 
     hipLaunchKernelGGL(policy_pack_kernel, dim3(blocks), dim3(256), 0, s, k, h->frags, h->bias, with_backward);
     h->backward_loaded = with_backward != 0;
     HIP_TRY(hipGetLastError());
-    {   // the inference kernel's copy: every weight split into three bf16 pieces (exact), fragment order
+    {   // the inference kernel's copy, fragment order: every weight split into two float16 pieces (22 bits; the default form) or
+        // three bf16 pieces (exact; CAVOID_POLICY_PRODUCTS = 3 / 4 / 5)
         constexpr int64_t items = kSpOffHead / 3 + kSpChWide * 64;
-        hipLaunchKernelGGL(policy_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k, h->sfrags);
+        hipLaunchKernelGGL(policy_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k, h->sfrags,
+                           h->split_products == kSpF16 ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     h->normalize = w->avg != nullptr;
@@ -126,7 +131,8 @@ static int policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_
     if (h->use_split) {
         SplitArgs sa{a, h->sfrags};
         hipStream_t s = static_cast<hipStream_t>(stream);
-        if (h->split_products == 5) hipLaunchKernelGGL(policy_forward_split_kernel<5>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
+        if (h->split_products == kSpF16) hipLaunchKernelGGL(policy_forward_split_kernel<kSpF16>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
+        else if (h->split_products == 5) hipLaunchKernelGGL(policy_forward_split_kernel<5>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
         else if (h->split_products == 4) hipLaunchKernelGGL(policy_forward_split_kernel<4>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
         else hipLaunchKernelGGL(policy_forward_split_kernel<3>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
     } else {

@@ -17,8 +17,8 @@ struct cavoid_policy {
     uint64_t seed = 0;
     void *slab = nullptr;
     f32x4 *frags = nullptr;
-    uint4 *sfrags = nullptr;         // bf16-split weight fragments of the inference kernel (cavoid_policy_split.hpp)
-    int split_products = cavoid::kSpDefaultProducts;   // bf16 partial products per float32 product: 3 (default), 4 or 5 (CAVOID_POLICY_PRODUCTS)
+    uint4 *sfrags = nullptr;         // split weight fragments of the inference kernel (cavoid_policy_split.hpp)
+    int split_products = cavoid::kSpDefaultProducts;   // 16 (default): float16 pieces, three products; 3 / 4 / 5: bf16 pieces (CAVOID_POLICY_PRODUCTS)
     bool use_split = true;           // CAVOID_POLICY_F32=1: run inference on the float32-MFMA kernel instead (A/B runs)
     float *bias = nullptr, *avg = nullptr, *std = nullptr;
     int32_t *step_counter = nullptr;

@@ -35,6 +35,8 @@ namespace cavoid {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // How many of the partial products w_i * a_j are formed (largest first) is a template parameter P of the kernels.  With
@@ -50,7 +52,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // i.e. the two smallest products buy less than a factor 2 of an error that the 16-bit activation pieces set anyway, for a third
 // more matrix time: P = 3 is the default (still 6x inside the 2e-5 bar on p, 8x inside 2e-4 on v, with saturating inputs);
 // CAVOID_POLICY_PRODUCTS=5 (or 4) selects the others at cavoid_policy_create time.
-constexpr int kSpDefaultProducts = 3;
+//
+// Round 4 -- the float32-GRADE form, P = kSpF16 (the default): the SAME three products on the SAME matrix instruction rate, with
+// float16 pieces (11 significant bits each) instead of bf16 ones (8):
+//       w = w1 + w2,  a = a1 + a2   (22 bits each: |x - x1 - x2| <= 2^-23 |x|, or 2^-25 absolute once x2 is a float16 subnormal)
+//       w*a ~= w1*a1 + w1*a2 + w2*a1          dropped: w2*a2 (2^-22)  -- v_mfma_f32_16x16x32_f16 runs at the bf16 instruction's rate
+// i.e. ~2^-21 per product where the bf16 form has ~2.5 x 2^-17: the reference's predictor is TensorFlow float32
+// (ThreadPredictor.py:46,67; NetworkVPCore.py:160-176), and this is the form whose error sits at float32's own (measured against
+// the network in float64, tools/split_products_ab.py, same cases as above: see profiles/r04_split_f16_vs_bf16.txt).  float16's
+// range is the price: a piece saturates at +-65504 (inputs and relu outputs are clamped there -- one v_med3 where the bf16 form has a
+// v_max -- so that an absurd activation degrades instead of turning into NaN; LSTM states are bounded by 1), weights beyond it do
+// not occur.  No scaling is needed at the small end: a second piece that falls into float16's subnormals keeps an ABSOLUTE
+// precision of 2^-25, which is below the float32 accumulator's own rounding of a sum of O(1) terms.
+constexpr int kSpF16 = 16;                      // P: two float16 pieces per operand, three partial products
+constexpr int kSpDefaultProducts = kSpF16;
+template <int P> struct SplitFmt { static constexpr bool f16 = (P == kSpF16); static constexpr int planes = f16 ? 2 : (P >= 4 ? 3 : 2); };
+constexpr float kSpF16Max = 65504.0f;
 constexpr int kSpStrideB = 528;                 // bytes per LDS row of one plane (264 bf16)
 constexpr int kSpPlaneB = 64 * kSpStrideB;      // 33 792 B
 constexpr int kSpSlotCol = 64;                  // first input-slot column
@@ -66,22 +83,37 @@ constexpr int64_t kSpOffHead = kSpOffFc1 + kSpChWide * kSpFragPerChunk;   // one
 constexpr int64_t kSpPackFrags = kSpOffHead + kSpChWide * 3 * 64;
 constexpr size_t policy_split_lds_bytes() { return (size_t)2 * kSpPlaneB + 64 * sizeof(float) + 64 * sizeof(int) + 64; }
 
-// float -> (hi, lo) bf16 with hi = rn(x), lo = rn(x - hi); two values at a time (v_cvt_pk_bf16_f32)
+// float -> (hi, lo) 16-bit pieces with hi = rn(x), lo = rn(x - hi); two values at a time (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+template <bool F16 = false>
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &lo) {
-    const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
-    hi = __builtin_bit_cast(uint32_t, h);
-    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    if constexpr (F16) {
+        const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+        hi = __builtin_bit_cast(uint32_t, h);
+        const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];       // exact (x - rn16(x) is a float32)
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+    } else {
+        const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+        hi = __builtin_bit_cast(uint32_t, h);
+        const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    }
 }
 // float -> three bf16 pieces (exact: 3 x 8 bits cover the 24-bit significand)
 __device__ __forceinline__ void split3(float x, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
     uint32_t a, b, c;
-    split2(x, 0.0f, a, b);
+    split2<false>(x, 0.0f, a, b);
     p1 = a & 0xFFFFu; p2 = b & 0xFFFFu;
     const float r = (x - __uint_as_float(p1 << 16)) - __uint_as_float(p2 << 16);
     const bf16x2 h = __builtin_convertvector(f32x2{r, 0.0f}, bf16x2);
     c = __builtin_bit_cast(uint32_t, h);
     p3 = c & 0xFFFFu;
+}
+// float -> two float16 pieces (22 bits; the third plane stays zero and is never read)
+__device__ __forceinline__ void split3_f16(float x, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    uint32_t a, b;
+    x = __builtin_amdgcn_fmed3f(x, -kSpF16Max, kSpF16Max);
+    split2<true>(x, 0.0f, a, b);
+    p1 = a & 0xFFFFu; p2 = b & 0xFFFFu; p3 = 0u;
 }
 
 // element (k-chunk c, k-group g, element e, packed column col) of a layer, in cavoid_policy.hpp's policy_weight() terms
@@ -95,7 +127,7 @@ __device__ __forceinline__ float split_weight(const PolicyWeights &w, int layer,
 }
 
 #ifdef CAVOID_POLICY_KERNELS     /* the non-template kernels are compiled by cavoid_policy_capi.hip only */
-__global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags) {
+__global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags, const int f16) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one (layer, chunk, column tile, lane): all 3 planes
     constexpr int64_t kWide = kSpOffHead / 3, kAll = kWide + kSpChWide * 64;
     if (f >= kAll) return;
@@ -120,8 +152,13 @@ __global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeig
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         uint32_t a1, a2, a3, b1, b2, b3;
-        split3(split_weight(w, layer, c, g, e, col), a1, a2, a3);
-        split3(split_weight(w, layer, c, g, e + 1, col), b1, b2, b3);
+        if (f16) {
+            split3_f16(split_weight(w, layer, c, g, e, col), a1, a2, a3);
+            split3_f16(split_weight(w, layer, c, g, e + 1, col), b1, b2, b3);
+        } else {
+            split3(split_weight(w, layer, c, g, e, col), a1, a2, a3);
+            split3(split_weight(w, layer, c, g, e + 1, col), b1, b2, b3);
+        }
         pl[0][e >> 1] = a1 | (b1 << 16); pl[1][e >> 1] = a2 | (b2 << 16); pl[2][e >> 1] = a3 | (b3 << 16);
     }
     const int64_t plane_stride = layer == 4 ? 64 : 16 * 64;
@@ -133,8 +170,10 @@ __global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeig
 
 struct SplitW { uint4 w[3][4]; };                            // weight fragments of one chunk: plane x column tile
 
+template <bool F16 = false>
 __device__ __forceinline__ f32x4 mfma_bf16(const uint4 &a, const uint4 &b, const f32x4 &c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ void split_load_w1(uint4 (&w)[4], const uint4 *layer, int plane, int wave, int lane, int c) {
@@ -145,7 +184,7 @@ __device__ __forceinline__ void split_load_w1(uint4 (&w)[4], const uint4 *layer,
 template <int P>
 __device__ __forceinline__ void split_load_w(SplitW &f, const uint4 *layer, int wave, int lane, int c) {
 #pragma unroll
-    for (int pl = 0; pl < (P >= 4 ? 3 : 2); ++pl) split_load_w1(f.w[pl], layer, pl, wave, lane, c);
+    for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) split_load_w1(f.w[pl], layer, pl, wave, lane, c);
 }
 
 // activation fragments (ONE plane) of the k-range starting at LDS column `col` (32 wide); `slot`: the input chunk --
@@ -162,11 +201,12 @@ __device__ __forceinline__ void split_load_a(uint4 (&a)[4], const unsigned char 
 }
 
 // one partial product for all 16 (column tile, row tile) pairs: consecutive MFMAs never share an accumulator
+template <bool F16 = false>
 __device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4 (&a)[4], f32x4 (&acc)[4][4]) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16(w[mt], a[nt], acc[mt][nt]);
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w[mt], a[nt], acc[mt][nt]);
 }
 
 // acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
@@ -200,6 +240,7 @@ __device__ __forceinline__ void split_load_bias(f32x4 (&b4)[4], const float *bia
 // The accumulators are not initialised: the very first product takes the layer's bias (this lane's four columns per column
 // tile, 16 registers: b4) as its C operand -- 64 register moves per GEMM less than broadcasting the bias into acc first.  b4 is
 // loaded one GEMM ahead, like the first weight fragments: the last chunk requests `next_bias` into it.
+template <bool F16>
 __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
                                             int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
                                             f32x4 (&b4)[4], const float *next_bias) {
@@ -222,18 +263,18 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16(w.w[0][mt], a_lo[nt], b4[mt]);
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w.w[0][mt], a_lo[nt], b4[mt]);
                 first = false;
             } else {
-                split_mfma_term(w.w[0], a_lo, acc);
+                split_mfma_term<F16>(w.w[0], a_lo, acc);
             }
             if (last) split_load_bias(b4, next_bias, wave, lane);   // (b4 was consumed by the first product: free since then)
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
-            split_mfma_term(w.w[1], a_hi, acc);
+            split_mfma_term<F16>(w.w[1], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[1], wl, 1, wave, lane, wc);
-            split_mfma_term(w.w[0], a_hi, acc);
+            split_mfma_term<F16>(w.w[0], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
             if (last) { split_load_w1(w.w[0], next_layer, 0, wave, lane, next_c); break; }
@@ -246,14 +287,14 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
             const int wc = last ? next_c : n;
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[0], wl, 0, wave, lane, wc);
-            split_mfma_term(w.w[2], a_lo, acc);
+            split_mfma_term<F16>(w.w[2], a_lo, acc);
             if (last) split_load_bias(b4, next_bias, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
-            split_mfma_term(w.w[1], a_hi, acc);
+            split_mfma_term<F16>(w.w[1], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[1], wl, 1, wave, lane, wc);
-            split_mfma_term(w.w[2], a_hi, acc);
+            split_mfma_term<F16>(w.w[2], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
             if (last) break;
@@ -267,8 +308,8 @@ template <int P>
 __device__ __forceinline__ void split_gemm(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
                                            const float *bias, f32x4 (&b4)[4], const float *next_bias) {
-    if constexpr (P == 3) {
-        split_gemm3(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, b4, next_bias);
+    if constexpr (P == 3 || P == kSpF16) {
+        split_gemm3<P == kSpF16>(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, b4, next_bias);
         return;
     }
     split_init_acc(bias, wave, lane, acc);
@@ -304,15 +345,17 @@ __device__ __forceinline__ void split_gemm(const unsigned char *planes, const ui
 }
 
 // four consecutive columns of one row -> both planes, 8 bytes each
+template <bool F16 = false>
 __device__ __forceinline__ void split_store4(unsigned char *planes, int row, int col, const f32x4 &z) {
     uint32_t h0, l0, h1, l1;
-    split2(z[0], z[1], h0, l0);
-    split2(z[2], z[3], h1, l1);
+    split2<F16>(z[0], z[1], h0, l0);
+    split2<F16>(z[2], z[3], h1, l1);
     unsigned char *p = planes + row * kSpStrideB + col * 2;
     *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
     *reinterpret_cast<uint2 *>(p + kSpPlaneB) = uint2{l0, l1};
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave, int lane, const f32x4 (&acc)[4][4]) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -323,9 +366,10 @@ __device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave
             for (int r = 0; r < 4; ++r) {                  // relu as ONE integer max on the bit pattern (negative floats are negative
                 const float v = acc[mt][nt][r];            // integers; fmaxf costs a canonicalising max more).  (Through a scalar:
                 const int bits = __float_as_int(v);        // __builtin_bit_cast straight on the vector element reads element 0.)
-                z[r] = __int_as_float(bits > 0 ? bits : 0);
+                if constexpr (F16) z[r] = __builtin_amdgcn_fmed3f(v, 0.0f, kSpF16Max);   // relu, saturating at float16's largest value
+                else z[r] = __int_as_float(bits > 0 ? bits : 0);
             }
-            split_store4(planes, 16 * nt + (lane & 15), 16 * (4 * wave + mt) + 4 * (lane >> 4), z);
+            split_store4<F16>(planes, 16 * nt + (lane & 15), 16 * (4 * wave + mt) + 4 * (lane >> 4), z);
         }
 }
 
@@ -378,6 +422,7 @@ template <int P, class Load, class Emit>
 __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned char *planes, float *len_f, int *wave_max, int rows_here,
                                                   int tid, Load load, Emit emit) {
     const PolicyArgs &p = sa.p;
+    constexpr bool F16 = SplitFmt<P>::f16;
     const int wave = tid >> 6, lane = tid & 63, g = lane >> 4;
     const int M = p.max_other, A = p.num_actions;
     const uint4 *w_lstm = sa.sfrags + kSpOffLstm;
@@ -420,9 +465,13 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (row_ok && e < n_in) ? v[e] : 0.0f;
+            if constexpr (F16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -kSpF16Max, kSpF16Max);
+            }
             uint32_t hi[4], lo[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+            for (int e = 0; e < 4; ++e) split2<F16>(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
             unsigned char *d = planes + r * kSpStrideB + (kSpSlotCol + 8 * s) * 2;
             *reinterpret_cast<uint4 *>(d) = uint4{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<uint4 *>(d + kSpPlaneB) = uint4{lo[0], lo[1], lo[2], lo[3]};
@@ -466,7 +515,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
                 h_new[r] = go * fast_tanh(c_new);
                 cell[nt][r] = live ? c_new : cell[nt][r];
             }
-            if (live) split_store4(planes, 16 * nt + (lane & 15), 16 * wave + 4 * g, h_new);   // (else h stays as it is)
+            if (live) split_store4<F16>(planes, 16 * nt + (lane & 15), 16 * wave + 4 * g, h_new);   // (else h stays as it is)
         }
         if (t == 1) POLICY_STAMP(11);
         __syncthreads();                                   // the new h is in place
@@ -483,7 +532,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, sa.sfrags + kSpOffL2, 0, p.bias + kBiasL1, b4,
                       p.bias + kBiasL2);
         __syncthreads();
-        split_store_relu(planes, wave, lane, acc);
+        split_store_relu<F16>(planes, wave, lane, acc);
         __syncthreads();
     }
     POLICY_STAMP(2);
@@ -493,7 +542,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, 0, p.bias + kBiasL2, b4,
                       p.bias + kBiasFc1);
         __syncthreads();
-        split_store_relu(planes, wave, lane, acc);
+        split_store_relu<F16>(planes, wave, lane, acc);
         __syncthreads();
     }
     uint4 hw[kSpChWide][3];                                // the heads' weight fragments: half in flight across the epilogue
@@ -505,9 +554,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
 #pragma unroll
         for (int c = 0; c < kSpChWide / 2; ++c)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
+            for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
         __syncthreads();
-        split_store_relu(planes, wave, lane, acc);
+        split_store_relu<F16>(planes, wave, lane, acc);
         __syncthreads();
     }
     POLICY_STAMP(3);
@@ -516,7 +565,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
 #pragma unroll
         for (int c = kSpChWide / 2; c < kSpChWide; ++c)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
+            for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
         f32x4 acc[5];
         acc[0] = *reinterpret_cast<const f32x4 *>(p.bias + kBiasHead + 4 * g);
         acc[1] = acc[2] = acc[3] = acc[4] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -524,11 +573,11 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
 #pragma unroll
         for (int c = 0; c < kSpChWide; ++c) {
             const uint4 a1 = *reinterpret_cast<const uint4 *>(arow + c * 64), a2 = *reinterpret_cast<const uint4 *>(arow + kSpPlaneB + c * 64);
-            if (P >= 4) acc[4] = mfma_bf16(hw[c][2], a1, acc[4]);
-            if (P >= 5) acc[3] = mfma_bf16(hw[c][1], a2, acc[3]);
-            acc[2] = mfma_bf16(hw[c][1], a1, acc[2]);
-            acc[1] = mfma_bf16(hw[c][0], a2, acc[1]);
-            acc[0] = mfma_bf16(hw[c][0], a1, acc[0]);
+            if (P == 4 || P == 5) acc[4] = mfma_bf16(hw[c][2], a1, acc[4]);
+            if (P == 5) acc[3] = mfma_bf16(hw[c][1], a2, acc[3]);
+            acc[2] = mfma_bf16<F16>(hw[c][1], a1, acc[2]);
+            acc[1] = mfma_bf16<F16>(hw[c][0], a2, acc[1]);
+            acc[0] = mfma_bf16<F16>(hw[c][0], a1, acc[0]);
         }
         const f32x4 logit = (acc[4] + acc[3]) + (acc[2] + acc[1]) + acc[0];
         // lane: row 16w + l%16, columns 4g + r.  Reductions over a row's 16 columns = over r in the lane and over the

@@ -389,16 +389,19 @@ def test_evaluate_reports_consistent_outcome_rates():
     env.close()
 
 
-@pytest.mark.parametrize("kernel", ["split", "split4", "split5", "f32"])
+@pytest.mark.parametrize("kernel", ["f16", "split3", "split4", "split5", "f32"])
 def test_both_inference_kernels_against_a_float64_yardstick(kernel, monkeypatch):
-    """The inference kernel computes its float32 GEMMs by error-free bf16 splitting (weights in three bf16 pieces, activations in
-    two; the 3 largest partial products by default, 4 or 5 with CAVOID_POLICY_PRODUCTS; float32 accumulate); CAVOID_POLICY_F32=1
-    selects the float32-MFMA kernel.  All are held to a quarter of the bar against the SAME network evaluated in float64 (the
-    float32 PyTorch graph's own error against float64 is printed beside it), also with large inputs (scale 4: saturating gates)."""
+    """The inference kernel computes its float32 GEMMs by operand splitting on the 16-bit matrix pipe, float32 accumulate.  Default
+    (round 4): float16 pieces -- weights and activations in two pieces each (22 bits), three partial products: a float32-GRADE form,
+    held to the bar a float32 predictor is held to (|dp| <= 1e-6, |dv| <= 5e-6 against the SAME network evaluated in float64 -- the
+    reference's predictor is TensorFlow float32, ThreadPredictor.py:46,67), also with large inputs (scale 4: saturating gates).
+    CAVOID_POLICY_PRODUCTS = 3 / 4 / 5: bf16 pieces (round 3's forms; their 16-bit activation pieces set an error of ~2^-17 per
+    product: a quarter of the 2e-5 / 2e-4 bar); CAVOID_POLICY_F32 = 1: the float32-MFMA kernel."""
     import copy
     from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
     monkeypatch.setenv("CAVOID_POLICY_F32", "1" if kernel == "f32" else "0")
-    monkeypatch.setenv("CAVOID_POLICY_PRODUCTS", {"split4": "4", "split5": "5"}.get(kernel, "3"))
+    monkeypatch.setenv("CAVOID_POLICY_PRODUCTS", {"split3": "3", "split4": "4", "split5": "5"}.get(kernel, "16"))
+    f32_grade = kernel in ("f16", "f32")
     for M, B, scale in ((3, 4096, 1.0), (9, 2048, 1.0), (3, 4096, 4.0)):
         net = _net(M, seed=40 + M)
         pol = FusedPolicy(net)
@@ -411,10 +414,36 @@ def test_both_inference_kernels_against_a_float64_yardstick(kernel, monkeypatch)
         e_kernel_p, e_torch_p = (p.double() - p64).abs().max().item(), (p32.double() - p64).abs().max().item()
         e_kernel_v, e_torch_v = (v.double() - v64).abs().max().item(), (v32.double() - v64).abs().max().item()
         assert e_kernel_p <= P_TOL and e_kernel_v <= V_TOL * (1.0 + v64.abs().max().item()), (kernel, M, scale, e_kernel_p, e_kernel_v)
-        # the activation pieces carry 16 significant bits, so the split kernels' error sits above float32 rounding
-        # (measured at scale 4: p 3.4e-6 / 2.8e-6 / 2.1e-6 with 3 / 4 / 5 products against 1e-7 for the float32 graph) -- and a
-        # factor >= 4 inside the bar
-        assert e_kernel_p <= P_TOL / 4 and e_kernel_v <= V_TOL / 4 * (1.0 + v64.abs().max().item()), \
-            (kernel, M, scale, e_kernel_p, e_torch_p, e_kernel_v, e_torch_v)
+        if f32_grade:
+            # float32 grade: the bar of the round-3 verdict (measured: f16 4.4e-8 / 3.7e-7, x4 inputs 1.9e-7 / 1.4e-6; the float32-MFMA
+            # kernel 3.9e-8 / 2.2e-7, x4 1.8e-7 / 8.7e-7; profiles/r04_split_f16_vs_bf16.txt) ...
+            assert e_kernel_p <= 1e-6 and e_kernel_v <= 5e-6, (kernel, M, scale, e_kernel_p, e_torch_p, e_kernel_v, e_torch_v)
+            # ... and within a small factor of what the float32 PyTorch graph itself differs from float64 by
+            assert e_kernel_p <= 6.0 * e_torch_p + 5e-8 and e_kernel_v <= 6.0 * e_torch_v + 5e-7, (kernel, M, scale, e_kernel_p, e_torch_p, e_kernel_v, e_torch_v)
+        else:
+            # the bf16 activation pieces carry 16 significant bits, so these forms sit above float32 rounding (measured at scale 4:
+            # p 3.4e-6 / 2.8e-6 / 2.1e-6 with 3 / 4 / 5 products against 1e-7 for the float32 graph) -- a factor >= 4 inside the bar
+            assert e_kernel_p <= P_TOL / 4 and e_kernel_v <= V_TOL / 4 * (1.0 + v64.abs().max().item()), \
+                (kernel, M, scale, e_kernel_p, e_torch_p, e_kernel_v, e_torch_v)
         print("policy kernel %s M=%d scale=%g: |dp| %.2e (torch f32 %.2e)  |dv| %.2e (torch f32 %.2e)"
               % (kernel, M, scale, e_kernel_p, e_torch_p, e_kernel_v, e_torch_v))
+
+
+def test_float16_pieces_saturate_instead_of_overflowing():
+    """float16's range is the price of the float32-grade split: a piece saturates at +-65504 (inputs and relu outputs are clamped
+    there) -- an absurd input must degrade, never turn into inf / NaN; and up to that range the kernel stays on the float32 graph."""
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(3, seed=3)
+    pol = FusedPolicy(net)
+    x = _inputs(net, 512, seed=1)
+    big = x.clone()
+    big[:, 1:] *= 1e7                                        # far beyond float16
+    p, v = pol(big)
+    assert torch.isfinite(p).all() and torch.isfinite(v).all()
+    assert (p.sum(dim=1) - 1.0).abs().max().item() <= 1e-5 and (p >= 0).all()
+    mid = x.clone()
+    mid[:, 1:] *= 300.0                                      # large but representable: |x| up to a few thousand
+    p, v = pol(mid)
+    with torch.no_grad():
+        _, p_ref, v_ref = net.forward(mid)
+    assert (p - p_ref).abs().max().item() <= P_TOL and ((v - v_ref).abs() <= V_TOL + V_TOL * v_ref.abs()).all()
