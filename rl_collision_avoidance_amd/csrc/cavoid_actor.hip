@@ -45,7 +45,7 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     a.frags = h->frags; a.bias = h->bias; a.min_policy = h->min_policy;
     a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
     a.step_counter = h->step_counter; a.blocks_done = h->blocks_done; a.cu_tickets = h->cu_tickets;
-    const SplitArgs sa{a, h->sfrags};
+    const SplitArgs sa{a, h->sfrags, h->sbias};
     RolloutCfg rc = r->c;
     rc.dup_capacity = b->dup_capacity; rc.ep_capacity = b->ep_capacity;
     RolloutIO rio{};

@@ -29,14 +29,14 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_frag = carve((size_t)kPackFragsTrain * sizeof(f32x4)), o_bias = carve(kBiasFloats * sizeof(float));
-    const size_t o_sfrag = carve((size_t)kSpPackFrags * sizeof(uint4));
+    const size_t o_sfrag = carve((size_t)kSpPackFrags * sizeof(uint4)), o_sbias = carve(kBiasFloats * sizeof(float));
     const size_t o_avg = carve(h->in_size * sizeof(float)), o_std = carve(h->in_size * sizeof(float));
     const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t)), o_tick = carve(kPolCuSlots * sizeof(uint32_t));
     if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return CAVOID_ENOMEM; }
     if (hipMemset(h->slab, 0, off) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP; }
     unsigned char *b = static_cast<unsigned char *>(h->slab);
     h->frags = reinterpret_cast<f32x4 *>(b + o_frag); h->bias = reinterpret_cast<float *>(b + o_bias);
-    h->sfrags = reinterpret_cast<uint4 *>(b + o_sfrag);
+    h->sfrags = reinterpret_cast<uint4 *>(b + o_sfrag); h->sbias = reinterpret_cast<float *>(b + o_sbias);
     if (const char *ov = std::getenv("CAVOID_POLICY_F32")) h->use_split = std::atoi(ov) == 0;
     // 16 (default): two float16 pieces per operand, three products -- float32-grade; 3 / 4 / 5: bf16 pieces, that many products (A/B runs)
     if (const char *ov = std::getenv("CAVOID_POLICY_PRODUCTS")) { const int v = std::atoi(ov); if ((v >= 3 && v <= 5) || v == kSpF16) h->split_products = v; }
@@ -91,7 +91,7 @@ extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights 
     {   // the inference kernel's copy, fragment order: every weight split into two float16 pieces (22 bits; the default form) or
         // three bf16 pieces (exact; CAVOID_POLICY_PRODUCTS = 3 / 4 / 5)
         constexpr int64_t items = kSpOffHead / 3 + kSpChWide * 64;
-        hipLaunchKernelGGL(policy_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k, h->sfrags,
+        hipLaunchKernelGGL(policy_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k, h->sfrags, h->sbias,
                            h->split_products == kSpF16 ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
@@ -129,7 +129,7 @@ static int policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_
     const int64_t blocks = (rows + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return CAVOID_EINVAL;
     if (h->use_split) {
-        SplitArgs sa{a, h->sfrags};
+        SplitArgs sa{a, h->sfrags, h->sbias};
         hipStream_t s = static_cast<hipStream_t>(stream);
         if (h->split_products == kSpF16) hipLaunchKernelGGL(policy_forward_split_kernel<kSpF16>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
         else if (h->split_products == 5) hipLaunchKernelGGL(policy_forward_split_kernel<5>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);

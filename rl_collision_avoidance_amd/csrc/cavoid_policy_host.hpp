@@ -18,6 +18,7 @@ struct cavoid_policy {
     void *slab = nullptr;
     f32x4 *frags = nullptr;
     uint4 *sfrags = nullptr;         // split weight fragments of the inference kernel (cavoid_policy_split.hpp)
+    float *sbias = nullptr;          // ... and its biases (packed order; the LSTM gates pre-scaled by log2 e / 2 log2 e like their weight columns)
     int split_products = cavoid::kSpDefaultProducts;   // 16 (default): float16 pieces, three products; 3 / 4 / 5: bf16 pieces (CAVOID_POLICY_PRODUCTS)
     bool use_split = true;           // CAVOID_POLICY_F32=1: run inference on the float32-MFMA kernel instead (A/B runs)
     float *bias = nullptr, *avg = nullptr, *std = nullptr;

@@ -71,7 +71,9 @@ constexpr float kSpF16Max = 65504.0f;
 constexpr int kSpStrideB = 528;                 // bytes per LDS row of one plane (264 bf16)
 constexpr int kSpPlaneB = 64 * kSpStrideB;      // 33 792 B
 constexpr int kSpSlotCol = 64;                  // first input-slot column
-constexpr int kSpMaxOthers = 23;                // slots 0..M must fit columns 64..263
+constexpr int kSpZeroCol = 256;                 // columns 256..263 of every row (both planes) hold zeros for the whole pass: what the k-groups
+                                                // 1..3 of an input-slot chunk read (a plain address select instead of 32 predicated moves)
+constexpr int kSpMaxOthers = 23;                // slots 0..M must fit columns 64..255
 // chunk counts (K = 32 each)
 constexpr int kSpChLstm = 3, kSpChL1 = 3, kSpChWide = 8;
 constexpr int64_t kSpFragPerChunk = 3 * 16 * 64;          // planes x column tiles x lanes
@@ -89,7 +91,11 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_
     if constexpr (F16) {
         const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
         hi = __builtin_bit_cast(uint32_t, h);
-        const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];       // exact (x - rn16(x) is a float32)
+        // x - rn16(x), exact in float32, as an fma on the float16 piece itself: v_fma_mix_f32 converts in the operand read (one
+        // instruction per value instead of v_cvt_f32_f16 + half a v_pk_add_f32; the compiler does not form it from a subtraction)
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
         lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, f16x2));
     } else {
         const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
@@ -117,19 +123,40 @@ __device__ __forceinline__ void split3_f16(float x, uint32_t &p1, uint32_t &p2, 
 }
 
 // element (k-chunk c, k-group g, element e, packed column col) of a layer, in cavoid_policy.hpp's policy_weight() terms
+// The LSTM gate pre-activations leave the GEMM already multiplied by what the cell update's 2^x needs: the i, f, o columns (and
+// biases) carry log2 e, the j column 2 log2 e -- sigmoid(x) = 1 / (1 + 2^-(x log2 e)), tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)) -- folded
+// into the packed weights at load time (one float32 rounding of each weight, 2^-24: below the split's own 2^-22).
+constexpr float kSpLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float split_gate_scale(int packed_col) { return ((packed_col >> 4) & 3) == 1 ? 2.0f * kSpLog2e : kSpLog2e; }
 __device__ __forceinline__ float split_weight(const PolicyWeights &w, int layer, int c, int g, int e, int col) {
     if (layer <= 1) {                                       // LSTM / layer1: two chunks of hidden state, then the input slot
-        if (c < 2) return policy_weight(w, layer, 32 * c + 8 * g + e, col);
+        const float scale = layer == 0 ? split_gate_scale(col) : 1.0f;
+        if (c < 2) return scale * policy_weight(w, layer, 32 * c + 8 * g + e, col);
         const int n_in = layer == 0 ? kPolOther : kPolHost;
-        return (g == 0 && e < n_in) ? policy_weight(w, layer, kPolHidden + e, col) : 0.0f;
+        return (g == 0 && e < n_in) ? scale * policy_weight(w, layer, kPolHidden + e, col) : 0.0f;
     }
     return policy_weight(w, layer, 32 * c + 8 * g + e, col);
 }
 
 #ifdef CAVOID_POLICY_KERNELS     /* the non-template kernels are compiled by cavoid_policy_capi.hip only */
-__global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags, const int f16) {
+__global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags, float *sbias, const int f16) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one (layer, chunk, column tile, lane): all 3 planes
     constexpr int64_t kWide = kSpOffHead / 3, kAll = kWide + kSpChWide * 64;
+    if (f < kBiasFloats) {                                                 // the biases in packed column order (as policy_pack_kernel), LSTM gates scaled
+        const int i = (int)f;
+        float b;
+        if (i < kBiasL1) {
+            const int wave = i >> 6, gate = (i >> 4) & 3, u = i & 15;
+            b = split_gate_scale(i) * (w.lstm_bias[gate * kPolHidden + 16 * wave + u] + (gate == 2 ? w.forget_bias : 0.0f));
+        } else if (i < kBiasL2) b = w.layer1_bias[i - kBiasL1];
+        else if (i < kBiasFc1) b = w.layer2_bias[i - kBiasL2];
+        else if (i < kBiasHead) b = w.fc1_bias[i - kBiasFc1];
+        else {
+            const int c = i - kBiasHead;
+            b = c < w.num_actions ? w.p_bias[c] : (c == w.num_actions ? w.v_bias[0] : 0.0f);
+        }
+        sbias[i] = b;
+    }
     if (f >= kAll) return;
     int layer, c, mt, lane;
     int64_t base;                                                          // frag index of plane 0
@@ -176,28 +203,38 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4 &a, const uint4 &b, const
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void split_load_w1(uint4 (&w)[4], const uint4 *layer, int plane, int wave, int lane, int c) {
-    const uint4 *p = layer + (int64_t)c * kSpFragPerChunk + (int64_t)plane * 16 * 64 + (int64_t)(4 * wave) * 64 + lane;
+// Weight fragments and biases are read through BUFFER loads: resource descriptor + a scalar offset (layer, chunk, plane, wave: all
+// uniform) + the lane's constant 32-bit offset -- no vector address arithmetic at all (the flat form spent ~170 64-bit vector adds per
+// tile on addresses).  Offsets are in fragments (16 bytes) / floats.
+struct SplitSrc { __amdgpu_buffer_rsrc_t w, b; };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ SplitSrc split_src(const uint4 *sfrags, const float *bias) {
+    return SplitSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(sfrags), 0, (int)(kSpPackFrags * 16), 0x00020000),
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias), 0, (int)(kBiasFloats * sizeof(float)), 0x00020000)};
+}
+__device__ __forceinline__ uint4 split_buf16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return uint4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void split_load_w1(uint4 (&w)[4], const SplitSrc &src, int layer, int plane, int wave, int lane, int c) {
+    const int soff = (layer + c * (int)kSpFragPerChunk + plane * 16 * 64 + (4 * wave) * 64) * 16;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) w[mt] = p[mt * 64];
+    for (int mt = 0; mt < 4; ++mt) w[mt] = split_buf16(src.w, lane * 16, soff + mt * 1024);
 }
 template <int P>
-__device__ __forceinline__ void split_load_w(SplitW &f, const uint4 *layer, int wave, int lane, int c) {
+__device__ __forceinline__ void split_load_w(SplitW &f, const SplitSrc &src, int layer, int wave, int lane, int c) {
 #pragma unroll
-    for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) split_load_w1(f.w[pl], layer, pl, wave, lane, c);
+    for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) split_load_w1(f.w[pl], src, layer, pl, wave, lane, c);
 }
 
 // activation fragments (ONE plane) of the k-range starting at LDS column `col` (32 wide); `slot`: the input chunk --
 // only k-group 0 holds data (one 8-value slot at column `col`), the other groups supply zeros
 __device__ __forceinline__ void split_load_a(uint4 (&a)[4], const unsigned char *planes, int plane, int lane, int col, bool slot) {
     const int g = lane >> 4;
-    const unsigned char *p = planes + plane * kSpPlaneB + (lane & 15) * kSpStrideB + (col + (slot ? 0 : 8 * g)) * 2;
+    const int c = slot ? (g == 0 ? col : kSpZeroCol) : col + 8 * g;
+    const unsigned char *p = planes + plane * kSpPlaneB + (lane & 15) * kSpStrideB + c * 2;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        uint4 v = uint4{0u, 0u, 0u, 0u};
-        if (!slot || g == 0) v = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
-        a[nt] = v;
-    }
+    for (int nt = 0; nt < 4; ++nt) a[nt] = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
 }
 
 // one partial product for all 16 (column tile, row tile) pairs: consecutive MFMAs never share an accumulator
@@ -209,16 +246,6 @@ __device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w[mt], a[nt], acc[mt][nt]);
 }
 
-// acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
-__device__ __forceinline__ void split_init_acc(const float *bias, int wave, int lane, f32x4 (&acc)[4][4]) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = b;
-    }
-}
-
 // acc += W(chunks c0..c1-1 of `layer`) x act.  Chunk c reads LDS columns 32c.., except `slot_chunk`, which reads the
 // 8-wide input slot at column `slot_col`.  w must already hold chunk c0's weights (issued before the barrier that
 // publishes the activations).  ONE set of weight registers and ONE set of activation registers: every fragment group is
@@ -227,10 +254,13 @@ __device__ __forceinline__ void split_init_acc(const float *bias, int wave, int 
 //     w1*a_lo   w1*a_hi   [w1 <- next]   w2*a_lo   [a_lo <- next]   w2*a_hi   [w2 <- next]   w3*a_hi   [w3, a_hi <- next]
 // 144 live registers (64 accumulators, 48 weight, 32 activation) instead of 240 for a double-buffered pipeline.
 //
-// this lane's four bias values per column tile (columns 16*(4*wave+mt) + 4*(lane/16) + r)
-__device__ __forceinline__ void split_load_bias(f32x4 (&b4)[4], const float *bias, int wave, int lane) {
+// this lane's four bias values per column tile (columns 16*(4*wave+mt) + 4*(lane/16) + r); `bias` = the layer's first float
+__device__ __forceinline__ void split_load_bias(f32x4 (&b4)[4], const SplitSrc &src, int bias, int wave, int lane) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) b4[mt] = *reinterpret_cast<const f32x4 *>(bias + 16 * (4 * wave + mt) + 4 * (lane >> 4));
+    for (int mt = 0; mt < 4; ++mt) {
+        const uint4 v = split_buf16(src.b, (lane >> 4) * 16, (bias + 64 * wave + 16 * mt) * 4);
+        b4[mt] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
 }
 
 // P = 3 reads only two weight planes, so the third register group double-buffers plane 1 (the plane both of whose products come
@@ -241,9 +271,9 @@ __device__ __forceinline__ void split_load_bias(f32x4 (&b4)[4], const float *bia
 // tile, 16 registers: b4) as its C operand -- 64 register moves per GEMM less than broadcasting the bias into acc first.  b4 is
 // loaded one GEMM ahead, like the first weight fragments: the last chunk requests `next_bias` into it.
 template <bool F16>
-__device__ __forceinline__ void split_gemm3(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
-                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
-                                            f32x4 (&b4)[4], const float *next_bias) {
+__device__ __forceinline__ void split_gemm3(const unsigned char *planes, const SplitSrc &src, int layer, int c0, int c1, int slot_chunk, int slot_col,
+                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], int next_layer, int next_c,
+                                            f32x4 (&b4)[4], int next_bias) {
     uint4 a_hi[4], a_lo[4];
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
     split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
@@ -255,10 +285,10 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
         {                                                  // chunk c with w1 in w.w[0]; w.w[2] is idle
             const bool last = c + 1 >= c1;
             const int n = last ? c : c + 1;
-            const uint4 *wl = last ? next_layer : layer;
+            const int wl = last ? next_layer : layer;
             const int wc = last ? next_c : n;
             __builtin_amdgcn_sched_barrier(0);
-            if (!last) split_load_w1(w.w[2], layer, 0, wave, lane, n);
+            if (!last) split_load_w1(w.w[2], src, layer, 0, wave, lane, n);
             if (first) {                                   // (uniform) acc = bias + w1 * a_lo
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -268,32 +298,32 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
             } else {
                 split_mfma_term<F16>(w.w[0], a_lo, acc);
             }
-            if (last) split_load_bias(b4, next_bias, wave, lane);   // (b4 was consumed by the first product: free since then)
+            if (last) split_load_bias(b4, src, next_bias, wave, lane);   // (b4 was consumed by the first product: free since then)
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
             split_mfma_term<F16>(w.w[1], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
-            split_load_w1(w.w[1], wl, 1, wave, lane, wc);
+            split_load_w1(w.w[1], src, wl, 1, wave, lane, wc);
             split_mfma_term<F16>(w.w[0], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
-            if (last) { split_load_w1(w.w[0], next_layer, 0, wave, lane, next_c); break; }
+            if (last) { split_load_w1(w.w[0], src, next_layer, 0, wave, lane, next_c); break; }
         }
         ++c;
         {                                                  // chunk c with w1 in w.w[2]; w.w[0] is idle
             const bool last = c + 1 >= c1;
             const int n = last ? c : c + 1;
-            const uint4 *wl = last ? next_layer : layer;
+            const int wl = last ? next_layer : layer;
             const int wc = last ? next_c : n;
             __builtin_amdgcn_sched_barrier(0);
-            split_load_w1(w.w[0], wl, 0, wave, lane, wc);
+            split_load_w1(w.w[0], src, wl, 0, wave, lane, wc);
             split_mfma_term<F16>(w.w[2], a_lo, acc);
-            if (last) split_load_bias(b4, next_bias, wave, lane);
+            if (last) split_load_bias(b4, src, next_bias, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
             split_mfma_term<F16>(w.w[1], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
-            split_load_w1(w.w[1], wl, 1, wave, lane, wc);
+            split_load_w1(w.w[1], src, wl, 1, wave, lane, wc);
             split_mfma_term<F16>(w.w[2], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
@@ -305,14 +335,21 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const u
 }
 
 template <int P>
-__device__ __forceinline__ void split_gemm(const unsigned char *planes, const uint4 *layer, int c0, int c1, int slot_chunk, int slot_col,
-                                           int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], const uint4 *next_layer, int next_c,
-                                           const float *bias, f32x4 (&b4)[4], const float *next_bias) {
+__device__ __forceinline__ void split_gemm(const unsigned char *planes, const SplitSrc &src, int layer, int c0, int c1, int slot_chunk, int slot_col,
+                                           int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], int next_layer, int next_c,
+                                           int bias, f32x4 (&b4)[4], int next_bias) {
     if constexpr (P == 3 || P == kSpF16) {
-        split_gemm3<P == kSpF16>(planes, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, b4, next_bias);
+        split_gemm3<P == kSpF16>(planes, src, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, b4, next_bias);
         return;
     }
-    split_init_acc(bias, wave, lane, acc);
+    {                                                      // acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
+        f32x4 bb[4];
+        split_load_bias(bb, src, bias, wave, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = bb[mt];
+    }
     uint4 a_hi[4], a_lo[4];
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
     split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
@@ -324,7 +361,7 @@ __device__ __forceinline__ void split_gemm(const unsigned char *planes, const ui
         split_mfma_term(w.w[0], a_lo, acc);
         split_mfma_term(w.w[0], a_hi, acc);
         __builtin_amdgcn_sched_barrier(0);
-        split_load_w1(w.w[0], layer, 0, wave, lane, n);
+        split_load_w1(w.w[0], src, layer, 0, wave, lane, n);
         if (P >= 5) {
             split_mfma_term(w.w[1], a_lo, acc);
             __builtin_amdgcn_sched_barrier(0);
@@ -332,16 +369,16 @@ __device__ __forceinline__ void split_gemm(const unsigned char *planes, const ui
         split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
         split_mfma_term(w.w[1], a_hi, acc);
         __builtin_amdgcn_sched_barrier(0);
-        split_load_w1(w.w[1], layer, 1, wave, lane, n);
+        split_load_w1(w.w[1], src, layer, 1, wave, lane, n);
         if (P >= 4) {
             split_mfma_term(w.w[2], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
-            split_load_w1(w.w[2], layer, 2, wave, lane, n);
+            split_load_w1(w.w[2], src, layer, 2, wave, lane, n);
         }
         split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
     }
     __builtin_amdgcn_sched_barrier(0);
-    split_load_w<P>(w, next_layer, wave, lane, next_c);    // the first weight fragments of the layer that follows
+    split_load_w<P>(w, src, next_layer, wave, lane, next_c);    // the first weight fragments of the layer that follows
 }
 
 // four consecutive columns of one row -> both planes, 8 bytes each
@@ -374,8 +411,9 @@ __device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave
 }
 
 struct SplitArgs {
-    PolicyArgs p;                      // the float32 kernel's arguments (frags / bias: bias is shared, frags unused here)
+    PolicyArgs p;                      // the float32 kernel's arguments (frags / bias are unused here)
     const uint4 *sfrags;               // split weight fragments
+    const float *sbias;                // the biases in packed order, the LSTM gates' pre-scaled like their weight columns
 };
 
 // select_action (ProcessAgent.py:98-103) for the row whose softmax this 4-lane group holds (lane: columns 4g..4g+3 in pj): argmax
@@ -412,6 +450,26 @@ __device__ __forceinline__ int split_select_action(const float (&pj)[4], int g, 
     return below < A - 1 ? below : A - 1;
 }
 
+// The LSTM cell update of TWO cells at once (elements r, r+1 of a lane's accumulators: consecutive registers), on the packed
+// float32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 issue at the plain instructions' rate for twice the values --
+// tools/ubench/valu_rate_f32.hip: 5.0-5.1 clocks against 4.75-5.8; v_exp_f32 / v_rcp_f32: 8.75, no packed form):
+//   sigmoid(x) = 1 / (1 + 2^(-x log2 e)),  tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e));  c' = f c + i j;  h = o tanh(c')
+// 10 transcendentals per cell and 9 packed operations per two cells (the gates' log2 e factors are folded into the weights).
+__device__ __forceinline__ f32x2 sp_exp2(const f32x2 x) { f32x2 r; r[0] = __builtin_amdgcn_exp2f(x[0]); r[1] = __builtin_amdgcn_exp2f(x[1]); return r; }
+__device__ __forceinline__ f32x2 sp_rcp(const f32x2 x) { f32x2 r; r[0] = __builtin_amdgcn_rcpf(x[0]); r[1] = __builtin_amdgcn_rcpf(x[1]); return r; }
+__device__ __forceinline__ f32x2 sp_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 sp_splat(float v) { f32x2 r; r[0] = v; r[1] = v; return r; }
+__device__ __forceinline__ void split_lstm_cell2(const f32x2 xi, const f32x2 xj, const f32x2 xf, const f32x2 xo, const f32x2 c_old, f32x2 &c_new,
+                                                 f32x2 &h_new) {
+    // (xi, xf, xo arrive multiplied by log2 e, xj by 2 log2 e: split_gate_scale)
+    const f32x2 one = sp_splat(1.0f), m2 = sp_splat(-2.0f);
+    const f32x2 gi = sp_rcp(sp_exp2(-xi) + one), gf = sp_rcp(sp_exp2(-xf) + one), go = sp_rcp(sp_exp2(-xo) + one);
+    const f32x2 gj = sp_fma(sp_rcp(sp_exp2(xj) + one), m2, one);
+    c_new = sp_fma(gf, c_old, gi * gj);
+    const f32x2 tc = sp_fma(sp_rcp(sp_exp2(c_new * sp_splat(2.0f * kSpLog2e)) + one), m2, one);
+    h_new = go * tc;
+}
+
 // The forward pass of ONE 64-row tile by the 4 wavefronts of a workgroup (layout: header of this file).
 //   load(r, k)  -> policy input k (0 = num_other_agents) of tile row r, r < rows_here; the rows may live in global memory (the
 //                  stand-alone kernel) or in LDS (the fused actor kernel: the env step left them there);
@@ -423,29 +481,36 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
                                                   int tid, Load load, Emit emit) {
     const PolicyArgs &p = sa.p;
     constexpr bool F16 = SplitFmt<P>::f16;
-    const int wave = tid >> 6, lane = tid & 63, g = lane >> 4;
+    // (wave in a scalar register: every weight / bias address is then a uniform base + this lane's constant 32-bit offset, and the
+    //  fragment loads need no vector address arithmetic)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4;
     const int M = p.max_other, A = p.num_actions;
-    const uint4 *w_lstm = sa.sfrags + kSpOffLstm;
+    const SplitSrc src = split_src(sa.sfrags, sa.sbias);
+    constexpr int w_lstm = (int)kSpOffLstm;
     SplitW f0;
     f32x4 b4[4];                                           // the bias of the GEMM that comes next (P = 3: its first product's C operand)
-    split_load_w<P>(f0, w_lstm, wave, lane, 2);               // first LSTM step: h == 0, only the input chunk contributes
-    split_load_bias(b4, p.bias + kBiasLstm, wave, lane);
+    split_load_w<P>(f0, src, w_lstm, wave, lane, 2);          // first LSTM step: h == 0, only the input chunk contributes
+    split_load_bias(b4, src, kBiasLstm, wave, lane);
 
     // ---- input tile: gather + normalise + split into the slot columns ---------------------------------------------
     {
-        int local_max = 0;
+        int local_max = 0, local_min = 0;
         if (tid < 64) {
             const float v = tid < rows_here ? load(tid, 0) : 0.0f;
             len_f[tid] = v;
             int len = (int)v;
             len = len < 0 ? 0 : (len > M ? M : len);
             local_max = len;
+            local_min = v >= (float)len ? len : len - 1;   // (a fractional count: the row's last step is live only up to floor)
+            local_min = local_min < 0 ? 0 : local_min;
         }
         // h = 0 (columns 0..63 of both planes)
         for (int e = tid; e < 2 * 64 * 8; e += 256) {
             const int pl = e >> 9, r = (e >> 3) & 63, c16 = e & 7;
             *reinterpret_cast<uint4 *>(planes + pl * kSpPlaneB + r * kSpStrideB + c16 * 16) = uint4{0u, 0u, 0u, 0u};
         }
+        if (tid < 128)                                      // the zero column (256..263) of every row of both planes
+            *reinterpret_cast<uint4 *>(planes + (tid >> 6) * kSpPlaneB + (tid & 63) * kSpStrideB + kSpZeroCol * 2) = uint4{0u, 0u, 0u, 0u};
         const int items = 64 * (M + 1);                    // (row, slot): slot 0 = host (4 values), slot s = observed agent s-1 (7)
         for (int it = tid; it < items; it += 256) {
             const int r = it & 63, s = it >> 6;
@@ -461,7 +526,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { av[e] = p.avg[e < n_in ? sc0 + e : sc0]; sd[e] = p.std[e < n_in ? sc0 + e : sc0]; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (v[e] - av[e]) / sd[e];
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] - av[e]) * __builtin_amdgcn_rcpf(sd[e]);   // (v_rcp_f32, 1 ulp: ten instructions less per value than a float32 division)
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (row_ok && e < n_in) ? v[e] : 0.0f;
@@ -477,11 +542,16 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
             *reinterpret_cast<uint4 *>(d + kSpPlaneB) = uint4{lo[0], lo[1], lo[2], lo[3]};
         }
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(local_max, d, 64); local_max = o > local_max ? o : local_max; }
-        if (lane == 0) wave_max[wave] = local_max;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_xor(local_max, d, 64), q = __shfl_xor(local_min, d, 64);
+            local_max = o > local_max ? o : local_max;
+            local_min = q < local_min ? q : local_min;
+        }
+        if (lane == 0) { wave_max[wave] = local_max; wave_max[5 + wave] = local_min; }
     }
     __syncthreads();
     const int steps = wave_max[0];                         // rows 0..63 are all in wavefront 0's threads
+    const int tile_min_len = wave_max[5];                  // every row of the tile (idle tail rows: 0) has more than t observed agents while t < this
     POLICY_STAMP(5);
 
     // this lane's rows (one per row tile) and their sequence lengths
@@ -496,24 +566,28 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     for (int t = 0; t < steps; ++t) {
         f32x4 acc[4][4];
         if (t == 1) POLICY_STAMP(8);
-        split_gemm<P>(planes, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
-                      t + 1 < steps ? w_lstm : sa.sfrags + kSpOffL1, 0, p.bias + kBiasLstm, b4,
-                      p.bias + (t + 1 < steps ? kBiasLstm : kBiasL1));      // (requests the next step's / layer1's first fragments and bias)
+        split_gemm<P>(planes, src, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
+                      t + 1 < steps ? w_lstm : (int)kSpOffL1, 0, kBiasLstm, b4,
+                      t + 1 < steps ? kBiasLstm : kBiasL1);                 // (requests the next step's / layer1's first fragments and bias)
         if (t == 1) POLICY_STAMP(9);
         __syncthreads();                                   // every wavefront has read h
         if (t == 1) POLICY_STAMP(10);
+        // lane: row 16nt + l%16, hidden units 16w + 4g + r; column tile = gate (i, j, f, o).  dynamic_rnn: rows past their own
+        // length keep (c, h) -- when EVERY row of the tile is still live (uniform: the usual case in full worlds) no select is needed
+        const bool all_live = t < tile_min_len;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            // lane: row 16nt + l%16, hidden units 16w + 4g + r; column tile = gate (i, j, f, o)
-            const bool live = len_r[nt] > (float)t;        // dynamic_rnn: rows past their own length keep (c, h)
+            const bool live = all_live || len_r[nt] > (float)t;
             f32x4 h_new;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float gi = fast_sigmoid(acc[0][nt][r]), gj = fast_tanh(acc[1][nt][r]);
-                const float gf = fast_sigmoid(acc[2][nt][r]), go = fast_sigmoid(acc[3][nt][r]);
-                const float c_new = gf * cell[nt][r] + gi * gj;
-                h_new[r] = go * fast_tanh(c_new);
-                cell[nt][r] = live ? c_new : cell[nt][r];
+            for (int r = 0; r < 4; r += 2) {
+                f32x2 c2, h2;
+                split_lstm_cell2(f32x2{acc[0][nt][r], acc[0][nt][r + 1]}, f32x2{acc[1][nt][r], acc[1][nt][r + 1]},
+                                 f32x2{acc[2][nt][r], acc[2][nt][r + 1]}, f32x2{acc[3][nt][r], acc[3][nt][r + 1]},
+                                 f32x2{cell[nt][r], cell[nt][r + 1]}, c2, h2);
+                h_new[r] = h2[0]; h_new[r + 1] = h2[1];
+                if (all_live) { cell[nt][r] = c2[0]; cell[nt][r + 1] = c2[1]; }          // (uniform branch)
+                else { cell[nt][r] = live ? c2[0] : cell[nt][r]; cell[nt][r + 1] = live ? c2[1] : cell[nt][r + 1]; }
             }
             if (live) split_store4<F16>(planes, 16 * nt + (lane & 15), 16 * wave + 4 * g, h_new);   // (else h stays as it is)
         }
@@ -526,11 +600,10 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     {
         f32x4 acc[4][4];
         if (steps == 0) {                                  // (else the last LSTM step asked for them)
-            split_load_w<P>(f0, sa.sfrags + kSpOffL1, wave, lane, 0);
-            split_load_bias(b4, p.bias + kBiasL1, wave, lane);
+            split_load_w<P>(f0, src, (int)kSpOffL1, wave, lane, 0);
+            split_load_bias(b4, src, kBiasL1, wave, lane);
         }
-        split_gemm<P>(planes, sa.sfrags + kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, sa.sfrags + kSpOffL2, 0, p.bias + kBiasL1, b4,
-                      p.bias + kBiasL2);
+        split_gemm<P>(planes, src, (int)kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, (int)kSpOffL2, 0, kBiasL1, b4, kBiasL2);
         __syncthreads();
         split_store_relu<F16>(planes, wave, lane, acc);
         __syncthreads();
@@ -539,22 +612,20 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     // ---- layer2, fullyconnected1 ----------------------------------------------------------------------------------
     {
         f32x4 acc[4][4];
-        split_gemm<P>(planes, sa.sfrags + kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, 0, p.bias + kBiasL2, b4,
-                      p.bias + kBiasFc1);
+        split_gemm<P>(planes, src, (int)kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, (int)kSpOffFc1, 0, kBiasL2, b4, kBiasFc1);
         __syncthreads();
         split_store_relu<F16>(planes, wave, lane, acc);
         __syncthreads();
     }
     uint4 hw[kSpChWide][3];                                // the heads' weight fragments: half in flight across the epilogue
-    const uint4 *hp = sa.sfrags + kSpOffHead + lane;
+    auto head_frag = [&](int c, int pl) { return split_buf16(src.w, lane * 16, ((int)kSpOffHead + (c * 3 + pl) * 64) * 16); };
     {
         f32x4 acc[4][4];
-        split_gemm<P>(planes, sa.sfrags + kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, sa.sfrags + kSpOffFc1, kSpChWide - 1, p.bias + kBiasFc1, b4,
-                      p.bias + kBiasFc1);
+        split_gemm<P>(planes, src, (int)kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, (int)kSpOffFc1, kSpChWide - 1, kBiasFc1, b4, kBiasFc1);
 #pragma unroll
         for (int c = 0; c < kSpChWide / 2; ++c)
 #pragma unroll
-            for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
+            for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) hw[c][pl] = head_frag(c, pl);
         __syncthreads();
         split_store_relu<F16>(planes, wave, lane, acc);
         __syncthreads();
@@ -565,7 +636,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
 #pragma unroll
         for (int c = kSpChWide / 2; c < kSpChWide; ++c)
 #pragma unroll
-            for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) hw[c][pl] = hp[(c * 3 + pl) * 64];
+            for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) hw[c][pl] = head_frag(c, pl);
         f32x4 acc[5];
         acc[0] = *reinterpret_cast<const f32x4 *>(p.bias + kBiasHead + 4 * g);
         acc[1] = acc[2] = acc[3] = acc[4] = f32x4{0.f, 0.f, 0.f, 0.f};
