@@ -201,7 +201,8 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
         # Agents that are done and wait for their world to end still occupy a policy row but yield nothing.
         out = {"learning_agent_steps_per_s_per_gpu": rows[0] / dt, "policy_rows_per_s_per_gpu": policy_rows / dt,
                "ms_per_env_step": dt * 1e3 / n, "env_steps": n, "rows_handed_over": rows[0],
-               "training_steps": trainer.training_step if train else 0}
+               "training_steps": trainer.training_step if train else 0,
+               "actor_path": roll.actor_path if actor_kernel else "one launch per phase (policy, env + bookkeeping) in a hipGraph"}
         roll.close()
         env.close()
         return out

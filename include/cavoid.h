@@ -296,8 +296,8 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
  * as in cavoid_step_autoreset.
  * CAVOID_EUNSUPPORTED (use the step-by-step entry points): holonomic dynamics, CAVOID_POLICY_F32 / a non-default
  * CAVOID_POLICY_PRODUCTS, rvo_enabled with so many agents per world (> 12) that the ORCA lines do not fit into the LDS the
- * policy lends the env step.  Frozen-network agents (CAVOID_POLICY_FROZEN_NET) take the action the CALLER supplies, which this
- * entry point does not do: run those worlds through the step-by-step entry points. */
+ * policy lends the env step.  Frozen-network agents (CAVOID_POLICY_FROZEN_NET) act by a SECOND network: cavoid_actor_run_mix carries it;
+ * this entry point refuses an env whose generator makes such agents. */
 typedef struct cavoid_rollout_buffers {
     int32_t struct_size;             /* sizeof(cavoid_rollout_buffers) */
     int32_t reserved;
@@ -308,6 +308,17 @@ typedef struct cavoid_rollout_buffers {
 int cavoid_actor_run(cavoid_env *env, cavoid_policy *policy, cavoid_rollout *rollout, const cavoid_rollout_buffers *buffers,
                      float *obs_cur, float *obs_next, float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values,
                      int32_t n_steps, int32_t greedy, void *stream);
+
+/* cavoid_actor_run for the reference's TRAINING MIX (static / non-cooperative / RVO / CADRL agents around the learners,
+ * ga3c/GA3C/checkpoints/RL/wandb/run-2018-backup/checkpoints/index.txt:1-3; the CADRL agent is a frozen network, ga3c/GA3C/Server.py:36):
+ * `frozen` = a second cavoid_policy (same shapes, its own weights) that drives the CAVOID_POLICY_FROZEN_NET agents.  A tile that holds a
+ * running frozen-network agent runs the forward pass once more on `frozen`'s weights and takes its ARGMAX for exactly those rows -- what the
+ * step-by-step form does with cavoid_policy_rows + cavoid_policy_forward_rows(greedy) -- inside the same launch; other tiles skip it.
+ * Runs over the env step's ORCA instantiation (ORCA agents and in-step box scenarios included).  Bit-identical to the step-by-step
+ * form.  CAVOID_EUNSUPPORTED as cavoid_actor_run, and for a `frozen` handle of another inference form (CAVOID_POLICY_PRODUCTS / _F32). */
+int cavoid_actor_run_mix(cavoid_env *env, cavoid_policy *policy, cavoid_policy *frozen, cavoid_rollout *rollout,
+                         const cavoid_rollout_buffers *buffers, float *obs_cur, float *obs_next, float *rewards, uint8_t *done, uint8_t *game_over,
+                         int32_t *actions, float *values, int32_t n_steps, int32_t greedy, void *stream);
 
 /* cavoid_step_autoreset + cavoid_rollout_push as ONE launch: the env step of every world and the Experience bookkeeping of its slots
  * (ProcessAgent.py:149-211) -- the fused actor's env phase for actors whose policy is a launch of its own (frozen-network agents,

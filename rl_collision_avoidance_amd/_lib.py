@@ -123,6 +123,7 @@ SYMBOLS = [
     ("cavoid_rollout_reset", C.c_int, [_P, _P]),
     ("cavoid_rollout_push", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32] + [_P] * 10 + [C.c_int64, _P, _P, C.c_int64, _P]),
     ("cavoid_actor_run", C.c_int, [_P, _P, _P, C.POINTER(CavoidRolloutBuffers)] + [_P] * 7 + [C.c_int32, C.c_int32, _P]),
+    ("cavoid_actor_run_mix", C.c_int, [_P, _P, _P, _P, C.POINTER(CavoidRolloutBuffers)] + [_P] * 7 + [C.c_int32, C.c_int32, _P]),
     ("cavoid_step_push", C.c_int, [_P, _P, C.POINTER(CavoidRolloutBuffers)] + [_P] * 7 + [C.c_int32, _P]),
     ("cavoid_rollout_compact", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32] + [_P] * 9 + [C.c_int64, _P]),
     ("cavoid_rollout_active_rows", C.c_int, [_P] * 7),

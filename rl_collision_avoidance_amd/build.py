@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
 SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_multistep.hip"), os.path.join(CSRC, "cavoid_rvo.hip"),
            os.path.join(CSRC, "cavoid_relay.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
            os.path.join(CSRC, "cavoid_policy_capi.hip"), os.path.join(CSRC, "cavoid_comm_capi.hip"), os.path.join(CSRC, "cavoid_actor.hip"),
-           os.path.join(CSRC, "cavoid_actor_rvo.hip")]
+           os.path.join(CSRC, "cavoid_actor_rvo.hip"), os.path.join(CSRC, "cavoid_actor_frozen.hip")]
 HEADERS = {
     "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_multistep.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
@@ -25,6 +25,8 @@ HEADERS = {
                          "cavoid_policy_split.hpp", "cavoid_policy_host.hpp", "cavoid_rollout.hpp", "cavoid_rollout_host.hpp", "cavoid_host.hpp"],
     "cavoid_actor_rvo.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
                              "cavoid_policy_split.hpp", "cavoid_rollout.hpp", "cavoid_host.hpp"],
+    "cavoid_actor_frozen.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
+                                "cavoid_policy_split.hpp", "cavoid_rollout.hpp", "cavoid_host.hpp"],
     "cavoid_comm_capi.hip": ["cavoid_host.hpp"],
 }
 # per-file extra flags.  The multi-step env kernels run their step loop inside the launch; MachineLICM would hoist every
@@ -34,7 +36,8 @@ EXTRA_FLAGS = {"cavoid_multistep.hip": ["-mllvm", "-disable-machine-licm"], "cav
                "cavoid_relay.hip": ["-mllvm", "-disable-machine-licm"],
                # the fused actor kernel runs policy + env step + bookkeeping inside ONE step loop: same reason (without it the
                # GEMM loops' fragment addresses are hoisted across the loop: 256 VGPRs + 232 B/lane of scratch instead of 243 + 0)
-               "cavoid_actor.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_actor_rvo.hip": ["-mllvm", "-disable-machine-licm"]}
+               "cavoid_actor.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_actor_rvo.hip": ["-mllvm", "-disable-machine-licm"],
+               "cavoid_actor_frozen.hip": ["-mllvm", "-disable-machine-licm"]}
 STAMP_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so.stamp")
 DEPS = SOURCES + [os.path.join(CSRC, h) for hs in HEADERS.values() for h in hs] + [os.path.join(ROOT, "include", "cavoid.h")]
 OBJ_DIR = os.path.join(PKG_DIR, "build")

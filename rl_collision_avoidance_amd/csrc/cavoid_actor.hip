@@ -8,9 +8,9 @@
 
 using namespace cavoid;
 
-extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout *r, const cavoid_rollout_buffers *b, float *obs_cur, float *obs_next,
-                                float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values, int32_t n_steps,
-                                int32_t greedy, void *stream) {
+static int actor_run(cavoid_env *e, cavoid_policy *h, cavoid_policy *frozen, cavoid_rollout *r, const cavoid_rollout_buffers *b, float *obs_cur, float *obs_next,
+                     float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values, int32_t n_steps,
+                     int32_t greedy, void *stream) {
     if (!e || !h || !r || !b || b->struct_size != (int32_t)sizeof(cavoid_rollout_buffers) || !obs_cur || !obs_next || obs_cur == obs_next ||
         !rewards || !done || !game_over || !actions || !values || n_steps < 0)
         return CAVOID_EINVAL;
@@ -27,8 +27,11 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     // or a non-default number of split products (the kernel carries the default form of cavoid_policy_forward, so that both stay
     // bit-identical); frozen-network agents need a second network (BatchedRollout keeps those on the step-by-step path)
     if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC || !h->use_split || h->split_products != kSpDefaultProducts) return CAVOID_EUNSUPPORTED;
-    // frozen-network agents take the action the CALLER supplies; this entry point would hand them the learner's sample
-    if (e->cfg.gen_frozen_fraction > 0.0 && e->cfg.gen_nonlearning_fraction > 0.0) return CAVOID_EUNSUPPORTED;
+    // frozen-network agents act by THEIR network: without it this entry point would hand them the learner's sample
+    if (!frozen && e->cfg.gen_frozen_fraction > 0.0 && e->cfg.gen_nonlearning_fraction > 0.0) return CAVOID_EUNSUPPORTED;
+    if (frozen && (!frozen->loaded || frozen->device != e->device || frozen->in_size != h->in_size || frozen->max_other != h->max_other ||
+                   frozen->num_actions != h->num_actions || !frozen->use_split || frozen->split_products != kSpDefaultProducts))
+        return frozen->loaded ? CAVOID_EUNSUPPORTED : CAVOID_EINVAL;
     HIP_TRY(hipSetDevice(e->device));
     const KCfg &k = e->k;
     // ORCA agents / box scenarios generated inside the step: the env step's RVO instantiation (as cavoid_step_autoreset routes them)
@@ -46,6 +49,12 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
     a.step_counter = h->step_counter; a.blocks_done = h->blocks_done; a.cu_tickets = h->cu_tickets;
     const SplitArgs sa{a, h->sfrags, h->sbias};
+    SplitArgs fz = sa;                                       // the frozen network: same shapes, its own weights / normalisation; argmax only
+    if (frozen) {
+        fz.p.avg = frozen->normalize ? frozen->avg : nullptr; fz.p.std = frozen->normalize ? frozen->std : nullptr;
+        fz.p.frags = frozen->frags; fz.p.bias = frozen->bias; fz.p.min_policy = frozen->min_policy;
+        fz.sfrags = frozen->sfrags; fz.sbias = frozen->sbias;
+    }
     RolloutCfg rc = r->c;
     rc.dup_capacity = b->dup_capacity; rc.ep_capacity = b->ep_capacity;
     RolloutIO rio{};
@@ -55,11 +64,25 @@ extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout 
     ActorIO io{};
     io.obs[0] = obs_cur; io.obs[1] = obs_next; io.rewards = rewards; io.done = done; io.game_over = game_over;
     io.actions = actions; io.values = values; io.rollout_step = r->s.step_counter; io.n_steps = n_steps; io.greedy = greedy ? 1 : 0;
-    const int rc_launch = rvo_form ? cavoid_launch_actor_rvo(e, sa, rc, r->s, rio, io, s) : launch_actor_any<false>(e, sa, rc, r->s, rio, io, s);
+    const int rc_launch = frozen ? cavoid_launch_actor_frozen(e, sa, fz, rc, r->s, rio, io, s)
+                                 : (rvo_form ? cavoid_launch_actor_rvo(e, sa, rc, r->s, rio, io, s) : launch_actor_any<false>(e, sa, sa, rc, r->s, rio, io, s));
     if (rc_launch != CAVOID_OK) return rc_launch;
     hipLaunchKernelGGL(actor_finish_kernel, dim3(1), dim3(1), 0, s, r->s.step_counter, h->step_counter, n_steps);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
+}
+
+extern "C" int cavoid_actor_run(cavoid_env *e, cavoid_policy *h, cavoid_rollout *r, const cavoid_rollout_buffers *b, float *obs_cur, float *obs_next,
+                                float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions, float *values, int32_t n_steps,
+                                int32_t greedy, void *stream) {
+    return actor_run(e, h, nullptr, r, b, obs_cur, obs_next, rewards, done, game_over, actions, values, n_steps, greedy, stream);
+}
+
+extern "C" int cavoid_actor_run_mix(cavoid_env *e, cavoid_policy *h, cavoid_policy *frozen, cavoid_rollout *r, const cavoid_rollout_buffers *b,
+                                    float *obs_cur, float *obs_next, float *rewards, uint8_t *done, uint8_t *game_over, int32_t *actions,
+                                    float *values, int32_t n_steps, int32_t greedy, void *stream) {
+    if (!frozen) return CAVOID_EINVAL;
+    return actor_run(e, h, frozen, r, b, obs_cur, obs_next, rewards, done, game_over, actions, values, n_steps, greedy, stream);
 }
 
 extern "C" int cavoid_step_push(cavoid_env *e, cavoid_rollout *r, const cavoid_rollout_buffers *b, const float *obs_cur, float *obs_next,

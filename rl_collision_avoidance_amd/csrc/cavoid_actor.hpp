@@ -81,8 +81,13 @@ __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState 
 
 // RVO = true: the env step's ORCA instantiation (scripted RVO agents; it is also the one that generates box scenarios inside the
 // step) -- its line scratch comes out of the activation planes too (cavoid_actor_rvo.hip)
-template <int N, bool RVO>
-__global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KState s, const PoolRec *pool, const SplitArgs sa,
+// FROZEN = true: the tile may hold frozen-network agents (scripted policy 4: NON-learning agents driven by a second, frozen
+// NetworkVP_rnn -- the GA3C-CADRL agent mechanism of the reference's training mix, ga3c/GA3C/Server.py:36, index.txt:1-3).  After the
+// learner's pass a tile with at least one RUNNING policy-4 agent runs the same forward pass once more on the frozen network's weights
+// (`fz`) and takes its argmax for exactly those rows -- what BatchedRollout.act does with cavoid_policy_rows + cavoid_policy_forward_rows
+// in the step-by-step form; tiles without such agents skip it (one ballot + a workgroup barrier per step).
+template <int N, bool RVO, bool FROZEN = false>
+__global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KState s, const PoolRec *pool, const SplitArgs sa, const SplitArgs fz,
                                                        const RolloutCfg rc, const RolloutState rs, const RolloutIO rio_arg, const ActorIO io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // the policy's activation planes ...
     float *len_f = reinterpret_cast<float *>(planes + 2 * kSpPlaneB);
@@ -137,6 +142,26 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
                 }
             };
             policy_split_tile<kSpDefaultProducts>(sa, planes, len_f, wave_max, rows, tid, load, emit);
+            if constexpr (FROZEN) {
+                // the rows whose agent is a running frozen-network agent (the env state's flags: this step has not run yet)
+                bool mine = false;
+                if (tid < rows) {
+                    const uint32_t f = s.flags[a0 + tid];
+                    mine = (f & CAVOID_F_PRESENT) && ((f >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK) == (uint32_t)CAVOID_POLICY_FROZEN_NET &&
+                           (f & CAVOID_F_DONE_MASK) == 0u;
+                }
+                __syncthreads();                             // every wavefront is done with the learner's pass (planes, wave_max)
+                if (tid < 64) { const unsigned long long m = __ballot(mine); if (lane == 0) { wave_max[12] = (int)(uint32_t)m; wave_max[13] = (int)(uint32_t)(m >> 32); } }
+                __syncthreads();
+                const unsigned long long frozen_rows = (unsigned long long)(uint32_t)wave_max[12] | ((unsigned long long)(uint32_t)wave_max[13] << 32);
+                if (frozen_rows != 0ull) {                   // (uniform over the workgroup)
+                    auto emit_fz = [&](int trow, int g, const float (&pj)[4], const f32x4 &) {
+                        const int action = split_select_action(pj, g, lane, A, true, a0 + trow, 0, 0u, 0u);       // argmax: no random draw
+                        if (trow < rows && g == 0 && ((frozen_rows >> trow) & 1ull)) io.actions[a0 + trow] = action;
+                    };
+                    policy_split_tile<kSpDefaultProducts>(fz, planes, len_f, wave_max, rows, tid, load, emit_fz);
+                }
+            }
         }
         __syncthreads();                                     // the tile's actions / values are in memory; the planes are idle
 

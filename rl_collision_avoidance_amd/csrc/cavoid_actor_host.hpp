@@ -1,4 +1,4 @@
-// cavoid_actor_host.hpp -- launch of actor_kernel<N, RVO> (cavoid_actor.hpp), shared by the two translation units that instantiate
+// cavoid_actor_host.hpp -- launch of actor_kernel<N, RVO, FROZEN> (cavoid_actor.hpp), shared by the two translation units that instantiate
 // it: cavoid_actor.hip (RVO = false) and cavoid_actor_rvo.hip (RVO = true: ORCA agents, box scenarios generated inside the step).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -10,28 +10,28 @@
 
 namespace cavoid {
 
-template <int N, bool RVO>
-static int launch_actor(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
+template <int N, bool RVO, bool FROZEN = false>
+static int launch_actor(cavoid_env *e, const SplitArgs &sa, const SplitArgs &fz, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
                         hipStream_t s) {
     // > 64 KiB of dynamic LDS: opted into once per instantiation AND device (the attribute belongs to the function on the current
     // device; a process may drive several).  The flags are only ever set, and setting the attribute twice is harmless: no lock.
     static bool opted_in[64] = {};
     const int dev = e->device;
     if (dev < 0 || dev >= 64 || !opted_in[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(actor_kernel<N, RVO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(actor_kernel<N, RVO, FROZEN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)policy_split_lds_bytes()));
         if (dev >= 0 && dev < 64) opted_in[dev] = true;
     }
     const int64_t tiles = (e->W + e->k.wpw - 1) / e->k.wpw;
-    hipLaunchKernelGGL((actor_kernel<N, RVO>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, e->k, e->st, e->pool, sa, rc, rs, rio, io);
+    hipLaunchKernelGGL((actor_kernel<N, RVO, FROZEN>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, e->k, e->st, e->pool, sa, fz, rc, rs, rio, io);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }
 
-template <bool RVO>
-static int launch_actor_any(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
+template <bool RVO, bool FROZEN = false>
+static int launch_actor_any(cavoid_env *e, const SplitArgs &sa, const SplitArgs &fz, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
                             hipStream_t s) {
-#define CAVOID_ACTOR_CASE(NN) case NN: return launch_actor<NN, RVO>(e, sa, rc, rs, rio, io, s);
+#define CAVOID_ACTOR_CASE(NN) case NN: return launch_actor<NN, RVO, FROZEN>(e, sa, fz, rc, rs, rio, io, s);
     switch (e->cfg.max_agents) {
 #ifdef CAVOID_DEV_ONLY_N
         CAVOID_ACTOR_CASE(4) CAVOID_ACTOR_CASE(10)
@@ -82,3 +82,7 @@ int cavoid_launch_step_push_rvo(cavoid_env *e, const cavoid::RolloutCfg &rc, con
                                 const cavoid::ActorIO &io, int32_t step, hipStream_t s);
 int cavoid_launch_actor_rvo(cavoid_env *e, const cavoid::SplitArgs &sa, const cavoid::RolloutCfg &rc, const cavoid::RolloutState &rs,
                             const cavoid::RolloutIO &rio, const cavoid::ActorIO &io, hipStream_t s);
+// cavoid_actor_frozen.hip: actor_kernel<N, true, true> -- the 'everything' instantiation (ORCA agents, in-step box scenarios) + a
+// second, frozen network for the policy-4 agents
+int cavoid_launch_actor_frozen(cavoid_env *e, const cavoid::SplitArgs &sa, const cavoid::SplitArgs &fz, const cavoid::RolloutCfg &rc,
+                               const cavoid::RolloutState &rs, const cavoid::RolloutIO &rio, const cavoid::ActorIO &io, hipStream_t s);

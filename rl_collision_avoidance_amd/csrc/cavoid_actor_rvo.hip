@@ -7,7 +7,7 @@ using namespace cavoid;
 
 int cavoid_launch_actor_rvo(cavoid_env *e, const SplitArgs &sa, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io,
                             hipStream_t s) {
-    return launch_actor_any<true>(e, sa, rc, rs, rio, io, s);
+    return launch_actor_any<true>(e, sa, sa, rc, rs, rio, io, s);
 }
 
 int cavoid_launch_step_push_rvo(cavoid_env *e, const RolloutCfg &rc, const RolloutState &rs, const RolloutIO &rio, const ActorIO &io, int32_t step,

@@ -108,6 +108,8 @@ class BatchedRollout(object):
                    "cavoid_rollout_create")
         self._h = h
         self._graph = None
+        self._bufs = None
+        self._actor_buffers()                     # (allocated here, never inside a hipGraph capture that calls step() first)
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
@@ -198,17 +200,39 @@ class BatchedRollout(object):
     # -- the fused actor: K closed-loop steps in ONE launch -------------------------------------------------------
     @property
     def fused_available(self) -> bool:
-        """``run_fused`` applies: a ``FusedPolicy`` on the bf16-split kernel, no velocity actions / row lists / second (frozen)
-        network; ORCA agents up to 12 agents per world (their line scratch must fit beside the env step's tile in the LDS the
-        policy lends it)."""
+        """``run_fused`` applies: a ``FusedPolicy`` on the default (float16-split) inference form, no velocity actions; ORCA agents
+        up to 12 agents per world (their line scratch must fit beside the env step's tile in the LDS the policy lends it); the
+        network behind frozen-network agents, if any, must be a ``FusedPolicy`` too (``cavoid_actor_run_mix``)."""
+        return self.fused_unavailable_reason is None
+
+    @property
+    def fused_unavailable_reason(self) -> Optional[str]:
+        """Why ``step()`` / the hipGraph form must be used instead of the fused actor kernel (None: it applies)."""
         import os
         cfg = self.env.cfg
         # (skip_finished -- the step-by-step path's row list of the agents that still need an action -- does not matter here: the
         #  kernel runs every row of a tile anyway, and what finished agents are given as action / value is never used)
-        return (getattr(self.policy, "accepts_strided_obs", False)
-                and not (cfg.rvo_enabled and cfg.max_agents > 12)
-                and self.frozen_policy is None and cfg.dynamics != 2
-                and os.environ.get("CAVOID_POLICY_F32", "0") in ("", "0"))
+        if not getattr(self.policy, "accepts_strided_obs", False):
+            return "the policy is not a FusedPolicy"
+        if cfg.rvo_enabled and cfg.max_agents > 12:
+            return "ORCA agents with more than 12 agents per world (the line scratch does not fit the lent LDS)"
+        if cfg.dynamics == 2:
+            return "holonomic (velocity) actions"
+        if self.frozen_policy is not None and not getattr(self.frozen_policy, "accepts_strided_obs", False):
+            return "the frozen-network agents' policy is not a FusedPolicy"
+        if os.environ.get("CAVOID_POLICY_F32", "0") not in ("", "0") or os.environ.get("CAVOID_POLICY_PRODUCTS", "16") not in ("", "16"):
+            return "a non-default inference form (CAVOID_POLICY_F32 / CAVOID_POLICY_PRODUCTS)"
+        return None
+
+    @property
+    def actor_path(self) -> str:
+        """Which form of the actor loop this rollout runs with -- for train / bench logs (a run that silently falls from the fused
+        kernel to one launch per phase loses ~40 % of its actor throughput)."""
+        if self.fused_available:
+            return "fused actor kernel (cavoid_actor_run%s)" % ("_mix: learner + frozen network" if self.frozen_policy is not None else "")
+        why = self.fused_unavailable_reason
+        return ("one launch per phase (policy, env + bookkeeping%s) -- fused kernel not applicable: %s"
+                % (", frozen network" if self.frozen_policy is not None else "", why))
 
     def _h_env(self):
         return self.env._h
@@ -238,9 +262,14 @@ class BatchedRollout(object):
         b = self._actor_buffers()
         cur, nxt = self._obs_buffers[self._cur], self._obs_buffers[1 - self._cur]
         p = BatchedCollisionAvoidanceEnv._ptr
-        _lib.check(self._lib.cavoid_actor_run(env._h, pol._h, self._h, C.byref(b), p(cur), p(nxt), p(env.rewards), p(env.done),
-                                              p(env.game_over), p(self._act_out), p(self._val_out), int(n_steps), 1 if self.greedy else 0,
-                                              env._stream()), "cavoid_actor_run")
+        if self.frozen_policy is not None:                  # learners + frozen-network agents (the GA3C-CADRL agent mechanism) in one launch
+            _lib.check(self._lib.cavoid_actor_run_mix(env._h, pol._h, self.frozen_policy._h, self._h, C.byref(b), p(cur), p(nxt), p(env.rewards),
+                                                      p(env.done), p(env.game_over), p(self._act_out), p(self._val_out), int(n_steps),
+                                                      1 if self.greedy else 0, env._stream()), "cavoid_actor_run_mix")
+        else:
+            _lib.check(self._lib.cavoid_actor_run(env._h, pol._h, self._h, C.byref(b), p(cur), p(nxt), p(env.rewards), p(env.done),
+                                                  p(env.game_over), p(self._act_out), p(self._val_out), int(n_steps), 1 if self.greedy else 0,
+                                                  env._stream()), "cavoid_actor_run")
         self._cur = (self._cur + int(n_steps)) & 1
         self.step_index += int(n_steps)
 

@@ -202,10 +202,11 @@ def main(argv=None) -> None:
     roll.reset()
     if roll.fused_available and not args.no_actor_kernel:
         roll.capture_fused(steps_per_graph=args.steps_per_graph)       # K closed-loop steps per launch (cavoid_actor_run)
-        actors = "fused actor kernel (cavoid_actor_run), %d env steps per launch" % args.steps_per_graph
+        actors = "%s, %d env steps per launch" % (roll.actor_path, args.steps_per_graph)
     else:
         roll.capture(steps_per_graph=args.steps_per_graph)
-        actors = "one launch per phase in a hipGraph, %d env steps per graph" % args.steps_per_graph
+        actors = "%s; in a hipGraph, %d env steps per graph" % (
+            roll.actor_path if not roll.fused_available else "one launch per phase (--no-actor-kernel)", args.steps_per_graph)
     if rank == 0:
         print("actors: " + actors, flush=True)
     done_flag = torch.zeros(1, device=device)

@@ -31,10 +31,14 @@ def _make(W, N, seed, reflush, greedy=False, skip_finished=None, **over):
     torch.manual_seed(1234)
     net = NetworkVP_rnn(cfg).to("cuda:0")
     pol = FusedPolicy(net, seed=77)
+    frozen = None
+    if over.get("gen_frozen_fraction", 0.0) > 0.0:          # the network behind the frozen-network agents: its own weights
+        torch.manual_seed(4321)
+        frozen = FusedPolicy(NetworkVP_rnn(cfg).to("cuda:0"), seed=0)
     # short chunks: many flushes; room for every duplicate row of the re-flush quirk (a full buffer drops rows in arrival order,
     # which legitimately differs between the two forms)
     roll = BatchedRollout(env, pol, reflush_done=reflush, greedy=greedy, time_max=5, dup_capacity=600000 if reflush else None,
-                          skip_finished=skip_finished)
+                          skip_finished=skip_finished, frozen_policy=frozen)
     roll.reset()
     return env, net, pol, roll
 
@@ -52,6 +56,12 @@ def _same(a, b, what):
     (4, 700, False, False, dict(rvo_enabled=1, gen_rvo_fraction=0.5, gen_nonlearning_fraction=0.5, gen_min_agents=2)),   # ORCA agents (actor_kernel<N, true>)
     (3, 200, True, False, dict(gen_mode=1, gen_pool_size=0)),           # box scenarios generated inside the step
     (10, 100, False, False, dict(rvo_enabled=1, gen_mode=1, gen_pool_size=0, gen_rvo_fraction=0.5, gen_nonlearning_fraction=0.4, gen_min_agents=3)),
+    # frozen-network agents (scripted policy 4: the GA3C-CADRL agent mechanism) inside the fused launch -- cavoid_actor_run_mix
+    (4, 600, False, False, dict(gen_min_agents=2, gen_nonlearning_fraction=0.6, gen_static_fraction=0.2, gen_frozen_fraction=0.6)),
+    # ... the reference's whole training mix: static / non-cooperative / RVO / frozen network, box scenarios generated in the step
+    (4, 500, True, False, dict(rvo_enabled=1, gen_mode=1, gen_pool_size=0, gen_min_agents=2, gen_nonlearning_fraction=0.7, gen_static_fraction=0.2,
+                               gen_rvo_fraction=0.3, gen_frozen_fraction=0.3)),
+    (10, 200, False, True, dict(gen_min_agents=3, gen_nonlearning_fraction=0.5, gen_static_fraction=0.1, gen_frozen_fraction=0.8, gen_pool_size=300)),
 ])
 def test_fused_actor_equals_step_by_step(N, W, reflush, greedy, over):
     seed = 21
@@ -155,7 +165,7 @@ def test_fused_actor_graph_replay_equals_eager_calls():
 def test_fused_actor_refuses_what_it_does_not_carry():
     from rl_collision_avoidance_amd import _lib
     env, _, _, roll = _make(64, 4, 1, False, dynamics=2)               # velocity (holonomic) actions: the step-by-step entry points carry them
-    assert not roll.fused_available
+    assert not roll.fused_available and "holonomic" in roll.actor_path
     with pytest.raises(RuntimeError):
         roll.run_fused(2)
     # straight at the C ABI: a code, not a crash
@@ -168,6 +178,15 @@ def test_fused_actor_refuses_what_it_does_not_carry():
     rc = _lib.lib().cavoid_actor_run(env._h, roll.policy._h, roll._h, C.byref(b), p(roll._obs_buffers[0]), p(roll._obs_buffers[0]),
                                      p(env.rewards), p(env.done), p(env.game_over), p(roll._act_out), p(roll._val_out), 2, 0, None)
     assert rc == -1
+    roll.close(); env.close()
+    # an env whose generator makes frozen-network agents: cavoid_actor_run (no second network) refuses it, cavoid_actor_run_mix carries it
+    env, _, _, roll = _make(64, 4, 1, False, gen_min_agents=2, gen_nonlearning_fraction=0.5, gen_frozen_fraction=0.5)
+    assert roll.fused_available and "cavoid_actor_run_mix" in roll.actor_path
+    b = roll._actor_buffers()
+    rc = _lib.lib().cavoid_actor_run(env._h, roll.policy._h, roll._h, C.byref(b), p(roll._obs_buffers[0]), p(roll._obs_buffers[1]),
+                                     p(env.rewards), p(env.done), p(env.game_over), p(roll._act_out), p(roll._val_out), 2, 0, None)
+    assert rc == -4
+    roll.run_fused(2)
     roll.close(); env.close()
 
 

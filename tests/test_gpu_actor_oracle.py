@@ -40,8 +40,12 @@ def _make(W, N, seed, reflush, greedy, ring_len, **over):
     torch.manual_seed(99)
     net = NetworkVP_rnn(cfg).to("cuda:0")
     pol = FusedPolicy(net, seed=5)
+    frozen = None
+    if over.get("gen_frozen_fraction", 0.0) > 0.0:          # the network behind the frozen-network agents (cavoid_actor_run_mix)
+        torch.manual_seed(7)
+        frozen = FusedPolicy(NetworkVP_rnn(cfg).to("cuda:0"), seed=0)
     roll = BatchedRollout(env, pol, reflush_done=reflush, greedy=greedy, time_max=T_MAX, discount=GAMMA, ring_len=ring_len,
-                          dup_capacity=2000000 if reflush else None, episode_capacity=100 * W)
+                          dup_capacity=2000000 if reflush else None, episode_capacity=100 * W, frozen_policy=frozen)
     roll.reset()
     return env, net, pol, roll
 
@@ -56,6 +60,9 @@ def _make(W, N, seed, reflush, greedy, ring_len, **over):
      dict(rvo_enabled=1, gen_rvo_fraction=0.5, gen_nonlearning_fraction=0.5, gen_min_agents=2, gen_mode=1, gen_pool_size=0)),
     # a finite sensing horizon and a time-step reward inside the loop (run-ws/config.yaml:249-251,326-328)
     (4, 256, False, False, (4, 16, 16, 16, 16, 16, 12), dict(sensing_horizon=3.0, reward_time_step=-0.01, gen_min_agents=2)),
+    # the training mix with frozen-network agents (scripted policy 4; their actions come from a second network inside the launch)
+    (4, 300, False, False, (3, 16, 16, 16, 16, 16, 13),
+     dict(gen_min_agents=2, gen_nonlearning_fraction=0.6, gen_static_fraction=0.2, gen_frozen_fraction=0.6)),
     # PLAY_MODE (argmax), in-kernel ring generator, ragged last tile
     (3, 130, False, True, (5, 16, 16, 16, 16, 16, 11), dict(gen_pool_size=0, gen_min_agents=2)),
 ])
@@ -71,6 +78,8 @@ def test_fused_actor_against_the_oracles(N, W, reflush, greedy, launches, over):
     obs0 = roll.obs.cpu().numpy().copy()
     assert rp.obs_diff(obs0, co.observe(ocfg, st)).max() <= OBS_TOL
     is_learning = [obs0[..., :1].astype(np.float32)]             # column 0 of the observation acted on at step t (from the ORACLE)
+    st0 = st.copy()
+    frozen_at = []                                               # [t] -> bool [W, N]: a running frozen-network agent acts at step t
     ora = []
     t0 = 0
     for k in launches:
@@ -78,6 +87,7 @@ def test_fused_actor_against_the_oracles(N, W, reflush, greedy, launches, over):
         acts = roll.act_ring[t0:t0 + k].cpu().numpy().astype(np.int32).reshape(k, W, N)
         assert acts.min() >= 0 and acts.max() < env.num_actions
         for j in range(k):
+            frozen_at.append((((st.flags >> 8) & 7 == 4) & (st.flags & 0x20 != 0) & (st.flags & 7 == 0)).reshape(W, N))
             ora.append(co.step_autoreset(ocfg, ogen, seed, st, ep, acts[j]))
             is_learning.append(ora[-1][0][..., :1].astype(np.float32))
         t0 += k
@@ -127,6 +137,19 @@ def test_fused_actor_against_the_oracles(N, W, reflush, greedy, launches, over):
         else:
             assert float((p_k - p_ref).abs().max()) <= 2e-5
     assert worst_v <= 2e-4 and mism == 0
+    if roll.frozen_policy is not None:
+        # the frozen-network agents took THEIR network's argmax (checked where the float32 graph's top two are clearly apart)
+        fnet, bad, seen = roll.frozen_policy.net, 0, 0
+        for t in range(T):
+            with torch.no_grad():
+                _, p_fz, _ = fnet.forward(roll.x[t])
+            top2 = p_fz.topk(2, dim=1).values
+            clear = ((top2[:, 0] - top2[:, 1]) > 1e-4).cpu().numpy().reshape(W, N)
+            fz_rows = frozen_at[t] & clear
+            want = p_fz.argmax(dim=1).cpu().numpy().reshape(W, N)
+            bad += int((acts_all[t][fz_rows] != want[fz_rows]).sum())
+            seen += int(fz_rows.sum())
+        assert seen > 100 and bad == 0, (seen, bad)
 
     # ---- the rollout half: the training rows and the episode log, against the reference-pinned rollout oracle ------------------
     rec = []

@@ -138,7 +138,8 @@ def test_graph_replay_equals_eager_steps():
 def test_rollout_with_rvo_and_frozen_network_agents_on_box_scenarios():
     """SURVEY section 8f-N3 reached from the GA3C loop: box scenarios generated inside the step, a scripted mix of static / RVO /
     frozen-network / non-cooperative agents.  The frozen-network agents act by THEIR network's argmax (checked row by row against
-    a direct forward pass of the frozen weights), never record experiences, and the step-by-step loop equals its hipGraph."""
+    a direct forward pass of the frozen weights), never record experiences, and the step-by-step loop equals its hipGraph and the
+    fused actor kernel (cavoid_actor_run_mix: the learner's and the frozen network's passes inside one launch)."""
     from rl_collision_avoidance_amd import _lib
     from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
     from rl_collision_avoidance_amd.config import EnvConfig
@@ -157,7 +158,7 @@ def test_rollout_with_rvo_and_frozen_network_agents_on_box_scenarios():
             self.SCRIPTED_FROZEN_NET_FRACTION = 0.3
             EnvConfig.__init__(self)
     outs = []
-    for graphed in (False, True):
+    for graphed in (False, True, "fused"):
         cfg = Cfg()
         env = BatchedCollisionAvoidanceEnv(W, cfg, seed=9, gen_min_agents=2, gen_pool_size=0)
         assert env.cfg.rvo_enabled == 1 and env.cfg.gen_mode == 1
@@ -166,9 +167,13 @@ def test_rollout_with_rvo_and_frozen_network_agents_on_box_scenarios():
         with pytest.raises(ValueError):
             BatchedRollout(env, pol)                          # the env generates frozen-network agents: their network is required
         roll = BatchedRollout(env, pol, reflush_done=False, frozen_policy=frozen, ring_len=64)
-        assert not roll.fused_available                       # (ORCA agents: the step-by-step kernels carry them)
+        assert roll.fused_available and "cavoid_actor_run_mix" in roll.actor_path    # the whole mix inside the fused launch (round 4)
         roll.reset()
-        if not graphed:
+        if graphed == "fused":
+            roll.run_fused(2)
+            for _ in range(10):
+                roll.run_fused(4)
+        elif not graphed:
             # one step by hand: the frozen rows carry the frozen network's argmax, the others the learner's draw
             obs = roll.obs.clone()
             flags = env.get_state()[2].view(W, N)
@@ -199,9 +204,10 @@ def test_rollout_with_rvo_and_frozen_network_agents_on_box_scenarios():
         # nothing a scripted agent did became a training row
         flags = env.get_state()[2]
         roll.close(); env.close()
-    (o0, s0, x0, r0, a0, e0), (o1, s1, x1, r1, a1, e1) = outs
-    assert torch.equal(o0, o1) and all(torch.equal(u, v) for u, v in zip(s0, s1)) and torch.equal(e0, e1)
-    assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(a0, a1)
+    (o0, s0, x0, r0, a0, e0) = outs[0]
+    for (o1, s1, x1, r1, a1, e1) in outs[1:]:               # eager steps == their hipGraph == the fused actor kernel, bitwise
+        assert torch.equal(o0, o1) and all(torch.equal(u, v) for u, v in zip(s0, s1)) and torch.equal(e0, e1)
+        assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(a0, a1)
     assert e0.max().item() >= 1
 
 
