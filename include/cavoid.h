@@ -311,7 +311,7 @@ int cavoid_actor_run(cavoid_env *env, cavoid_policy *policy, cavoid_rollout *rol
 
 /* cavoid_actor_run for the reference's TRAINING MIX (static / non-cooperative / RVO / CADRL agents around the learners,
  * ga3c/GA3C/checkpoints/RL/wandb/run-2018-backup/checkpoints/index.txt:1-3; the CADRL agent is a frozen network, ga3c/GA3C/Server.py:36):
- * `frozen` = a second cavoid_policy (same shapes, its own weights) that drives the CAVOID_POLICY_FROZEN_NET agents.  A tile that holds a
+ * `frozen` = a second cavoid_policy handle (same shapes, its own weights) that drives the CAVOID_POLICY_FROZEN_NET agents.  A tile that holds a
  * running frozen-network agent runs the forward pass once more on `frozen`'s weights and takes its ARGMAX for exactly those rows -- what the
  * step-by-step form does with cavoid_policy_rows + cavoid_policy_forward_rows(greedy) -- inside the same launch; other tiles skip it.
  * Runs over the env step's ORCA instantiation (ORCA agents and in-step box scenarios included).  Bit-identical to the step-by-step
