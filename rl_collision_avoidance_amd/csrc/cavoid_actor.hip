@@ -39,7 +39,7 @@ static int actor_run(cavoid_env *e, cavoid_policy *h, cavoid_policy *frozen, cav
     int tile = (k.tile_rows * k.width + 3) & ~3;
     if (tile < k.park_floats) tile = k.park_floats;
     // the env step borrows the (idle) activation planes: staging arrays + obs tile (+ the ORCA lines, 64 (N-1) x 16 floats: N <= 12)
-    if (actor_env_lds_bytes(tile, k.rvo_lds_floats) > (size_t)2 * kSpPlaneB) return CAVOID_EUNSUPPORTED;
+    if (actor_env_lds_bytes(e->cfg.max_agents, tile, k.rvo_lds_floats) > (size_t)2 * kSpPlaneB) return CAVOID_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     PolicyArgs a{};

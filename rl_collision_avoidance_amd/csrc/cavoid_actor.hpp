@@ -41,8 +41,8 @@ struct ActorIO {
 
 // LDS the env step of a tile needs inside the (idle) activation planes: the action table + one wavefront's staging arrays and
 // obs tile
-__host__ __device__ inline size_t actor_env_lds_bytes(int tile_floats, int rvo_floats = 0) {
-    return (size_t)(lds_floats_block() + lds_floats_fixed() + tile_floats + rvo_floats) * sizeof(float);
+__host__ __device__ inline size_t actor_env_lds_bytes(int n_agents, int tile_floats, int rvo_floats = 0) {
+    return (size_t)(lds_floats_block() + lds_floats_fixed(n_agents) + tile_floats + rvo_floats) * sizeof(float);
 }
 
 // env.step of ONE tile by ONE wavefront + the Experience bookkeeping of the tile's slots (the env step's lane mapping: one lane
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) step_push_kernel(const KCfg c, const KSta
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile_need = (c.tile_rows * c.width + 3) & ~3;
     const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
-    const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
+    const int per_wave_floats = lds_floats_fixed(N) + tile_floats + c.rvo_lds_floats;
     double *lds_tab = reinterpret_cast<double *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
     const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;

@@ -177,7 +177,8 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
 
     const size_t W = (size_t)e->W;
     size_t o_act = 0;
-    rc = alloc_state(W, (size_t)cfg->max_agents, CAVOID_MAX_ACTIONS * 2 * sizeof(double), &e->slab, &e->st, &o_act);
+    constexpr size_t kActBytes = CAVOID_MAX_ACTIONS * 2 * sizeof(double);                  // the action table, then the cold constants
+    rc = alloc_state(W, (size_t)cfg->max_agents, kActBytes + sizeof(KCold), &e->slab, &e->st, &o_act);
     if (rc == CAVOID_OK && cfg->gen_pool_size > 0) {
         e->pool_size = cfg->gen_pool_size;
         const size_t recs = (size_t)e->pool_size * (size_t)cfg->max_agents * sizeof(PoolRec);
@@ -197,33 +198,43 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
         return CAVOID_EHIP;
     }
 
+    KCold cold{};
+    cold.budget_offset = cfg->time_budget_from_goal_edge ? cfg->near_goal_threshold : 0.0;
+    cold.max_time_ratio = cfg->max_time_ratio;
+    cold.max_turn_rate = cfg->max_turn_rate;
+    cold.gen_nonlearning = cfg->gen_nonlearning_fraction; cold.gen_static = cfg->gen_static_fraction;
+    cold.gen_goal_jitter = cfg->gen_goal_jitter; cold.gen_angle_jitter = cfg->gen_angle_jitter;
+    cold.gen_rvo = cfg->gen_rvo_fraction; cold.gen_min_trip = cfg->gen_min_trip; cold.gen_frozen = cfg->gen_frozen_fraction;
+    cold.gen_box_small_lo = cfg->gen_box_small[0]; cold.gen_box_small_hi = cfg->gen_box_small[1];
+    cold.gen_box_large_lo = cfg->gen_box_large[0]; cold.gen_box_large_hi = cfg->gen_box_large[1];
+    cold.gen_box_large_from = cfg->gen_box_large_from;
+    cold.rvo_inv_horizon = cfg->rvo_enabled ? 1.0 / cfg->rvo_time_horizon : 0.0;
+    cold.rvo_collab = cfg->rvo_collab_coeff; cold.rvo_radius_scale = cfg->rvo_radius_scale; cold.rvo_max_dh = cfg->rvo_max_delta_heading;
+    cold.gen_min_agents = cfg->gen_min_agents; cold.gen_max_agents = cfg->gen_max_agents;
+    KCold *d_cold = reinterpret_cast<KCold *>(static_cast<unsigned char *>(e->slab) + o_act + kActBytes);
+    if (hipMemcpy(d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice) != hipSuccess) {
+        g_last_hip_error = (int)hipGetLastError();
+        cavoid_destroy(e);
+        return CAVOID_EHIP;
+    }
+
     KCfg &k = e->k;
+    k.cold = d_cold;
     k.dt = cfg->dt;
-    k.near_goal = cfg->near_goal_threshold;
-    k.budget_offset = cfg->time_budget_from_goal_edge ? cfg->near_goal_threshold : 0.0;
     k.near_goal_sq = cfg->near_goal_threshold * cfg->near_goal_threshold;
-    k.max_time_ratio = cfg->max_time_ratio;
     k.collision_dist = cfg->collision_dist;
     k.close_range = cfg->getting_close_range;
     k.r_goal = cfg->reward_at_goal; k.r_coll = cfg->reward_collision; k.r_close = cfg->reward_getting_close;
     k.r_step = cfg->reward_time_step; k.close_slope = cfg->close_penalty_slope;
     k.clip_lo = cfg->reward_clip_lo; k.clip_hi = cfg->reward_clip_hi;
-    k.horizon = cfg->sensing_horizon; k.max_turn_rate = cfg->max_turn_rate;
-    k.gen_nonlearning = cfg->gen_nonlearning_fraction; k.gen_static = cfg->gen_static_fraction;
-    k.gen_goal_jitter = cfg->gen_goal_jitter; k.gen_angle_jitter = cfg->gen_angle_jitter;
-    k.gen_rvo = cfg->gen_rvo_fraction; k.gen_min_trip = cfg->gen_min_trip; k.gen_frozen = cfg->gen_frozen_fraction;
+    k.horizon = cfg->sensing_horizon;
     k.switches = (cfg->done_agents_collide ? 0u : kSwSkipDonePairs) | (cfg->sort_round_gap ? 0u : kSwExactGap) |
                  (cfg->sort_tie_lateral ? 0u : kSwIndexTie) | (cfg->wrap_closed_end ? kSwWrapClosed : 0u);
-    k.gen_box_small_lo = cfg->gen_box_small[0]; k.gen_box_small_hi = cfg->gen_box_small[1];
-    k.gen_box_large_lo = cfg->gen_box_large[0]; k.gen_box_large_hi = cfg->gen_box_large[1];
-    k.gen_mode = cfg->gen_mode; k.gen_box_large_from = cfg->gen_box_large_from; k.pool_epoch = cfg->gen_pool_epoch;
+    k.gen_mode = cfg->gen_mode; k.pool_epoch = cfg->gen_pool_epoch;
     k.rvo_enabled = cfg->rvo_enabled ? 1 : 0;
-    k.rvo_inv_horizon = cfg->rvo_enabled ? 1.0 / cfg->rvo_time_horizon : 0.0;
-    k.rvo_collab = cfg->rvo_collab_coeff; k.rvo_radius_scale = cfg->rvo_radius_scale; k.rvo_max_dh = cfg->rvo_max_delta_heading;
     k.max_other = cfg->max_other; k.width = 6 + 7 * cfg->max_other;
     k.sort_method = cfg->sort_method; k.dynamics = cfg->dynamics; k.actions_fp32 = cfg->actions_fp32;
     k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
-    k.gen_min_agents = cfg->gen_min_agents; k.gen_max_agents = cfg->gen_max_agents;
     k.pool_size = cfg->gen_pool_size;
     k.evaluate_mode = cfg->evaluate_mode ? 1 : 0;
     k.seed_lo = 0; k.seed_hi = 0;
@@ -263,19 +274,22 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     // rvo_enabled the STEP launches take the RVO instantiations (no parking, the ORCA scratch is theirs); reset / observe still
     // run the parking instantiations, whose parked floats may then run past a small tile into the wavefront's ORCA scratch --
     // by construction: that scratch (1024 (N-1) floats) is idle in those modes and always larger than the 192 (N-1) parked.
-    k.park_floats = (N >= kParkFromN && !cfg->rvo_enabled) ? 3 * (N - 1) * 64 : 0;
-    static_assert(64 * 2 * 4 * 2 >= 3 * 64, "reset / observe of an RVO env park keys and gaps in the idle ORCA scratch");
+    // ... then the float64 velocities of the time-to-impact order (256 floats), and at least the field-major scratch of the ORCA
+    // policy / the box generator
+    k.park_floats = ((N >= kParkFromN && !cfg->rvo_enabled) ? 3 * (N - 1) * 64 : 0) + 256;
+    if (k.park_floats < lds_floats_scratch()) k.park_floats = lds_floats_scratch();
+    static_assert(64 * 2 * 4 * 2 * (kParkFromN - 1) >= 3 * 64 * (kParkFromN - 1) + 256, "reset / observe of an RVO env park keys, gaps and velocities in the idle ORCA scratch");
     const int row_floats = k.width + 2;
     int tile_rows = (int)(9216 / ((size_t)row_floats * sizeof(float))) & ~3;
     if (tile_rows < 4) tile_rows = 4;
-    const bool one_pass_fits = (size_t)(lds_floats_block() + lds_floats_fixed() + k.rvo_lds_floats + lanes * row_floats + 4) * sizeof(float) <= 65536;
+    const bool one_pass_fits = (size_t)(lds_floats_block() + lds_floats_fixed(N) + k.rvo_lds_floats + lanes * row_floats + 4) * sizeof(float) <= 65536;
     if (tile_rows > lanes || (e->latency_mode && one_pass_fits)) tile_rows = lanes;
     if (const char *ov = std::getenv("CAVOID_TILE_ROWS")) { int v = std::atoi(ov); if (v >= 1 && v <= lanes) tile_rows = v; }
     // one wavefront must fit the 64 KiB a workgroup may ask for: with the ORCA scratch of a large N the tile shrinks
     auto wave_bytes = [&](int rows) {
         int tile = (rows * row_floats + 3) & ~3;
         if (tile < k.park_floats) tile = k.park_floats;
-        return (size_t)(lds_floats_fixed() + k.rvo_lds_floats + tile) * sizeof(float);
+        return (size_t)(lds_floats_fixed(N) + k.rvo_lds_floats + tile) * sizeof(float);
     };
     while (tile_rows > 4 && wave_bytes(tile_rows) + lds_floats_block() * sizeof(float) > 65536) tile_rows -= 4;
     k.tile_rows = tile_rows;

@@ -47,28 +47,40 @@ __device__ unsigned long long *g_trace = nullptr;
 // branch-probability hint: the block is laid out behind the hot path (the step loop of the larger instantiations is tens of
 // KB of code, most of it rarely taken paths; the instruction cache is 64 KB per two CUs)
 #define CAVOID_RARE(x) __builtin_expect(!!(x), 0)
+#ifndef CAVOID_SKIP
+#define CAVOID_SKIP 0   /* development: bit mask of phases left out (wrong results; instruction-count ablations) */
+#endif
 
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kRelayMaxConsumers = 4;   // observation wavefronts per tile of env_relay_kernel (cavoid_relay.hpp)
 
-// kernel-argument POD (by value).  The action table lives in device memory (per-lane index).
-struct KCfg {
-    double dt, near_goal_sq, near_goal, budget_offset, max_time_ratio, collision_dist, close_range;
-    double r_goal, r_coll, r_close, r_step, close_slope, clip_lo, clip_hi, horizon, max_turn_rate;
+// Create-time constants of the rarely taken paths (scenario generators, a fresh agent's time budget, the ORCA policy, the
+// max-turn-rate dynamics): in device memory behind KCfg::cold, read with scalar loads where they are used.  By value they were
+// 42 more scalar registers live across the whole step (the kernel-argument struct is loaded up front), and the step's hot
+// constants paid for them in spills to vector-register lanes (v_readlane per use).
+struct KCold {
+    double budget_offset, max_time_ratio, max_turn_rate;
     double gen_nonlearning, gen_static, gen_goal_jitter, gen_angle_jitter;
     double gen_rvo, gen_box_small_lo, gen_box_small_hi, gen_box_large_lo, gen_box_large_hi, gen_min_trip;
     double rvo_inv_horizon, rvo_collab, rvo_radius_scale, rvo_max_dh;
     double gen_frozen;           // P(frozen-network agent) among the scripted ones
+    int32_t gen_min_agents, gen_max_agents, gen_box_large_from, pad;
+};
+
+// kernel-argument POD (by value).  The action table lives in device memory (per-lane index).
+struct KCfg {
+    double dt, near_goal_sq, collision_dist, close_range;
+    double r_goal, r_coll, r_close, r_step, close_slope, clip_lo, clip_hi, horizon;
+    const KCold *__restrict__ cold;
     int32_t max_other, width, sort_method, dynamics, actions_fp32, timeout_enabled, num_actions;
-    int32_t gen_min_agents, gen_max_agents;
-    int32_t gen_mode, gen_box_large_from, rvo_enabled;
+    int32_t gen_mode, rvo_enabled;
     uint32_t pool_epoch;         // the pool holds generator worlds 0..P-1 of this episode index
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
     int32_t wpw;                 // worlds per wavefront, 1..floor(64/N): small batches spread over more, emptier wavefronts
     int32_t rvo_lds_floats;      // per-wavefront LDS floats of the ORCA line scratch (0 unless rvo_enabled)
-    int32_t park_floats;         // N >= kParkFromN: the obs tile region is at least this large (it parks the sort keys / gaps)
+    int32_t park_floats;         // least size of the tile region (parked sort keys / gaps, float64 velocities, field-major scratch)
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
     uint32_t switches;           // kSw* bits: the rarely flipped U-switches in ONE word, tested by uniform branches that sit OUTSIDE the
                                  // unrolled hot loops (measured on the one-step launch at 4 x 8192, same box: separate scalars tested
@@ -176,11 +188,27 @@ struct Agent {
     uint32_t flags;
 };
 
+// One staged agent -- what the lanes of the other agents of its world read of it after the move: 32 bytes, so a neighbour
+// costs two 16-byte LDS reads at ONE address (position | float32 velocity, radius) where field-major arrays cost five reads at
+// two.  The velocity is the float32 the observation features are made of; the float64 velocities, which only the
+// time-to-impact ordering and the ORCA policy read, live in the (then idle) tile region.  r < 0 marks an absent row.
+struct alignas(16) StageRec { double px, py; float vxf, vyf, r, pad; };
+static_assert(sizeof(StageRec) == 32, "two 16-byte reads per neighbour");
+// N >= kRingDoubleFromN: a world's records are staged TWICE, back to back ([a0 .. aN-1 | a0 .. aN-1]), so that the N-1 others of
+// agent i in ring order are simply the N-1 records behind its own: every neighbour address is the lane's own record address
+// plus a compile-time offset -- no index arithmetic at all in the pair pass and the row pass (it was 5-6 vector instructions
+// per neighbour and pass).  Smaller N keep one copy (the LDS of four wavefronts per SIMD is full at N = 4) and pay a compare
+// and a select per neighbour for the wrap.
+constexpr int kRingDoubleFromN = 6;
 // LDS carve: per workgroup double[64] (the action table, 32 x 2: every wavefront writes the same values, so no
-// workgroup barrier is needed), then per wavefront 4 double[64] (pos, vel) + float[64] (radius) + the obs tile
-// float[tile_rows * obs_stride]
+// workgroup barrier is needed), then per wavefront the staged records (64, or 128 when doubled) + the obs tile
+// float[tile_rows * obs_stride] (whose region also holds, while no rows are in it, the parked keys, the float64 velocities and
+// the scratch arrays of the ORCA policy / the box generator)
 __host__ __device__ constexpr int lds_floats_block() { return 64 * 2; }
-__host__ __device__ constexpr int lds_floats_fixed() { return 64 * 2 * 4 + 64; }
+__host__ __device__ constexpr int lds_floats_fixed(int n) { return (n >= kRingDoubleFromN ? 128 : 64) * (int)(sizeof(StageRec) / sizeof(float)); }
+// scratch the tile region must hold in instantiations that stage field-major arrays there (ORCA pre-move state, box generator):
+// four double[64] + one float[64]
+__host__ __device__ constexpr int lds_floats_scratch() { return 64 * 2 * 4 + 64; }
 
 // sin/cos for |x| up to a few thousand: 2-term Cody-Waite reduction by pi/2 and the degree-13/14
 // kernels of the classic fdlibm sin/cos (max error ~1 ulp).  Headings live in [-pi, pi), so the
@@ -212,11 +240,11 @@ __device__ __forceinline__ void sincos_bounded(double x, double *sn, double *cs)
 
 // scripted-policy draw shared by both generators (oracle: _draw_policy)
 __device__ __forceinline__ uint32_t draw_policy(const KCfg &c, const U4 &q, int i) {
-    if (i > 0 && u01(q.z) < c.gen_nonlearning) {
+    if (i > 0 && u01(q.z) < c.cold->gen_nonlearning) {
         const double u = u01(q.w);
-        if (u < c.gen_static) return 1u;
-        if (u < c.gen_static + c.gen_rvo) return 3u;
-        return u < c.gen_static + c.gen_rvo + c.gen_frozen ? 4u : 2u;
+        if (u < c.cold->gen_static) return 1u;
+        if (u < c.cold->gen_static + c.cold->gen_rvo) return 3u;
+        return u < c.cold->gen_static + c.cold->gen_rvo + c.cold->gen_frozen ? 4u : 2u;
     }
     return 0u;
 }
@@ -225,9 +253,9 @@ __device__ __forceinline__ uint32_t draw_policy(const KCfg &c, const U4 &q, int 
 __device__ __forceinline__ void finish_agent(const KCfg &c, uint32_t pol, Agent &a) {
     const double tx = (double)a.gx - a.px, ty = (double)a.gy - a.py;
     const double dxg = a.px - (double)a.gx, dyg = a.py - (double)a.gy;
-    const double straight = (sqrt(dxg * dxg + dyg * dyg) - c.budget_offset) / (double)a.pref;   // U11 (x - 0.0 is exact)
+    const double straight = (sqrt(dxg * dxg + dyg * dyg) - c.cold->budget_offset) / (double)a.pref;   // U11 (x - 0.0 is exact)
     a.heading = atan2(ty, tx);
-    a.t_rem = fmax(c.max_time_ratio * straight, c.dt);
+    a.t_rem = fmax(c.cold->max_time_ratio * straight, c.dt);
     a.vx = a.vy = 0.0;
     a.speed = 0.0f;
     a.flags = CAVOID_F_PRESENT | (pol == 0u ? CAVOID_F_LEARNING : 0u) | (pol << CAVOID_F_POLICY_SHIFT);
@@ -243,22 +271,22 @@ __device__ __forceinline__ void absent_agent(Agent &a) {
 template <int N>
 __device__ __forceinline__ void generate_agent(const KCfg &c, uint32_t gw, uint32_t ep, int i, Agent &a) {
     const U4 r = philox4x32(gw, ep, 0u, 0u, c.seed_lo, c.seed_hi);
-    const int span = c.gen_max_agents - c.gen_min_agents + 1;
-    const int n = c.gen_min_agents + (int)(r.x % (uint32_t)span);
+    const int span = c.cold->gen_max_agents - c.cold->gen_min_agents + 1;
+    const int n = c.cold->gen_min_agents + (int)(r.x % (uint32_t)span);
     if (i >= n) { absent_agent(a); return; }
     const double base = fmax(4.0, 0.7 * n), ring = base * (1.0 + u01(r.y)), phase = u01(r.z);
     const U4 p = philox4x32(gw, ep, 1u, (uint32_t)i, c.seed_lo, c.seed_hi);
     const U4 q = philox4x32(gw, ep, 2u, (uint32_t)i, c.seed_lo, c.seed_hi);
     a.radius = (float)(0.2 + 0.6 * u01(p.x));
     a.pref = (float)(0.5 + 1.5 * u01(p.y));
-    const double turn = phase + (i + (u01(p.z) - 0.5) * 2.0 * c.gen_angle_jitter) / n;
+    const double turn = phase + (i + (u01(p.z) - 0.5) * 2.0 * c.cold->gen_angle_jitter) / n;
     const double theta = 2.0 * kPi * turn;
     double sn, cs;
     sincos_bounded(theta, &sn, &cs);
     a.px = ring * cs;
     a.py = ring * sn;
-    a.gx = (float)(-a.px + (u01(q.x) - 0.5) * 2.0 * c.gen_goal_jitter);
-    a.gy = (float)(-a.py + (u01(q.y) - 0.5) * 2.0 * c.gen_goal_jitter);
+    a.gx = (float)(-a.px + (u01(q.x) - 0.5) * 2.0 * c.cold->gen_goal_jitter);
+    a.gy = (float)(-a.py + (u01(q.y) - 0.5) * 2.0 * c.cold->gen_goal_jitter);
     finish_agent(c, draw_policy(c, q, i), a);
 }
 
@@ -272,10 +300,10 @@ __device__ __forceinline__ void generate_world_v2(const KCfg &c, uint32_t gw, ui
                                                   double *lds_px, double *lds_py, double *lds_gx, double *lds_gy, float *lds_r,
                                                   Agent &a) {
     const U4 r = philox4x32(gw, ep, 0u, 0u, c.seed_lo, c.seed_hi);
-    const int span = c.gen_max_agents - c.gen_min_agents + 1;
-    const int n = c.gen_min_agents + (int)(r.x % (uint32_t)span);
-    const double lo = n < c.gen_box_large_from ? c.gen_box_small_lo : c.gen_box_large_lo;
-    const double hi = n < c.gen_box_large_from ? c.gen_box_small_hi : c.gen_box_large_hi;
+    const int span = c.cold->gen_max_agents - c.cold->gen_min_agents + 1;
+    const int n = c.cold->gen_min_agents + (int)(r.x % (uint32_t)span);
+    const double lo = n < c.cold->gen_box_large_from ? c.cold->gen_box_small_lo : c.cold->gen_box_large_lo;
+    const double hi = n < c.cold->gen_box_large_from ? c.cold->gen_box_small_hi : c.cold->gen_box_large_hi;
     double side = lo + (hi - lo) * u01(r.y);
     const U4 p = philox4x32(gw, ep, 1u, (uint32_t)i, c.seed_lo, c.seed_hi);
     const U4 q = philox4x32(gw, ep, 2u, (uint32_t)i, c.seed_lo, c.seed_hi);
@@ -294,7 +322,7 @@ __device__ __forceinline__ void generate_world_v2(const KCfg &c, uint32_t gw, ui
                 sx = side * (2.0 * u01(d.x) - 1.0); sy = side * (2.0 * u01(d.y) - 1.0);
                 gx = (float)(side * (2.0 * u01(d.z) - 1.0)); gy = (float)(side * (2.0 * u01(d.w) - 1.0));
                 const double tx = (double)gx - sx, ty = (double)gy - sy;
-                bool ok = sqrt(tx * tx + ty * ty) >= c.gen_min_trip;
+                bool ok = sqrt(tx * tx + ty * ty) >= c.cold->gen_min_trip;
                 for (int j = 0; j < round; ++j) {
                     const double margin = ((double)radius + (double)lds_r[base + j]) + c.close_range;
                     const double ax = sx - lds_px[base + j], ay = sy - lds_py[base + j];
@@ -366,9 +394,12 @@ __device__ __forceinline__ double time_to_impact(double rx, double ry, double vx
 // sqrt of a squared distance, bit for bit the device library's correctly rounded sqrt(double) for x = 0 and x >= 2^-767
 // (anything a sum of two squares of position differences can be): the library's iteration -- rsq seed, one coupled
 // Goldschmidt step, two residual corrections -- without its rescaling of tiny arguments (a compare, two ldexp and a select
-// per call; the pair pass calls it N-1 times per agent and step).  tests/test_gpu_parity.py holds the flags to the oracle's.
+// per call; the pair pass calls it N-1 times per agent and step).  x = 0 (two agents on one point) needs no select either: the
+// seed is taken of max(x, 2^-1000) -- finite -- so g = x * y is an exact 0 and every correction leaves it there (the library
+// returns x itself for 0); for x >= 2^-1000 the max is the identity.  x = +inf does not occur (positions are finite).
+// tests/test_gpu_parity.py holds the flags to the oracle's.
 __device__ __forceinline__ double sqrt_dist2(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
+    const double y = __builtin_amdgcn_rsq(fmax(x, 0x1p-1000));
     double g = x * y;
     double h = y * 0.5;
     const double r = __builtin_fma(-h, g, 0.5);
@@ -378,7 +409,7 @@ __device__ __forceinline__ double sqrt_dist2(double x) {
     g = __builtin_fma(d, h, g);
     d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
-    return __builtin_amdgcn_class(x, 0x260) ? x : g;          // +-0 and +inf come back as they are (like the library)
+    return g;
 }
 
 // Others of host i, in ring order: o = 0..N-2  ->  agent j = (i + 1 + o) mod N.  Iterating the N-1
@@ -403,32 +434,93 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 // Sort key of one neighbour, 63 bits: hi = 2^30 - bucket (far -> near is ASCENDING in hi), lo = the orderable float32
 // lateral offset.  bucket = rint(gap*100) (order-isomorphic to round(gap, 2)); |gap| < 1e7 m keeps hi in [1, 2^31).
 // A neighbour that is absent or beyond the sensing horizon gets a sentinel above every real key (and distinct per
-// slot), so the ranking needs no validity masks: sentinels simply sort last.
-struct Key { uint32_t hi, lo; };
+// slot, in the hi word: its lo word is whatever the arithmetic left there), so the ranking needs no validity masks:
+// sentinels simply sort last.
+// (one 64-bit value: the ranking compares whole keys with v_cmp_lt_u64, which wants the halves in a register pair)
+struct Key {
+    uint64_t v;
+    __device__ __forceinline__ uint32_t hi() const { return (uint32_t)(v >> 32); }
+    __device__ __forceinline__ uint32_t lo() const { return (uint32_t)v; }
+    __device__ __forceinline__ void set(uint32_t hi, uint32_t lo) { v = ((uint64_t)hi << 32) | lo; }
+};
 constexpr uint32_t kKeyBias = 1u << 30;
-__device__ __forceinline__ int key_bucket(const Key &k) { return (int)(kKeyBias - k.hi); }
+// sentinels: hi = kKeySentinel + slot (distinct per slot, above every real key: a real hi is < 2^31 - 16), lo = anything
+constexpr uint32_t kKeySentinel = 0x7FFFFFF0u;
+__device__ __forceinline__ bool key_is_sentinel(uint32_t hi) { return hi >= kKeySentinel; }
+__device__ __forceinline__ int key_bucket(const Key &k) { return (int)(kKeyBias - k.hi()); }
 
-// E6: centre distances to the other agents of the lane's world (from the LDS-staged positions), the
+// How a lane finds the staged post-move state of the OTHER agents of its world, in ring order (o = 0..N-2 -> agent
+// (i + 1 + o) mod N).  Two layouts behind one interface:
+struct OtherState { double px, py; float vxf, vyf, r; };
+
+// env_tile's wave-private records (StageRec; doubled from kRingDoubleFromN agents on)
+template <int N>
+struct RingStage {
+    static constexpr bool kDouble = N >= kRingDoubleFromN;
+    const StageRec *self;       // the lane's own record (its first copy)
+    const double *vx64, *vy64;  // float64 velocities by lane (kept current only for the time-to-impact order)
+    int i, base;                // agent index in its world, first lane of the world
+    __device__ __forceinline__ OtherState other(int o) const {
+        const StageRec *q = self + (o + 1);
+        if (!kDouble) q = (o + 1 + i >= N) ? q - N : q;        // (one compare + select; the rest is the read's immediate offset)
+        return OtherState{q->px, q->py, q->vxf, q->vyf, q->r};
+    }
+    __device__ __forceinline__ void vel64(int o, double &vx, double &vy) const {
+        const int j = base + other_index(i, o, N);
+        vx = vx64[j]; vy = vy64[j];
+    }
+};
+// the field-major hand-over buffers of the pipeline and relay kernels (another wavefront staged them)
+template <int N>
+struct ArrayStage {
+    const double *px, *py, *vx, *vy;
+    const float *r;
+    int i, base;
+    __device__ __forceinline__ OtherState other(int o) const {
+        const int j = base + other_index(i, o, N);
+        return OtherState{px[j], py[j], (float)vx[j], (float)vy[j], r[j]};
+    }
+    __device__ __forceinline__ void vel64(int o, double &ovx, double &ovy) const {
+        const int j = base + other_index(i, o, N);
+        ovx = vx[j]; ovy = vy[j];
+    }
+};
+
+// The four rotated features of one neighbour + its radius: everything here ends in a float32 observation (tolerance 1e-5) and
+// nowhere else.  The positions take one fused multiply-add per feature in float64 (more accurate than the oracle's separate
+// product and sum, an instruction less); the velocities (a few m/s at most: < 4e-7 of error) run in float32.  ONE statement of
+// it for every launch form (they are held bit-identical to each other).
+constexpr int kFeat = 5;   // p_par, p_orth, v_par, v_orth, r_other
+__device__ __forceinline__ void neighbour_features(const Ego &e, float pxf, float pyf, double rx, double ry, const OtherState &q, float (&f)[kFeat]) {
+    f[0] = (float)__builtin_fma(rx, e.prll_x, ry * e.prll_y);
+    f[1] = (float)__builtin_fma(ry, e.prll_x, -(rx * e.prll_y));
+    f[2] = __builtin_fmaf(q.vxf, pxf, q.vyf * pyf);
+    f[3] = __builtin_fmaf(q.vyf, pxf, -(q.vxf * pyf));
+    f[4] = q.r;
+}
+
+// E6: centre distances to the other agents of the lane's world (from the staged positions), the
 // collision test and the nearest gap.  All 64 lanes call this together.  What E9 needs later is kept
 // in its cheapest form -- the gap as the float32 that goes into the observation and one 63-bit sort key
 // per neighbour (its centimetre bucket and the float32 rounding of the lateral offset ry*tx - rx*ty, the
 // tie-break inside a bucket) -- not the float64 values (the register budget decides how many wavefronts a
 // SIMD holds, and with it how much memory latency hides).  float32 rounding is monotonic, so two DIFFERENT
 // float32 laterals order exactly as the float64 ones do; equal keys fall back to the exact comparison.
+// FEAT: the neighbour's observation features are made here too, while its staged state and the offset (rx, ry) are in
+// registers (the row pass then only places values: no second read of the neighbour, no second subtraction) -- the forms that
+// have the registers for it (everything but PARK).
 // PARK (N >= kParkFromN): the keys and gaps do not stay in 3(N-1) registers from here to the observation rows; they are
-// parked in the wave-private obs-tile region of LDS (idle until the rows are written), field-major [3][N-1][64]:
-// key.hi, key.lo, gap.  The loop is then rolled three neighbours at a time (three square-root chains in flight instead of
+// parked in the wave-private obs-tile region of LDS (idle until the rows are written), field-major: the keys [N-1][64] as
+// 64-bit words, then the gaps [N-1][64].  The loop is then rolled three neighbours at a time (three square-root chains in flight instead of
 // N-1), which is what lets the N = 10 kernels fit 128 registers.
 constexpr int kParkFromN = 6;
 // SW: some U-switch of c.switches is flipped (the caller tests the word once and picks the instantiation: inside the unrolled pair
 // loop even a never-taken uniform branch per neighbour splits the N-1 square-root chains into separate scheduling regions and
 // costs the one-step launch 9 %).
-template <int N, bool PARK = false, bool SW = false>
-__device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
-                                          const double *lds_px, const double *lds_py, const float *lds_r,
-                                          Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K],
-                                          uint32_t &valid, bool &hit, double &min_gap, uint32_t *park = nullptr, int lane = 0,
-                                          uint32_t frozen_w = 0u) {
+template <int N, bool PARK, bool SW, bool FEAT, class Stage>
+__device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, const Ego &e, bool present, const Stage &st,
+                                          Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K], float (*feat)[kFeat],
+                                          uint32_t &valid, bool &hit, double &min_gap, uint32_t *park, int lane, uint32_t frozen_w) {
     // frozen_w (U4 flipped, else 0): bit jj = agent jj of this lane's world was done before the step -- its pairs are skipped in
     // the collision test and the nearest gap (the observation still shows it)
     constexpr int K = Others<N>::K;
@@ -436,15 +528,18 @@ __device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, co
     valid = 0u;
     hit = false;
     min_gap = INFINITY;
-    if (!PARK) { key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f; }
+    if (!PARK) { key[0].set(kKeySentinel, 0u); gapf[0] = 0.0f; }
     auto one = [&](int o) {
-        const int jj = other_index(i, o, N), j = base + jj;
-        const float rjf = lds_r[j];
-        const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
+        const OtherState q = st.other(o);
+        const float rjf = q.r;
+        const double rx = q.px - a.px, ry = q.py - a.py;
         const double d = sqrt_dist2(rx * rx + ry * ry);
         const bool other = present && (rjf >= 0.0f);
         bool collides = other;
-        if (SW) collides = other && ((frozen_w >> jj) & 1u) == 0u && ((frozen_w >> i) & 1u) == 0u;    // (frozen_w = 0 unless U4 is flipped)
+        if (SW) {
+            const int jj = other_index(st.i, o, N);
+            collides = other && ((frozen_w >> jj) & 1u) == 0u && ((frozen_w >> st.i) & 1u) == 0u;    // (frozen_w = 0 unless U4 is flipped)
+        }
         // unordered-pair gap d - (r_lo + r_hi): the sum is commutative, both ends agree bitwise
         const double gap_c = d - (ri + (double)rjf);
         min_gap = collides ? fmin(min_gap, gap_c) : min_gap;
@@ -461,20 +556,18 @@ __device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, co
         if (SW) {
             // U7b flipped: the agent index (distinct per neighbour) instead of the lateral offset -- a stable sort on the bucket;
             // with exact gaps: nothing -- equal float32 gaps must compare EQUAL so that the exact path decides
-            if (c.switches & kSwIndexTie) lo = (uint32_t)jj;
+            if (c.switches & kSwIndexTie) lo = (uint32_t)other_index(st.i, o, N);
             if (c.switches & kSwExactGap) { lo = 0u; hi = 0x7FFFFFFEu - (orderable((float)gap_o) >> 1); }
         }
-        hi = seen ? hi : 0x7FFFFFFFu;
-        lo = seen ? lo : (uint32_t)o;
+        hi = seen ? hi : kKeySentinel + (uint32_t)o;
         if (PARK) {
-            park[(0 * K + o) * 64 + lane] = hi;
-            park[(1 * K + o) * 64 + lane] = lo;
+            reinterpret_cast<uint64_t *>(park)[o * 64 + lane] = ((uint64_t)hi << 32) | lo;
             park[(2 * K + o) * 64 + lane] = __float_as_uint((float)gap_o);
         } else {
             gapf[o] = (float)gap_o;
-            key[o].hi = hi;
-            key[o].lo = lo;
+            key[o].set(hi, lo);
         }
+        if (FEAT) neighbour_features(e, (float)e.prll_x, (float)e.prll_y, rx, ry, q, feat[o]);
     };
     if (PARK) {
         // (a scheduling fence per neighbour: left alone the scheduler interleaves all N-1 square-root chains of the unrolled loop
@@ -483,20 +576,19 @@ __device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, co
         for (int o = 0; o < N - 1; ++o) { one(o); __builtin_amdgcn_sched_barrier(0); }
     } else {
 #pragma unroll
-        for (int o = 0; o < N - 1; ++o) one(o);
+        for (int o = 0; o < N - 1; ++o) if (!(CAVOID_SKIP & 16) || o == 0) one(o);
     }
 }
 
-template <int N, bool PARK = false>
-__device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const Ego &e, bool present, int i, int base,
-                                          const double *lds_px, const double *lds_py, const float *lds_r,
-                                          Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K],
+template <int N, bool PARK, bool FEAT, class Stage>
+__device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const Ego &e, bool present, const Stage &st,
+                                          Key (&key)[Others<N>::K], float (&gapf)[Others<N>::K], float (*feat)[kFeat],
                                           uint32_t &valid, bool &hit, double &min_gap, uint32_t *park = nullptr, int lane = 0,
                                           uint32_t frozen_w = 0u) {
     if (CAVOID_RARE(c.switches != 0u))
-        pair_pass_impl<N, PARK, true>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, park, lane, frozen_w);
+        pair_pass_impl<N, PARK, true, FEAT>(c, a, e, present, st, key, gapf, feat, valid, hit, min_gap, park, lane, frozen_w);
     else
-        pair_pass_impl<N, PARK, false>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, park, lane, 0u);
+        pair_pass_impl<N, PARK, false, FEAT>(c, a, e, present, st, key, gapf, feat, valid, hit, min_gap, park, lane, 0u);
 }
 
 // Coalesced write-out of the wave's obs tile: n_floats contiguous floats starting at dst.
@@ -535,76 +627,39 @@ struct Slots {
 };
 static_assert(CAVOID_MAX_AGENTS - 1 <= 15, "a slot number must fit 4 bits");
 
-// Ranking by a round-robin tournament in integer arithmetic.  For every unordered pair (p, q), p < q, the borrow of the
-// 64-bit difference of their keys says "p comes first"; the loser's packed counter is bumped, so a neighbour's position in
-// the order = the number of pairs it lost.  No wave masks are produced (a comparison per pair would park 2 x N(N-1)/2 of
-// them in scalar registers), no branch is taken, nine instructions per pair; `tie` comes back true when two keys were EQUAL
-// (then the caller ranks the exact way).
+// Ranking by a round-robin tournament in integer arithmetic.  For every unordered pair (p, q), p < q, the sign of the 64-bit
+// difference of their keys says "p comes first"; the position of a neighbour in the order = the number of pairs it lost:
+// pos[q] += first, pos[p] -= first on top of the start value NO-1-p (p loses to every later neighbour unless the difference
+// says otherwise).  Full-rate 32-bit instructions only (v_sub_co / v_subb_co / shift / add / sub), no wave mask parked in scalar
+// registers, no branch: 5.2 vector instructions per pair measured at N = 10 (PMC), against 7.5 for the forms that packed the
+// counters four bits each or kept one outcome bit per pair.  Measured and dropped: the borrow consumed as a carry
+// (__builtin_usubll_overflow -> v_addc_co / v_subb_co: +0.9 instructions per pair after the hazard no-ops), and 64-bit compares
+// (v_cmp_lt_u64 / v_cmp_eq_u64 issue at a quarter of the 32-bit rate on gfx950).  `tie` comes back true when two keys were EQUAL
+// (difference zero): the caller then ranks the exact way.  With equal keys the later neighbour comes first.
 template <int NO, bool ASC_BUCKET, int KK>
-__device__ __forceinline__ bool tournament(const Key (&key)[KK], Slots &pos) {
-    pos.clear();
+__device__ __forceinline__ bool tournament(const Key (&key)[KK], int (&pos)[KK]) {
+    uint64_t k[KK];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        // near -> far order (closest_first) flips the bucket half of the key; sentinels stay on top
+        if (ASC_BUCKET) k[o] = ((uint64_t)(key_is_sentinel(key[o].hi()) ? key[o].hi() : 2u * kKeyBias - key[o].hi()) << 32) | key[o].lo();
+        else k[o] = key[o].v;
+        pos[o] = NO - 1 - o;
+    }
     uint32_t differ = 0xFFFFFFFFu;
 #pragma unroll
     for (int p = 0; p < NO; ++p)
 #pragma unroll
         for (int q = p + 1; q < NO; ++q) {
-            // near -> far order (closest_first) flips the bucket half of the key; sentinels stay on top
-            const uint64_t kp = ((uint64_t)(ASC_BUCKET ? ((key[p].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[p].hi) : key[p].hi) << 32) | key[p].lo;
-            const uint64_t kq = ((uint64_t)(ASC_BUCKET ? ((key[q].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[q].hi) : key[q].hi) << 32) | key[q].lo;
-            const uint64_t d = kp - kq;                              // both < 2^63: bit 63 of d <=> kp < kq <=> p first
-            const uint32_t p_first = (uint32_t)(d >> 63);
-            pos.bump(q, p_first);                                    // q lost
-            pos.bump(p, p_first ^ 1u);                               // p lost
+            const uint64_t d = k[p] - k[q];                          // both < 2^63: bit 63 of d <=> kp < kq <=> p first
+            const int p_first = (int)(d >> 63);
+            pos[q] += p_first;
+            pos[p] -= p_first;
             const uint32_t nz = (uint32_t)d | (uint32_t)(d >> 32);
             differ = nz < differ ? nz : differ;
         }
     return differ == 0u;
 }
-
-// The same tournament with the outcomes kept as one bit per pair and the positions extracted afterwards: a few more
-// instructions but shorter dependency chains -- faster where registers are not the limit (measured, N = 10 step loop:
-// 7.8 vs 8.4 us per step at 8192 worlds; N = 4 one step per launch: 6.7 vs 6.9 us).  Ranking by a round-robin tournament in integer arithmetic.  For every unordered pair (p, q), p < q, one bit says
-// "p comes first" (the borrow of the 64-bit difference of their keys); the position of a neighbour in the order is the
-// number of pairs it lost.  No wave masks are produced (a comparison per pair would park 2 x N(N-1)/2 of them in scalar
-// registers) and no branch is taken; `tie` comes back true when two keys were EQUAL (then the caller ranks the exact way).
-template <int NO>
-struct TournamentBits {
-    static constexpr int kPairs = NO * (NO - 1) / 2;
-    uint32_t t[(kPairs + 31) / 32 > 0 ? (kPairs + 31) / 32 : 1];
-    template <bool ASC_BUCKET, int KK>
-    __device__ __forceinline__ bool play(const Key (&key)[KK]) {
-#pragma unroll
-        for (int w = 0; w < (int)(sizeof(t) / sizeof(t[0])); ++w) t[w] = 0u;
-        uint32_t differ = 0xFFFFFFFFu;
-        int k = 0;
-#pragma unroll
-        for (int p = 0; p < NO; ++p)
-#pragma unroll
-            for (int q = p + 1; q < NO; ++q, ++k) {
-                // near -> far order (closest_first) flips the bucket half of the key; sentinels stay on top
-                const uint64_t kp = ((uint64_t)(ASC_BUCKET ? ((key[p].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[p].hi) : key[p].hi) << 32) | key[p].lo;
-                const uint64_t kq = ((uint64_t)(ASC_BUCKET ? ((key[q].hi == 0x7FFFFFFFu) ? 0x7FFFFFFFu : 2u * kKeyBias - key[q].hi) : key[q].hi) << 32) | key[q].lo;
-                const uint64_t d = kp - kq;                              // both < 2^63: bit 63 of d <=> kp < kq
-                t[k >> 5] |= (uint32_t)(d >> 63) << (k & 31);
-                const uint32_t nz = (uint32_t)d | (uint32_t)(d >> 32);
-                differ = nz < differ ? nz : differ;
-            }
-        return differ == 0u;
-    }
-    // number of neighbours that come before o
-    __device__ __forceinline__ int position(int o) const {
-        int lost = 0, k = 0;
-#pragma unroll
-        for (int p = 0; p < NO; ++p)
-#pragma unroll
-            for (int q = p + 1; q < NO; ++q, ++k) {
-                const uint32_t bit = (t[k >> 5] >> (k & 31)) & 1u;
-                if (q == o) lost += (int)bit;                            // p came first
-                if (p == o) lost += (int)(bit ^ 1u);                     // q came first
-            }
-        return lost;
-    }
-};
 
 // the same for a compile-time float count (the common shape: a full wavefront of rows of the default width): every
 // round but the last is unpredicated
@@ -625,6 +680,9 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
                 v[u] = ((r + 1) * 64 <= n4 || k < n4) ? src4[k] : float4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        // (left alone the scheduler pairs every read with its store -- read, wait for the LDS, store, 17 times over at N = 10:
+        //  a serial LDS round trip per 16 bytes on the step's chain; fenced, the eight reads are in flight together)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int r = r0 + u;
@@ -633,6 +691,7 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
                 if ((r + 1) * 64 <= n4 || k < n4) dst4[k] = v[u];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -644,23 +703,23 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // the rows of the steps before it, which other wavefronts write)
 // FLUSH = false: the rows stay in the LDS tile (row r at tile + r * ostride; needs c.tile_rows >= rows_active), nothing is written
 // to obs_dst
-template <int N, bool PARK = false, bool LEAN = PARK, class PreFlush = NoHook, bool FLUSH = true>
-__device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, int i, int base,
-                                             const double *lds_px, const double *lds_py, const double *lds_vx,
-                                             const double *lds_vy, const float *lds_r, const Key (&key_in)[Others<N>::K],
-                                             const float (&gapf_in)[Others<N>::K], uint32_t valid, float *tile,
+// FEAT: the pair pass made the neighbours' features (feat_in); else they are made here from the staged state.
+template <int N, bool PARK, bool FEAT, class Stage, class PreFlush = NoHook, bool FLUSH = true>
+__device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, const Stage &st,
+                                             const Key (&key_in)[Others<N>::K], const float (&gapf_in)[Others<N>::K], const float (*feat_in)[kFeat],
+                                             uint32_t valid, float *tile,
                                              float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave,
                                              PreFlush pre_flush = PreFlush()) {
     constexpr int K = Others<N>::K, NO = N - 1;
+    const int i = st.i;
     // PARK: the pair pass left keys and gaps in the tile region (pair_pass); they come back into registers only now
     Key key[K];
     float gapf[K];
 #pragma unroll
     for (int o = 0; o < K; ++o) {
         if (PARK) {
-            const uint32_t *park = reinterpret_cast<const uint32_t *>(tile);
-            key[o].hi = o < NO ? park[(0 * K + o) * 64 + lane] : 0x7FFFFFFFu;
-            key[o].lo = o < NO ? park[(1 * K + o) * 64 + lane] : 0u;
+            if (o < NO) key[o].v = reinterpret_cast<const uint64_t *>(tile)[o * 64 + lane];
+            else key[o].set(kKeySentinel + (uint32_t)o, 0u);
             gapf[o] = 0.0f;                                      // (fetched after the ranking, just before the rows are written)
         } else { key[o] = key_in[o]; gapf[o] = gapf_in[o]; }
     }
@@ -672,24 +731,31 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     // tournament over the 63-bit keys of the pair pass.  Two neighbours with EQUAL keys (same bucket, same float32
     // lateral) need the exact float64 laterals and the index rule: the generic path below (wave-uniform branch).
     // The exact ranking (rare: two equal fast keys in the tile, the time_to_impact order): ROLLED loops over the others with every
-    // criterion re-derived from the LDS-staged state -- O(N^2) square roots at run time, but a constant amount of code (unrolled
+    // criterion re-derived from the staged state -- O(N^2) square roots at run time, but a constant amount of code (unrolled
     // per pair, this path was a third of the kernel's code).  `among`: the candidates; near_first: the closest_first re-rank of the
     // kept set.  Criteria, in order: [time to impact, larger first]; the gap (its centimetre bucket, or -- U7a flipped -- the exact
     // float64 gap), larger first (smaller first when near_first); the lateral offset, smaller first (U7b flipped: skipped); the
-    // agent index (what the oracle's stable sort leaves).
-    auto rank_exact = [&](uint32_t among, bool near_first, bool use_tti) -> Slots {
-        Slots out;
-        out.clear();
+    // agent index (what the oracle's stable sort leaves).  Neighbours outside `among` come behind the candidates, in ring order
+    // (their slots, where the row has them, take zeros).
+    auto rank_exact = [&](uint32_t among, bool near_first, bool use_tti, int (&out)[K]) {
         auto criteria = [&](int o, double &g, double &l, double &t, int &jj) {
             jj = other_index(i, o, N);
-            const int j = base + jj;
-            const double rj = (double)lds_r[j];
-            const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
+            const OtherState q = st.other(o);
+            const double rj = (double)q.r;
+            const double rx = q.px - a.px, ry = q.py - a.py;
             const double gap = sqrt_dist2(rx * rx + ry * ry) - ri - rj;
             g = (c.switches & kSwExactGap) ? gap : rint(gap * 100.0);
             l = (c.switches & kSwIndexTie) ? 0.0 : ry * e.tx - rx * e.ty;
-            t = use_tti ? time_to_impact(rx, ry, a.vx - lds_vx[j], a.vy - lds_vy[j], ri + rj) : 0.0;
+            t = 0.0;
+            if (use_tti) {
+                double ovx, ovy;
+                st.vel64(o, ovx, ovy);
+                t = time_to_impact(rx, ry, a.vx - ovx, a.vy - ovy, ri + rj);
+            }
         };
+        Slots packed_out;
+        packed_out.clear();
+        const int n_among = __popc(among);
 #pragma unroll 1
         for (int p = 0; p < NO; ++p) {
             double gp, lp, tp;
@@ -706,52 +772,38 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
                 const bool q_first = use_tti ? (tq > tp) || (tq == tp && by_gap) : by_gap;
                 before += (q != p && ((among >> q) & 1u) && q_first) ? 1 : 0;
             }
-            out.set(p, before);
+            const bool member = (among >> p) & 1u;
+            packed_out.set(p, member ? before : n_among + __popc(~among & ((1u << p) - 1u)));
         }
-        return out;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) out[o] = packed_out.get(o);
     };
     const int m = __popc(valid);
     const int first = m > M ? m - M : 0;
     const int kept = m - first;
-    Slots pos;
-    pos.clear();
+    int pos[K];
+#pragma unroll
+    for (int o = 0; o < K; ++o) pos[o] = 0;
     uint32_t keep = 0u;
     bool generic = c.sort_method == CAVOID_SORT_TIME_TO_IMPACT;
     if (!generic) {
-        // far -> near: larger bucket first, then smaller lateral.  LEAN: packed counters (fewest registers), else bit vector
-        bool tie;
-        if (LEAN) tie = tournament<NO, false>(key, pos);
-        else {
-            TournamentBits<NO> tour;
-            tie = tour.template play<false>(key);
-#pragma unroll
-            for (int o = 0; o < NO; ++o) pos.set(o, tour.position(o));
-        }
+        // far -> near: larger bucket first, then smaller lateral
+        const bool tie = (CAVOID_SKIP & 2) ? false : tournament<NO, false>(key, pos);
         generic = __ballot(tie) != 0ull;                        // wave-uniform: redo this tile's ranks the exact way
     }
-    if (CAVOID_RARE(generic)) pos = rank_exact(valid, false, c.sort_method == CAVOID_SORT_TIME_TO_IMPACT);
+    if (CAVOID_RARE(generic)) rank_exact(valid, false, c.sort_method == CAVOID_SORT_TIME_TO_IMPACT, pos);
 #pragma unroll
-    for (int o = 0; o < NO; ++o) keep |= (((valid >> o) & 1u) && pos.get(o) >= first) ? (1u << o) : 0u;
+    for (int o = 0; o < NO; ++o) keep |= (((valid >> o) & 1u) && pos[o] >= first) ? (1u << o) : 0u;
     // pos - first IS the slot (closest_last / time_to_impact); subtracted at the use
     int slot_bias = first;
     if (CAVOID_RARE(c.sort_method == CAVOID_SORT_CLOSEST_FIRST)) {      // kept set re-ranked near -> far; full ties keep index order
         slot_bias = 0;
         Key k2[K];
 #pragma unroll
-        for (int o = 0; o < K; ++o) {                          // neighbours that were clipped away become sentinels
-            k2[o].hi = ((keep >> o) & 1u) ? key[o].hi : 0x7FFFFFFFu;
-            k2[o].lo = ((keep >> o) & 1u) ? key[o].lo : (uint32_t)o;
-        }
-        bool tie;
-        if (LEAN) tie = tournament<NO, true>(k2, pos);
-        else {
-            TournamentBits<NO> tour;
-            tie = tour.template play<true>(k2);
-            pos.clear();
-#pragma unroll
-            for (int o = 0; o < NO; ++o) pos.set(o, tour.position(o));
-        }
-        if (CAVOID_RARE(__ballot(tie) != 0ull)) pos = rank_exact(keep, true, false);
+        for (int o = 0; o < K; ++o)                            // neighbours that were clipped away become sentinels
+            k2[o].set(((keep >> o) & 1u) ? key[o].hi() : kKeySentinel + (uint32_t)o, key[o].lo());
+        const bool tie = tournament<NO, true>(k2, pos);
+        if (CAVOID_RARE(__ballot(tie) != 0ull)) rank_exact(keep, true, false, pos);
     }
 
     CAVOID_STAMP(9);                                             // ranks done
@@ -761,9 +813,10 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         for (int o = 0; o < NO; ++o) gapf[o] = __uint_as_float(park[(2 * K + o) * 64 + lane]);
         wave_lds_sync();
     }
+    const float pxf = (float)e.prll_x, pyf = (float)e.prll_y;
     const int rpp = c.tile_rows;                                 // rows per pass
     for (int p0 = 0; p0 < rows_active; p0 += rpp) {
-    if (active && lane >= p0 && lane < p0 + rpp) {
+    if (!(CAVOID_SKIP & 4) && active && lane >= p0 && lane < p0 + rpp) {
         float *row = tile + (lane - p0) * ostride;
         row[0] = (present && (a.flags & CAVOID_F_LEARNING)) ? 1.0f : 0.0f;
         row[1] = (float)kept;                                   // 0 for an absent agent (others == 0)
@@ -771,30 +824,32 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         row[3] = present ? (float)e.heading_ego : 0.0f;
         row[4] = present ? a.pref : 0.0f;
         row[5] = present ? a.radius : 0.0f;
+        // r_host + r_other as ONE float32 add is bit for bit the float32 rounding of the float64 sum (the sum of two floats is
+        // exact in float64).
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
             if (!((keep >> o) & 1u)) continue;
-            const int j = base + other_index(i, o, N);
-            const double rj = (double)lds_r[j];
-            const double rx = lds_px[j] - a.px, ry = lds_py[j] - a.py;
-            const double ovx = lds_vx[j], ovy = lds_vy[j];
-            float *f = row + 6 + 7 * (pos.get(o) - slot_bias);
-            f[0] = (float)(rx * e.prll_x + ry * e.prll_y);
-            f[1] = (float)(ry * e.prll_x - rx * e.prll_y);
-            f[2] = (float)(ovx * e.prll_x + ovy * e.prll_y);
-            f[3] = (float)(ovy * e.prll_x - ovx * e.prll_y);
-            f[4] = (float)rj;
-            f[5] = (float)(ri + rj);
-            f[6] = gapf[o];
+            float f[kFeat];
+            if (FEAT) {
+#pragma unroll
+                for (int q = 0; q < kFeat; ++q) f[q] = feat_in[o][q];
+            } else {
+                const OtherState q = st.other(o);
+                neighbour_features(e, pxf, pyf, q.px - a.px, q.py - a.py, q, f);
+            }
+            float *dst = row + 6 + 7 * (pos[o] - slot_bias);
+            dst[0] = f[0]; dst[1] = f[1]; dst[2] = f[2]; dst[3] = f[3]; dst[4] = f[4]; dst[5] = a.radius + f[4]; dst[6] = gapf[o];
         }
-        for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;   // unfilled slots
+        // unfilled slots.  (Measured and dropped at N = 10 with 2..10 agents present: straight-line predicated zero writes into
+        // the slots the not-kept neighbours rank at -- +80 vector instructions per wavefront-step over this loop.)
+        for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;
         if (packed) { row[width] = rew_f; row[width + 1] = done_f; }   // (obs | reward | done) gather record
     }
     wave_lds_sync();
     CAVOID_STAMP(10);                                            // rows in the LDS tile
     if (p0 == 0) pre_flush();
     const int rows_here = rows_active - p0 < rpp ? rows_active - p0 : rpp;
-    if (FLUSH) {
+    if (FLUSH && !(CAVOID_SKIP & 8)) {
         constexpr int kRows = (64 / N) * N, kW = 6 + 7 * (N - 1);   // a full wavefront, the default row widths
         constexpr bool kPlainOk = (kRows * kW) % 4 == 0, kPackedOk = (kRows * (kW + 2)) % 4 == 0;
         float *dst = obs_dst + (int64_t)p0 * ostride;
@@ -957,13 +1012,13 @@ __device__ __forceinline__ void rvo_action(const KCfg &c, const Agent &a, int i,
         if (jj == i || rjf < 0.0f) continue;
         const double rpx = lds_px[j] - a.px, rpy = lds_py[j] - a.py, rvx = hvx - lds_vx[j], rvy = hvy - lds_vy[j];
         const double dist_sq = rpx * rpx + rpy * rpy;
-        const double comb = c.rvo_radius_scale * (double)a.radius + c.rvo_radius_scale * (double)rjf, comb_sq = comb * comb;
+        const double comb = c.cold->rvo_radius_scale * (double)a.radius + c.cold->rvo_radius_scale * (double)rjf, comb_sq = comb * comb;
         double dx, dy, ucx, ucy;
         if (dist_sq > comb_sq) {
-            const double wx = rvx - c.rvo_inv_horizon * rpx, wy = rvy - c.rvo_inv_horizon * rpy;
+            const double wx = rvx - c.cold->rvo_inv_horizon * rpx, wy = rvy - c.cold->rvo_inv_horizon * rpy;
             const double w_sq = wx * wx + wy * wy, dot1 = wx * rpx + wy * rpy;
             if (dot1 < 0.0 && dot1 * dot1 > comb_sq * w_sq) {
-                const double w_len = sqrt(w_sq), ux = wx / w_len, uy = wy / w_len, scale = comb * c.rvo_inv_horizon - w_len;
+                const double w_len = sqrt(w_sq), ux = wx / w_len, uy = wy / w_len, scale = comb * c.cold->rvo_inv_horizon - w_len;
                 dx = uy; dy = -ux; ucx = scale * ux; ucy = scale * uy;
             } else {
                 const double leg = sqrt(dist_sq - comb_sq);
@@ -977,7 +1032,7 @@ __device__ __forceinline__ void rvo_action(const KCfg &c, const Agent &a, int i,
             const double w_len = sqrt(wx * wx + wy * wy), ux = wx / w_len, uy = wy / w_len, scale = comb * inv_dt - w_len;
             dx = uy; dy = -ux; ucx = scale * ux; ucy = scale * uy;
         }
-        L.put(0, m, Line{hvx + c.rvo_collab * ucx, hvy + c.rvo_collab * ucy, dx, dy});
+        L.put(0, m, Line{hvx + c.cold->rvo_collab * ucx, hvy + c.cold->rvo_collab * ucy, dx, dy});
         ++m;
     }
     const double gx = (double)a.gx - a.px, gy = (double)a.gy - a.py, gn = sqrt(gx * gx + gy * gy);
@@ -993,7 +1048,7 @@ __device__ __forceinline__ void rvo_action(const KCfg &c, const Agent &a, int i,
         while (delta < -kPi) delta += 2.0 * kPi;
         delta = wrap_closed_fixup(delta, c.switches);
     }
-    if (fabs(delta) > c.rvo_max_dh) { delta = copysign(c.rvo_max_dh, delta); speed = 0.0; }
+    if (fabs(delta) > c.cold->rvo_max_dh) { delta = copysign(c.cold->rvo_max_dh, delta); speed = 0.0; }
     a0 = speed; a1 = delta;
 }
 
@@ -1035,12 +1090,18 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
     // 272 -> 235 us); the step-loop instantiations stay at 2 wavefronts/SIMD either way and lose ILP to the rolled pair loop
     // (204 -> 212 us), and the RVO instantiations need their LDS for the ORCA lines
     constexpr bool kPark = N >= kParkFromN && !RVO && MODE != MODE_STEP_AUTORESET_PF && MODE != MODE_STEP_AUTORESET_N;
+    // the pair pass also makes the neighbours' observation features wherever their 5 (N-1) values can stay in registers
+    constexpr bool kFused = !kPark;
     const int tile_need = (c.tile_rows * ostride + 3) & ~3;
     const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
-    double *lds_px = reinterpret_cast<double *>(wbase);
+    StageRec *recs = reinterpret_cast<StageRec *>(wbase);  // the staged post-move records (twice per world from kRingDoubleFromN agents on)
+    float *tile = wbase + lds_floats_fixed(N);
+    // field-major scratch in the tile region while no rows are in it: the ORCA policy's pre-move state, the box generator's placements
+    double *lds_px = reinterpret_cast<double *>(tile);
     double *lds_py = lds_px + 64, *lds_vx = lds_py + 64, *lds_vy = lds_vx + 64;
     float *lds_r = reinterpret_cast<float *>(lds_vy + 64);
-    float *tile = lds_r + 64;
+    // ... and the float64 velocities the time-to-impact order reads (behind the parked keys / gaps where there are any)
+    double *vx64 = reinterpret_cast<double *>(tile + (kPark ? 3 * Others<N>::K * 64 : 0)), *vy64 = vx64 + 64;
     double *rvo_mem = reinterpret_cast<double *>(tile + tile_floats);   // ORCA lines (only with c.rvo_enabled)
 
     const int wpw = c.wpw, lanes_used = wpw * N;          // worlds / lanes this wavefront really owns
@@ -1195,12 +1256,12 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
         } else {
             double dh = a1;
             if (CAVOID_RARE(c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN)) {
-                const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
+                const double rate = fmin(fmax(dh / c.dt, -c.cold->max_turn_rate), c.cold->max_turn_rate);
                 dh = rate * c.dt;
             }
             nh = wrap_angle(dh + a.heading, c.switches);
-            double sn, cs;
-            sincos_bounded(nh, &sn, &cs);
+            double sn = 0.0, cs = 1.0;
+            if (!(CAVOID_SKIP & 32)) sincos_bounded(nh, &sn, &cs);
             npx = a.px + a0 * cs * c.dt; npy = a.py + a0 * sn * c.dt;
             nvx = a0 * cs; nvy = a0 * sn; nsp = a0;
         }
@@ -1221,20 +1282,31 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
     CAVOID_STAMP(3);                                        // dynamics done
     // ---- stage post-move state in LDS; E6 pair pass (ego frame in the same block: independent chains) ---
     bool present = active && (a.flags & CAVOID_F_PRESENT);
-    lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = a.vx; lds_vy[lane] = a.vy;
-    lds_r[lane] = present ? a.radius : -1.0f;              // radius < 0 marks an absent row
+    constexpr bool kDouble = RingStage<N>::kDouble;
+    const int rec_self = kDouble ? 2 * base + i : lane;    // doubled: world lw's two copies start at record 2 * base
+    const bool tti = c.sort_method == CAVOID_SORT_TIME_TO_IMPACT;
+    auto stage_self = [&](bool is_present) {               // (the doubled layout has no records for the lanes behind the last world)
+        if (!kDouble || lane < lanes_used) {
+            const StageRec me{a.px, a.py, (float)a.vx, (float)a.vy, is_present ? a.radius : -1.0f, 0.0f};   // radius < 0 marks an absent row
+            recs[rec_self] = me;
+            if (kDouble) recs[rec_self + N] = me;
+        }
+        if (CAVOID_RARE(tti)) { vx64[lane] = a.vx; vy64[lane] = a.vy; }
+    };
+    stage_self(present);
     wave_lds_sync();
+    const RingStage<N> st{recs + rec_self, vx64, vy64, i, base};
     Ego e = ego_frame_obs(c, a);
     Key key[Others<N>::K];
     float gapf[Others<N>::K];
+    float feat[Others<N>::K][kFeat];                       // the neighbours' features, made by the pair pass (kFused)
     uint32_t valid;
     bool hit;
     double min_gap;
     uint32_t frozen_w = 0u;                                 // U4 flipped: the agents of this lane's world that were done before the step
     if (kStepping && CAVOID_RARE(c.switches & kSwSkipDonePairs))
         frozen_w = (uint32_t)(__ballot(present_in && done_in) >> base) & ((1u << N) - 1u);
-    pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit, min_gap, reinterpret_cast<uint32_t *>(tile), lane,
-                        frozen_w);
+    pair_pass<N, kPark, kFused>(c, a, e, present, st, key, gapf, feat, valid, hit, min_gap, reinterpret_cast<uint32_t *>(tile), lane, frozen_w);
 
     CAVOID_STAMP(4);                                        // ego frame + pair pass done
     float rew_f = 0.0f, done_f = (present && (a.flags & CAVOID_F_DONE_MASK) == 0u) ? 0.0f : 1.0f;   // reset / observe, packed
@@ -1287,15 +1359,14 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
                             load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), episode + 1u) * N + i, nxt);
                     } else if (!box_in_step) new_episode<N>(c, pool, (uint32_t)(c.world_offset + w), episode, i, a);
                     present = (a.flags & CAVOID_F_PRESENT) != 0u;
-                    lds_px[lane] = a.px; lds_py[lane] = a.py; lds_vx[lane] = 0.0; lds_vy[lane] = 0.0;
-                    lds_r[lane] = present ? a.radius : -1.0f;
+                    stage_self(present);                   // (a fresh agent stands: a.vx = a.vy = 0)
                 }
                 wave_lds_sync();
                 if (restart) {
                     e = ego_frame_obs(c, a);
                     bool hit2;
                     double gap2;
-                    pair_pass<N, kPark>(c, a, e, present, i, base, lds_px, lds_py, lds_r, key, gapf, valid, hit2, gap2, reinterpret_cast<uint32_t *>(tile), lane);
+                    pair_pass<N, kPark, kFused>(c, a, e, present, st, key, gapf, feat, valid, hit2, gap2, reinterpret_cast<uint32_t *>(tile), lane);
                 }
             }
         }
@@ -1303,9 +1374,9 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
 
     CAVOID_STAMP(5);                                        // rewards / restart done
     // ---- E9 observation: once per step, after the restart decision -----------------------------------
-    if (io.obs) {
+    if (io.obs && !(CAVOID_SKIP & 1)) {
         CAVOID_STAMP(6);
-        assemble_obs<N, kPark>(c, a, e, active, lane, i, base, lds_px, lds_py, lds_vx, lds_vy, lds_r, key, gapf, valid, tile,
+        assemble_obs<N, kPark, kFused>(c, a, e, active, lane, st, key, gapf, feat, valid, tile,
                         io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave);
     }
     CAVOID_STAMP(7);                                        // tile flushed
@@ -1350,7 +1421,7 @@ env_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     const int ostride = io.obs ? io.obs_stride : c.width;
     const int tile_need = (c.tile_rows * ostride + 3) & ~3;
     const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
-    const int per_wave_floats = lds_floats_fixed() + tile_floats + c.rvo_lds_floats;
+    const int per_wave_floats = lds_floats_fixed(N) + tile_floats + c.rvo_lds_floats;
     double *lds_tab = reinterpret_cast<double *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
@@ -1373,7 +1444,7 @@ struct PipeRec {                       // per-buffer hand-over record, field-maj
     double tx[64], ty[64], heading[64];
     float pref[64], radius[64], rew[64], done[64];
     uint32_t flags[64], valid[64];
-    uint32_t key_hi[K][64], key_lo[K][64];
+    uint64_t key[K][64];
     float gap[K][64];
 };
 struct PipeStage { double px[64], py[64], vx[64], vy[64]; float r[64]; };
@@ -1482,7 +1553,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 moved_any = moved_any || moving;
                 double dh = a1;
                 if (CAVOID_RARE(c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN)) {
-                    const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
+                    const double rate = fmin(fmax(dh / c.dt, -c.cold->max_turn_rate), c.cold->max_turn_rate);
                     dh = rate * c.dt;
                 }
                 const double nh = wrap_angle(dh + a.heading, c.switches);
@@ -1517,7 +1588,8 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 double min_gap;
                 uint32_t frozen_w = 0u;
                 if (CAVOID_RARE(c.switches & kSwSkipDonePairs)) frozen_w = (uint32_t)(__ballot(present_in && done_in) >> base) & ((1u << N) - 1u);
-                pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit, min_gap, nullptr, 0, frozen_w);
+                const ArrayStage<N> as{st.px, st.py, st.vx, st.vy, st.r, i, base};
+                pair_pass<N, false, false>(c, a, e, present, as, key, gapf, nullptr, valid, hit, min_gap, nullptr, 0, frozen_w);
                 CAVOID_STAMP(4);
                 // ---- E7 rewards, E8 done -------------------------------------------------------------------------------
                 double r = 0.0;
@@ -1564,7 +1636,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                         e.tx = (double)a.gx - a.px; e.ty = (double)a.gy - a.py;
                         bool hit2;
                         double gap2;
-                        pair_pass<N>(c, a, e, present, i, base, st.px, st.py, st.r, key, gapf, valid, hit2, gap2);
+                        pair_pass<N, false, false>(c, a, e, present, as, key, gapf, nullptr, valid, hit2, gap2);
                     }
                 }
                 CAVOID_STAMP(5);
@@ -1573,7 +1645,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
                 rc.pref[lane] = a.pref; rc.radius[lane] = a.radius; rc.rew[lane] = rew_f; rc.done[lane] = done_f;
                 rc.flags[lane] = a.flags; rc.valid[lane] = valid;
 #pragma unroll
-                for (int o = 0; o < N - 1; ++o) { rc.key_hi[o][lane] = key[o].hi; rc.key_lo[o][lane] = key[o].lo; rc.gap[o][lane] = gapf[o]; }
+                for (int o = 0; o < N - 1; ++o) { rc.key[o][lane] = key[o].v; rc.gap[o][lane] = gapf[o]; }
                 CAVOID_STAMP(8);
             }
         } else if (k >= 1) {
@@ -1589,10 +1661,11 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
             const Ego e = ego_from(c, rc.tx[lane], rc.ty[lane], ao.heading);
             Key key[Others<N>::K];
             float gapf[Others<N>::K];
-            key[0].hi = 0x7FFFFFFFu; key[0].lo = 0u; gapf[0] = 0.0f;
+            key[0].set(kKeySentinel, 0u); gapf[0] = 0.0f;
 #pragma unroll
-            for (int o = 0; o < N - 1; ++o) { key[o].hi = rc.key_hi[o][lane]; key[o].lo = rc.key_lo[o][lane]; gapf[o] = rc.gap[o][lane]; }
-            assemble_obs<N, false, true>(c, ao, e, active, lane, i, base, st.px, st.py, st.vx, st.vy, st.r, key, gapf, rc.valid[lane], tile,
+            for (int o = 0; o < N - 1; ++o) { key[o].v = rc.key[o][lane]; gapf[o] = rc.gap[o][lane]; }
+            const ArrayStage<N> as{st.px, st.py, st.vx, st.vy, st.r, i, base};
+            assemble_obs<N, false, false>(c, ao, e, active, lane, as, key, gapf, nullptr, rc.valid[lane], tile,
                             io.obs + ((int64_t)(k - 1) * io.out_step_stride + w0) * N * ostride, (int)worlds_here * N, ostride, packed,
                             rc.rew[lane], rc.done[lane], wave);
             CAVOID_STAMP(7);

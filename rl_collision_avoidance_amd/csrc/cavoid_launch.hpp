@@ -42,7 +42,7 @@ static inline int launch_on(cavoid_env *e, const KCfg &k, const KState &st, int 
     const int row = io.obs ? io.obs_stride : k.width;
     int tile = (k.tile_rows * row + 3) & ~3;
     if (tile < k.park_floats) tile = k.park_floats;
-    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed() + k.rvo_lds_floats + tile)) * sizeof(float);
+    const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed(e->cfg.max_agents) + k.rvo_lds_floats + tile)) * sizeof(float);
 #define CAVOID_CASE(NN) \
     case NN:                                                                                                            \
         if (ev_start || ev_stop)                                                                                        \

@@ -169,7 +169,7 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &t
     moving = present_in && !done_in;
     double dh = a1;
     if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
-        const double rate = fmin(fmax(dh / c.dt, -c.max_turn_rate), c.max_turn_rate);
+        const double rate = fmin(fmax(dh / c.dt, -c.cold->max_turn_rate), c.cold->max_turn_rate);
         dh = rate * c.dt;
     }
     const double nh = wrap_angle(dh + a.heading, c.switches);
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         // ================================================ D: state owner =====================================================
         __builtin_amdgcn_s_setprio(3);
         KCfg cd = c;                                        // this role's constants, pinned in scalar registers (see P)
-        asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.max_turn_rate), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
+        asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
                      "+s"(cd.timeout_enabled), "+s"(cd.switches));
         const RelayTrig trig = relay_trig_constants();
         Agent a;
@@ -567,7 +567,9 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             uint32_t valid;
             bool hit;
             double min_gap;
-            pair_pass<N>(cc, ao, e, present, i, base, f.px, f.py, f.r, key, gapf, valid, hit, min_gap);
+            const ArrayStage<N> as{f.px, f.py, f.vx, f.vy, f.r, i, base};
+            float feat[Others<N>::K][kFeat];
+            pair_pass<N, false, true>(cc, ao, e, present, as, key, gapf, feat, valid, hit, min_gap);
             RELAY_STAMP(18);                               // C: ego frame + keys
             const bool last = t == n_steps - 1 && io.out_step_stride == 0;   // (with per-step slots no two steps share an address)
             const int64_t slot_w = (int64_t)t * io.out_step_stride;
@@ -576,7 +578,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     for (int o = 0; o < NC; ++o)
                         if (o != cid) relay_wait_bounded(&seq->cfin[o], 1);
             };
-            assemble_obs<N, false, true>(cc, ao, e, active, lane, i, base, f.px, f.py, f.vx, f.vy, f.r, key, gapf, valid, tile,
+            assemble_obs<N, false, true, ArrayStage<N>, decltype(order_last)>(cc, ao, e, active, lane, as, key, gapf, feat, valid, tile,
                                          io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,
                                          order_last);
             if (active) {                                  // the step's plain outputs (behind order_last, like the rows)
