@@ -58,10 +58,13 @@ __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState 
     k.actions = io.actions; k.obs = obs_n; k.rew = io.rewards; k.done = io.done; k.game_over = io.game_over;
     k.obs_stride = ow; k.n_steps = 1;
     StepOut so{0.0f, true, false};
-    env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = w0 + lw, a = w * N + i;
     const bool in_range = lane < wpw * N && w < c.num_worlds;
+    // (measured and dropped: the bookkeeping's two dependent reads -- the slot's counters, then its pending rewards -- issued under
+    //  the env step through a hook in env_tile; every lane then loads its pending rewards every step instead of the flushing lanes
+    //  once per T_max steps: actor loop 41.4 -> 49.8 us per env step, step_push 15.3 -> 23.3 us)
+    env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
     const bool learning = in_range && obs_t[a * ow] > 0.5f;          // is_learning of the state acted on (ProcessAgent.py:130)
     const int base = lane < wpw * N ? lw * N : 0;
     const int n_learning = __popcll(__ballot(learning) & (((1ull << N) - 1ull) << base));
@@ -179,26 +182,32 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
 // One auto-reset step of every world + its Experience bookkeeping in ONE launch (cavoid_step_push): the env phase of the loop
 // above as a kernel of its own -- one wavefront per tile, env_kernel's launch shape -- for actors whose policy runs as its own
 // launch (frozen-network agents, row lists, a caller-supplied policy): three launches (env, push, episode log) become one, the
-// step's rewards / done flags go from the env step to the bookkeeping in registers.
+// step's rewards / done flags go from the env step to the bookkeeping in registers.  Grid: (tiles / wavefronts per block, 2) --
+// y = 0 runs env step + bookkeeping, y = 1 copies the step's state rows into the experience store at the same time.
 template <int N, bool RVO>
 __global__ void __launch_bounds__(256) step_push_kernel(const KCfg c, const KState s, const PoolRec *pool, const RolloutCfg rc, const RolloutState rs,
                                                         const RolloutIO rio_arg, const ActorIO io, const int32_t step_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const int32_t step = step_arg >= 0 ? step_arg : *io.rollout_step;
+    const int blk = step % rc.ring_len;
+    if (blockIdx.y == 1) {
+        // the second half of the grid: the step's state rows -> the time-major experience store, by a wavefront of its own per
+        // tile (the rows are obs_cur, complete before the launch; nothing here depends on the env step the first half runs --
+        // in sequence on one wavefront the copy was a third of the launch's chain)
+        const int64_t a0 = tile * c.wpw * N;
+        int64_t worlds_here = c.num_worlds - tile * c.wpw;
+        worlds_here = worlds_here > c.wpw ? c.wpw : (worlds_here < 0 ? 0 : worlds_here);
+        rollout_copy_rows(rc, io.obs[0], rio_arg.x, a0, (int)worlds_here * N, blk, lane, 64);
+        return;
+    }
     const int tile_need = (c.tile_rows * c.width + 3) & ~3;
     const int tile_floats = tile_need > c.park_floats ? tile_need : c.park_floats;
     const int per_wave_floats = lds_floats_fixed(N) + tile_floats + c.rvo_lds_floats;
     double *lds_tab = reinterpret_cast<double *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
-    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-    const int32_t step = step_arg >= 0 ? step_arg : *io.rollout_step;
-    const int blk = step % rc.ring_len;
     actor_env_push_tile<N, RVO>(c, s, pool, rc, rs, rio_arg, io, io.obs[0], io.obs[1], lds_tab, wbase, lane, tile, step, blk);
-    // the step's state rows -> the time-major experience store
-    const int64_t a0 = tile * c.wpw * N;
-    int64_t worlds_here = c.num_worlds - tile * c.wpw;
-    worlds_here = worlds_here > c.wpw ? c.wpw : (worlds_here < 0 ? 0 : worlds_here);
-    rollout_copy_rows(rc, io.obs[0], rio_arg.x, a0, (int)worlds_here * N, blk, lane, 64);
 }
 
 #ifdef CAVOID_ACTOR_KERNELS      /* the non-template kernel is compiled by cavoid_actor.hip only */

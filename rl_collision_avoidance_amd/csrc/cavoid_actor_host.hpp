@@ -52,7 +52,7 @@ static int launch_step_push(cavoid_env *e, const RolloutCfg &rc, const RolloutSt
     int tile = (k.tile_rows * k.width + 3) & ~3;
     if (tile < k.park_floats) tile = k.park_floats;
     const size_t lds = (size_t)(lds_floats_block() + e->waves_per_block * (lds_floats_fixed(e->cfg.max_agents) + k.rvo_lds_floats + tile)) * sizeof(float);
-    hipLaunchKernelGGL((step_push_kernel<N, RVO>), dim3((unsigned)e->grid), dim3(64 * e->waves_per_block), lds, s, k, e->st, e->pool, rc, rs, rio, io, step);
+    hipLaunchKernelGGL((step_push_kernel<N, RVO>), dim3((unsigned)e->grid, 2u), dim3(64 * e->waves_per_block), lds, s, k, e->st, e->pool, rc, rs, rio, io, step);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }

@@ -494,8 +494,15 @@ constexpr int kFeat = 5;   // p_par, p_orth, v_par, v_orth, r_other
 __device__ __forceinline__ void neighbour_features(const Ego &e, float pxf, float pyf, double rx, double ry, const OtherState &q, float (&f)[kFeat]) {
     f[0] = (float)__builtin_fma(rx, e.prll_x, ry * e.prll_y);
     f[1] = (float)__builtin_fma(ry, e.prll_x, -(rx * e.prll_y));
-    f[2] = __builtin_fmaf(q.vxf, pxf, q.vyf * pyf);
-    f[3] = __builtin_fmaf(q.vyf, pxf, -(q.vxf * pyf));
+    // (scalar float32 on purpose: left to itself the compiler packs the two dot products into v_pk_mul_f32 + v_pk_fma_f32 whose
+    //  third operand reads the product pair with its halves SWAPPED (op_sel:[0,0,1] op_sel_hi:[1,0,0]).  Inside the fused actor
+    //  kernel -- matrix instructions of the CU's other workgroup sharing the SIMD -- the low lane of that fma, v_par, came out
+    //  wrong now and then, run to run, for the neighbours whose mul and fma sat a few instructions apart; never in the env-only
+    //  kernels.  tools/repro_actor_case.py; the barriers keep the two chains out of the vectoriser's sight.)
+    float t_par = q.vyf * pyf, t_orth = q.vxf * pyf;
+    asm volatile("" : "+v"(t_par), "+v"(t_orth));
+    f[2] = __builtin_fmaf(q.vxf, pxf, t_par);
+    f[3] = __builtin_fmaf(q.vyf, pxf, -t_orth);
     f[4] = q.r;
 }
 
@@ -840,9 +847,15 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
             float *dst = row + 6 + 7 * (pos[o] - slot_bias);
             dst[0] = f[0]; dst[1] = f[1]; dst[2] = f[2]; dst[3] = f[3]; dst[4] = f[4]; dst[5] = a.radius + f[4]; dst[6] = gapf[o];
         }
-        // unfilled slots.  (Measured and dropped at N = 10 with 2..10 agents present: straight-line predicated zero writes into
-        // the slots the not-kept neighbours rank at -- +80 vector instructions per wavefront-step over this loop.)
-        for (int k = 6 + 7 * kept; k < width; ++k) row[k] = 0.0f;
+        // unfilled slots, a slot (seven floats) per iteration: the loop runs as long as the emptiest row of the wavefront -- an absent
+        // agent's, all M slots -- so float by float it was 7 M dependent iterations per step at N = 10 with 2..10 agents present.
+        // (Measured and dropped there: straight-line predicated zero writes into the slots the not-kept neighbours rank at, +80
+        // vector instructions per wavefront-step.)
+        for (int sl = kept; sl < M; ++sl) {
+            float *z = row + 6 + 7 * sl;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) z[q] = 0.0f;
+        }
         if (packed) { row[width] = rew_f; row[width + 1] = done_f; }   // (obs | reward | done) gather record
     }
     wave_lds_sync();

@@ -46,7 +46,7 @@ struct RelaySeq {                        // sequence counters (each written by e
     int fin;                             // D: the state and verdict slots of steps < fin are final (restarted worlds patched in)
     int act;                             // L: actions of steps < act are in the ring
     int ev;                              // D: restart events posted (it has read the old records of the restarted lanes)
-    int nxt;                             // L: restart events served (pool records of the restarted lanes re-armed)
+    int nxt;                             // L: 1 + restart events served (1: the first pool records are in; then re-armed after every restart)
     int cons[kRelayMaxConsumers];        // C: steps < cons[c] of consumer c's share are flushed (ring slots free)
     int cfin[kRelayMaxConsumers];        // C: all of the consumer's stores have completed
     int pad[1];
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 Agent S = T;                               // the committed state of step t
                 S.flags = vflags;
                 if (rmask != 0ull) {                       // some world of the tile starts a new episode
-                    relay_wait(&seq->nxt, events);         // every earlier restart's records are re-armed
+                    relay_wait(&seq->nxt, events + 1);     // the first records are in / every earlier restart's are re-armed
                     Agent nx;
                     relay_read_nxt(*nbuf, lane, nx);
                     bool mr;
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 stage_out(tn, Tn, lane);                   // the posted successor was wrong for some lane
                 relay_post(&seq->stage, t + 2);
                 if (rmask != 0ull) {                       // tell the loader which lanes need their next pool record
-                    relay_wait(&seq->nxt, events - (kRelayEvq - 1));
+                    relay_wait(&seq->nxt, events + 1 - (kRelayEvq - 1));
                     if (lane == 0) evq[events & (kRelayEvq - 1)] = rmask;
                     events += 1;
                     relay_post(&seq->ev, events);
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             S.flags = vflags;
             const bool restart = (ctl & 2u) != 0u;
             if (__ballot(restart) != 0ull) {
-                relay_wait(&seq->nxt, events);
+                relay_wait(&seq->nxt, events + 1);
                 Agent nx;
                 relay_read_nxt(*nbuf, lane0, nx);
                 if (restart) {
@@ -471,18 +471,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         // ================================================ L: actions and pool records ==========================================
         __builtin_amdgcn_s_setprio(1);
         uint32_t ep = 0u;
-        {
-            Agent r0;
-            absent_agent(r0);
-            if (active) {
-                ep = s.episode[w];
-                load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), ep + 1u) * N + i0, r0);
-            }
-            RelayNxt &nb = *nbuf;
-            nb.px[lane0] = r0.px; nb.py[lane0] = r0.py; nb.heading[lane0] = r0.heading; nb.t_rem[lane0] = r0.t_rem;
-            nb.gx[lane0] = r0.gx; nb.gy[lane0] = r0.gy; nb.radius[lane0] = r0.radius; nb.pref[lane0] = r0.pref;
-            nb.flags[lane0] = r0.flags;
-        }
+        if (active) ep = s.episode[w];
         int loaded = 0;
         const int64_t a_safe = active ? a_idx0 : 0;        // (idle lanes read lane 0's actions: no branch around the loads)
         auto load_actions = [&](int upto) {                 // steps [loaded, upto) -> ring, clamped like E4 does: the loads of up to
@@ -504,6 +493,18 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         load_actions(n_steps < 8 ? n_steps : 8);            // enough for D to start; the rest follows while the loop runs
         __syncthreads();
         relay_post(&seq->act, loaded);
+        // the next scenario-pool record of every lane: two dependent trips to memory (episode -> pool index -> record) that nobody
+        // needs before the first restart, so they are taken AFTER the roles have started (D waits for nxt >= 1 when a world ends)
+        {
+            Agent r0;
+            absent_agent(r0);
+            if (active) load_pool(pool, (int64_t)pool_index(c, (uint32_t)(c.world_offset + w), ep + 1u) * N + i0, r0);
+            RelayNxt &nb = *nbuf;
+            nb.px[lane0] = r0.px; nb.py[lane0] = r0.py; nb.heading[lane0] = r0.heading; nb.t_rem[lane0] = r0.t_rem;
+            nb.gx[lane0] = r0.gx; nb.gy[lane0] = r0.gy; nb.radius[lane0] = r0.radius; nb.pref[lane0] = r0.pref;
+            nb.flags[lane0] = r0.flags;
+            relay_post(&seq->nxt, 1);
+        }
         int served = 0, idle_polls = 0;
         while (true) {
             const int ev = relay_peek(&seq->ev), fin = relay_peek(&seq->fin);
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 }
                 served += 1;
                 idle_polls = 0;
-                relay_post(&seq->nxt, served);
+                relay_post(&seq->nxt, served + 1);
                 continue;
             }
             if (loaded < n_steps && loaded < fin + kRelayActAhead) {

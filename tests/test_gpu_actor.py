@@ -62,6 +62,11 @@ def _same(a, b, what):
     (4, 500, True, False, dict(rvo_enabled=1, gen_mode=1, gen_pool_size=0, gen_min_agents=2, gen_nonlearning_fraction=0.7, gen_static_fraction=0.2,
                                gen_rvo_fraction=0.3, gen_frozen_fraction=0.3)),
     (10, 200, False, True, dict(gen_min_agents=3, gen_nonlearning_fraction=0.5, gen_static_fraction=0.1, gen_frozen_fraction=0.8, gen_pool_size=300)),
+    # full-size batches: TWO workgroups per compute unit, so a tile's env step shares its SIMD with the other tile's matrix phase --
+    # the only place a packed-float32 operand-swap pattern in the env step ever misbehaved (round 4; tools/repro_actor_case.py)
+    (4, 8192, False, False, dict(rvo_enabled=1, gen_rvo_fraction=1.0, gen_nonlearning_fraction=0.7, gen_pool_size=20000)),
+    (4, 8192, False, False, dict()),
+    (10, 4096, False, False, dict(gen_min_agents=2)),
 ])
 def test_fused_actor_equals_step_by_step(N, W, reflush, greedy, over):
     seed = 21
