@@ -7,6 +7,8 @@
 //      r  = {vx, vy} * {px, px} + {m.hi, m.lo}    v_pk_fma_f32 ... op_sel:[0,0,1] op_sel_hi:[1,0,0]
 // on changing inputs and compare both lanes with the same two dot products made by scalar v_mul_f32 / v_fma_f32; wavefronts 0..3
 // are idle or stream v_mfma_f32_16x16x32_f16.  Prints mismatches per lane half for every (partner, FILL).
+// Result on MI355X (profiles/r04_pk_opsel_hazard.txt): exact in every configuration -- the bare pair is not what trips inside the
+// fused actor kernel; the context is.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
