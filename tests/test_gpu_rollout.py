@@ -25,8 +25,10 @@ def _make(W, N, seed, **over):
     return BatchedCollisionAvoidanceEnv(W, Cfg(), seed=seed, **over)
 
 
+@pytest.mark.parametrize("fuse_env_push", ["1", "0"])      # env.step + bookkeeping as ONE launch (cavoid_step_push, the default) / as three
 @pytest.mark.parametrize("N,gen_min,nonl,reflush", [(4, 2, 0.3, True), (4, 4, 0.0, False), (10, 2, 0.2, True)])
-def test_rollout_matches_oracle(N, gen_min, nonl, reflush):
+def test_rollout_matches_oracle(N, gen_min, nonl, reflush, fuse_env_push, monkeypatch):
+    monkeypatch.setenv("CAVOID_FUSE_ENV_PUSH", fuse_env_push)
     from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
     W, steps, seed, T_MAX, GAMMA = 96, 260, 3, 20, 0.97
     env = _make(W, N, seed, gen_min_agents=gen_min, gen_nonlearning_fraction=nonl)
