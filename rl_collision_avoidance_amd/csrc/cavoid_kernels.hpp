@@ -599,6 +599,20 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
 }
 
 // Coalesced write-out of the wave's obs tile: n_floats contiguous floats starting at dst.
+// stream: the rows are written once and not read again by this launch (per-step output slots of a K-step launch): non-temporal
+// stores, so that K x 3.8 MB of output do not displace the L2's working set on their way to memory
+#ifndef CAVOID_NT_STORES
+#define CAVOID_NT_STORES 1
+#endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// (a compile-time choice per flush: behind a run-time flag per store the optimiser merges the two stores of the diamond into one
+//  plain store)
+template <bool STREAM>
+__device__ __forceinline__ void store16(float4 *p, const float4 &v) {
+    if (CAVOID_NT_STORES && STREAM) __builtin_nontemporal_store(f32x4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v *>(p));
+    else *p = v;
+}
+template <bool STREAM = false>
 __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_floats, int lane) {
     if ((n_floats & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
         const float4 *src4 = reinterpret_cast<const float4 *>(tile);
@@ -614,7 +628,7 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + 64 * u;
-                if (k < n4) dst4[k] = v[u];
+                if (k < n4) store16<STREAM>(dst4 + k, v[u]);
             }
         }
     } else {
@@ -670,7 +684,7 @@ __device__ __forceinline__ bool tournament(const Key (&key)[KK], int (&pos)[KK])
 
 // the same for a compile-time float count (the common shape: a full wavefront of rows of the default width): every
 // round but the last is unpredicated
-template <int NF>
+template <int NF, bool STREAM = false>
 __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, int lane) {
     static_assert(NF % 4 == 0, "whole float4s");
     constexpr int n4 = NF / 4, rounds = (n4 + 63) / 64;
@@ -695,7 +709,7 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
             const int r = r0 + u;
             if (r < rounds) {
                 const int k = lane + 64 * r;
-                if ((r + 1) * 64 <= n4 || k < n4) dst4[k] = v[u];
+                if ((r + 1) * 64 <= n4 || k < n4) store16<STREAM>(dst4 + k, v[u]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -716,7 +730,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
                                              const Key (&key_in)[Others<N>::K], const float (&gapf_in)[Others<N>::K], const float (*feat_in)[kFeat],
                                              uint32_t valid, float *tile,
                                              float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave,
-                                             PreFlush pre_flush = PreFlush()) {
+                                             PreFlush pre_flush = PreFlush(), bool stream_out = false) {
     constexpr int K = Others<N>::K, NO = N - 1;
     const int i = st.i;
     // PARK: the pair pass left keys and gaps in the tile region (pair_pass); they come back into registers only now
@@ -867,9 +881,15 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         constexpr bool kPlainOk = (kRows * kW) % 4 == 0, kPackedOk = (kRows * (kW + 2)) % 4 == 0;
         float *dst = obs_dst + (int64_t)p0 * ostride;
         const bool whole = rows_here == kRows && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-        if (kPlainOk && whole && ostride == kW) flush_tile_fixed<kPlainOk ? kRows * kW : 4>(tile, dst, lane);
-        else if (kPackedOk && whole && ostride == kW + 2) flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4>(tile, dst, lane);
-        else flush_tile(tile, dst, rows_here * ostride, lane);
+        if (stream_out) {                                        // (wave-uniform: a property of the launch)
+            if (kPlainOk && whole && ostride == kW) flush_tile_fixed<kPlainOk ? kRows * kW : 4, true>(tile, dst, lane);
+            else if (kPackedOk && whole && ostride == kW + 2) flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4, true>(tile, dst, lane);
+            else flush_tile<true>(tile, dst, rows_here * ostride, lane);
+        } else {
+            if (kPlainOk && whole && ostride == kW) flush_tile_fixed<kPlainOk ? kRows * kW : 4>(tile, dst, lane);
+            else if (kPackedOk && whole && ostride == kW + 2) flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4>(tile, dst, lane);
+            else flush_tile(tile, dst, rows_here * ostride, lane);
+        }
     }
     if (p0 + rpp < rows_active) wave_lds_sync();                 // the next pass overwrites the tile
     }
@@ -1390,7 +1410,8 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
     if (io.obs && !(CAVOID_SKIP & 1)) {
         CAVOID_STAMP(6);
         assemble_obs<N, kPark, kFused>(c, a, e, active, lane, st, key, gapf, feat, valid, tile,
-                        io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave);
+                        io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave, NoHook(),
+                        kLoop && io.out_step_stride != 0);
     }
     CAVOID_STAMP(7);                                        // tile flushed
     if (kLoop && n_steps > 1) wave_lds_sync();             // the next step re-stages the LDS arrays and the tile
@@ -1680,7 +1701,7 @@ __global__ void __launch_bounds__(128, 1) env_pipe_kernel(const KCfg c, const KS
             const ArrayStage<N> as{st.px, st.py, st.vx, st.vy, st.r, i, base};
             assemble_obs<N, false, false>(c, ao, e, active, lane, as, key, gapf, nullptr, rc.valid[lane], tile,
                             io.obs + ((int64_t)(k - 1) * io.out_step_stride + w0) * N * ostride, (int)worlds_here * N, ostride, packed,
-                            rc.rew[lane], rc.done[lane], wave);
+                            rc.rew[lane], rc.done[lane], wave, NoHook(), io.out_step_stride != 0);
             CAVOID_STAMP(7);
         }
         __syncthreads();

@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             };
             assemble_obs<N, false, true, ArrayStage<N>, decltype(order_last)>(cc, ao, e, active, lane, as, key, gapf, feat, valid, tile,
                                          io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_c, done_c, wave,
-                                         order_last);
+                                         order_last, io.out_step_stride != 0);
             if (active) {                                  // the step's plain outputs (behind order_last, like the rows)
                 if (!packed) {
                     io.rew[slot_w * N + a_idx0] = rew_c;
