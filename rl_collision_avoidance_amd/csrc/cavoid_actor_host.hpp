@@ -23,7 +23,9 @@ static int launch_actor(cavoid_env *e, const SplitArgs &sa, const SplitArgs &fz,
         if (dev >= 0 && dev < 64) opted_in[dev] = true;
     }
     const int64_t tiles = (e->W + e->k.wpw - 1) / e->k.wpw;
-    hipLaunchKernelGGL((actor_kernel<N, RVO, FROZEN>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, e->k, e->st, e->pool, sa, fz, rc, rs, rio, io);
+    KCfg k = e->k;
+    k.stream_obs = 0;                                        // (the tile's own policy phase reads the rows next: they stay in the L2)
+    hipLaunchKernelGGL((actor_kernel<N, RVO, FROZEN>), dim3((unsigned)tiles), dim3(256), policy_split_lds_bytes(), s, k, e->st, e->pool, sa, fz, rc, rs, rio, io);
     HIP_TRY(hipGetLastError());
     return CAVOID_OK;
 }

@@ -82,6 +82,7 @@ struct KCfg {
     int32_t rvo_lds_floats;      // per-wavefront LDS floats of the ORCA line scratch (0 unless rvo_enabled)
     int32_t park_floats;         // least size of the tile region (parked sort keys / gaps, float64 velocities, field-major scratch)
     int32_t evaluate_mode;       // game over needs EVERY agent done (EVALUATE_MODE), not only the learning ones
+    int32_t stream_obs;          // the batch's observation is larger than the L2 can hold for the next kernel (> 16 MB): one-step launches stream their rows out too
     uint32_t switches;           // kSw* bits: the rarely flipped U-switches in ONE word, tested by uniform branches that sit OUTSIDE the
                                  // unrolled hot loops (measured on the one-step launch at 4 x 8192, same box: separate scalars tested
                                  // per neighbour 7.4 us; pinned in scalar registers at the top 7.0; this form 6.3 -- round 2: 6.5)
@@ -1411,7 +1412,9 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
         CAVOID_STAMP(6);
         assemble_obs<N, kPark, kFused>(c, a, e, active, lane, st, key, gapf, feat, valid, tile,
                         io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave, NoHook(),
-                        kLoop && io.out_step_stride != 0);
+                        kLoop ? io.out_step_stride != 0 : (N > CAVOID_OCC4_MAX_N && c.stream_obs != 0));
+        // (a loop that overwrites ONE slot keeps it in the L2; the one-step kernels of up to 4 agents sit at the 128-register cliff of
+        //  four wavefronts per SIMD -- a second, streaming copy of the flush cost env_kernel<4, 1> 194 spilled registers and 4 us)
     }
     CAVOID_STAMP(7);                                        // tile flushed
     if (kLoop && n_steps > 1) wave_lds_sync();             // the next step re-stages the LDS arrays and the tile
