@@ -1425,9 +1425,11 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
         CAVOID_STAMP(6);
         assemble_obs<N, kPark, kFused>(c, a, e, active, lane, st, key, gapf, feat, valid, tile,
                         io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave, NoHook(),
-                        kLoop ? io.out_step_stride != 0 : (N > CAVOID_OCC4_MAX_N && c.stream_obs != 0));
+                        kLoop ? (io.out_step_stride != 0 && !(MODE == MODE_STEP_AUTORESET_N && N <= CAVOID_OCC4_MAX_N))
+                              : (N > CAVOID_OCC4_MAX_N && c.stream_obs != 0));
         // (a loop that overwrites ONE slot keeps it in the L2; the one-step kernels of up to 4 agents sit at the 128-register cliff of
-        //  four wavefronts per SIMD -- a second, streaming copy of the flush cost env_kernel<4, 1> 194 spilled registers and 4 us)
+        //  four wavefronts per SIMD -- a second, streaming copy of the flush cost env_kernel<4, 1> 194 spilled registers and 4 us,
+        //  and the large-batch loop env_kernel<4, MODE_STEP_AUTORESET_N> 11 more, 1771 -> 2008 us per 16 steps at 4 x 1048576)
     }
     CAVOID_STAMP(7);                                        // tile flushed
     if (kLoop && n_steps > 1) wave_lds_sync();             // the next step re-stages the LDS arrays and the tile
