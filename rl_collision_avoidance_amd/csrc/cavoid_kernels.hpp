@@ -731,7 +731,10 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
                                              const Key (&key_in)[Others<N>::K], const float (&gapf_in)[Others<N>::K], const float (*feat_in)[kFeat],
                                              uint32_t valid, float *tile,
                                              float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave,
-                                             PreFlush pre_flush = PreFlush(), bool stream_out = false) {
+                                             PreFlush pre_flush = PreFlush(), bool stream_out = false, int *prev_kept = nullptr) {
+    // prev_kept (step loops that own their tile from step to step): how many slots of this lane's row the PREVIOUS step of the
+    // launch filled -- the slots behind them are still zero in the tile, so only the slots [kept, *prev_kept) need zeroing now
+    // (none, step after step, unless the lane's world restarted or a neighbour went out of sight).  Null: every slot behind `kept`.
     constexpr int K = Others<N>::K, NO = N - 1;
     const int i = st.i;
     // PARK: the pair pass left keys and gaps in the tile region (pair_pass); they come back into registers only now
@@ -879,12 +882,14 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         // agent's, all M slots -- so float by float it was 7 M dependent iterations per step at N = 10 with 2..10 agents present.
         // (Measured and dropped there: straight-line predicated zero writes into the slots the not-kept neighbours rank at, +80
         // vector instructions per wavefront-step.)
-        for (int sl = zero_first ? M : kept; sl < M; ++sl) {
+        const int zero_to = prev_kept ? *prev_kept : M;
+        for (int sl = zero_first ? M : kept; sl < zero_to; ++sl) {
             float *z = row + 6 + 7 * sl;
 #pragma unroll
             for (int q = 0; q < 7; ++q) z[q] = 0.0f;
         }
         if (packed) { row[width] = rew_f; row[width + 1] = done_f; }   // (obs | reward | done) gather record
+        if (prev_kept) *prev_kept = kept;
     }
     wave_lds_sync();
     CAVOID_STAMP(10);                                            // rows in the LDS tile
@@ -1239,6 +1244,10 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
     }
 
     const int n_steps = kLoop ? io.n_steps : 1;
+    // (the step loops own their obs tile from step to step -- unless the time-to-impact order parks velocities in it, the ORCA /
+    //  box-generator instantiations use it as scratch, or the rows go out in several passes: then every step zeroes all it must)
+    const bool tile_persists = kLoop && !RVO && c.sort_method != CAVOID_SORT_TIME_TO_IMPACT && c.tile_rows >= lanes_used;
+    int prev_kept = c.max_other;
     bool restarted_any = false, moved_any = false;         // what the write-back after the last step must cover
     const int lane0 = lane, i0 = i, base0 = base;
     const int64_t a_idx0 = a_idx;
@@ -1426,7 +1435,8 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
         assemble_obs<N, kPark, kFused>(c, a, e, active, lane, st, key, gapf, feat, valid, tile,
                         io.obs + (slot_w + w0) * N * ostride, (int)worlds_here * N, ostride, packed, rew_f, done_f, wave, NoHook(),
                         kLoop ? (io.out_step_stride != 0 && !(MODE == MODE_STEP_AUTORESET_N && N <= CAVOID_OCC4_MAX_N))
-                              : (N > CAVOID_OCC4_MAX_N && c.stream_obs != 0));
+                              : (N > CAVOID_OCC4_MAX_N && c.stream_obs != 0),
+                        tile_persists ? &prev_kept : nullptr);
         // (a loop that overwrites ONE slot keeps it in the L2; the one-step kernels of up to 4 agents sit at the 128-register cliff of
         //  four wavefronts per SIMD -- a second, streaming copy of the flush cost env_kernel<4, 1> 194 spilled registers and 4 us,
         //  and the large-batch loop env_kernel<4, MODE_STEP_AUTORESET_N> 11 more, 1771 -> 2008 us per 16 steps at 4 x 1048576)
