@@ -72,7 +72,10 @@ def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1, slots=False, po
         acts = rng.integers(0, 11, size=(n, W, N)).astype(np.int32)
         acts[rng.random((n, W, N)) < 0.75] = 2
         per_step = slots and chunk > 1 and n == chunk
-        check_state = chunk > 1 or (t0 % 25 == 24) or t0 + n == steps
+        # (with ORCA agents the state is compared after EVERY launch: a world that leaves the oracle by 6e-8 rad -- below the
+        #  observation bar -- must be classified at the step where it happens, from states that still agreed at its start; round 4:
+        #  seen 20 steps late, the classifier was handed two states that already differed and could only say "real")
+        check_state = chunk > 1 or rvo > 0 or (t0 % 25 == 24) or t0 + n == steps
         # the launch's starting point on both sides (what a classification replays from); single-step launches without ORCA agents
         # skip the read-back on the steps whose state is not compared anyway
         start = (hip_state(), st.copy(), ep.copy()) if (rvo > 0 or check_state) else None

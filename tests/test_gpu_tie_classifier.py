@@ -23,6 +23,16 @@ def test_known_orca_ties_are_classified_as_ties(seed):
     assert r["obs"] <= 1e-5 and r["rew"] <= 1e-5, r
 
 
+def test_an_ill_conditioned_orca_programme_is_classified_as_a_tie():
+    """parity stress pass 5 (round 4; the round-3 kernels give the same): one world of 2048 in which an ORCA agent's linear
+    programme is ill-conditioned at one step -- HIP's speed and heading each land one float32 ulp from the oracle's (6e-8 rad,
+    1.6e-8 m).  No perturbed oracle answer IS HIP's, but HIP's lies inside the spread of the oracle's own answers under +-1e-13 m."""
+    import parity_stress as ps
+    r = ps.run(4, 2048, 300, 706, 0.6, 0, 1, 0.5, 1)
+    assert r["ties"] >= 1 and r["unexplained"] == 0, r
+    assert r["flag_mismatch"] == 0 and r["episode_mismatch"] == 0 and r["obs"] <= 1e-5, r
+
+
 def test_a_clean_orca_run_has_no_ties_to_excuse():
     import parity_stress as ps
     r = ps.run(4, 1024, 200, 700, 0.6, 0, 1, 0.5, 1)
