@@ -10,12 +10,16 @@
 //     (fewer for small batches, so that every SIMD has wavefronts to interleave);
 //     flat agent index a = w*N + i, so a wavefront's agents are CONTIGUOUS in every SoA field
 //     and each field is one coalesced global_load per wavefront;
-//   * post-move agent state (pos, vel, radius) is staged in LDS, wave-private, and the O(N^2)
-//     neighbour pass reads the other agents of the lane's world from there (same-world lanes
-//     read the same address -> LDS broadcast);
-//   * neighbour ordering by counting ranks (O(N^2) compares, no data-dependent control flow);
-//   * the [agents, 1+D] observation tile is assembled in LDS and leaves as 16-byte coalesced
-//     stores (a lane-owns-a-row store would touch 64 cache lines per instruction);
+//   * post-move agent state is staged in LDS, wave-private, as one 32-byte record per agent (position | float32
+//     velocity, radius), and the O(N^2) neighbour pass reads the other agents of the lane's world from there
+//     (same-world lanes read the same address -> LDS broadcast); from 6 agents per world on the records of a world
+//     are staged twice back to back, so that every neighbour address is the lane's own plus an immediate;
+//   * the pair pass makes, per neighbour, the collision test AND what the observation needs of it (gap, sort key,
+//     rotated features) while the neighbour's record is in registers;
+//   * neighbour ordering by counting ranks (O(N^2) integer compares, no data-dependent control flow);
+//   * the [agents, 1+D] observation tile is assembled in LDS and leaves as 16-byte coalesced stores (a
+//     lane-owns-a-row store would touch 64 cache lines per instruction) -- non-temporal ones where nobody in the
+//     launch reads the rows again (per-step output slots; batches whose observation exceeds the L2);
 //   * float64 arithmetic throughout (the reference env is NumPy float64; flags are threshold
 //     tests that flip on fp32 rounding), compiled with -ffp-contract=off so that everything that
 //     decides a flag, a reward branch or a sort order is the oracle's operation sequence; what
