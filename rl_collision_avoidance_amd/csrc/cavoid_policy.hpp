@@ -499,7 +499,9 @@ __global__ void __launch_bounds__(256, TRAIN ? 1 : (RT == 4 ? 2 : 4)) policy_for
                 const bool live = len_r[rt][r] > (float)t;
                 const float gi = fast_sigmoid(acc[rt][0][r]), gj = fast_tanh(acc[rt][1][r]);
                 const float gf = fast_sigmoid(acc[rt][2][r]), go = fast_sigmoid(acc[rt][3][r]);
-                const float c_new = gf * cell[rt][r] + gi * gj;
+                float keep = gf * cell[rt][r], add = gi * gj;
+                if (TRAIN) asm volatile("" : "+v"(keep), "+v"(add));   // (no packed add with swapped halves: DESIGN.md 3.7 (d))
+                const float c_new = keep + add;
                 const float tc = fast_tanh(c_new);
                 const float h_new = go * tc;
                 if (TRAIN) {                               // lane-private 32-byte records: the backward pass reads them back as is

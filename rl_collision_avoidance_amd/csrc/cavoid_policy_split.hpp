@@ -432,7 +432,12 @@ __device__ __forceinline__ int split_select_action(const float (&pj)[4], int g, 
         return idx;
     }
     // inverse CDF: #{c : cdf_c <= u * cdf_{A-1}}
-    const float t_g = (pj[0] + pj[1]) + (pj[2] + pj[3]);
+    // (the two partial sums are fenced from the final add: left alone the compiler makes it a packed add that reads its own result
+    //  with the halves swapped -- v_pk_add_f32 ... op_sel:[0,1] -- the operand pattern that misbehaved next to matrix work in the
+    //  env step, cavoid_kernels.hpp neighbour_features; same values, one scalar add)
+    float s01 = pj[0] + pj[1], s23 = pj[2] + pj[3];
+    asm volatile("" : "+v"(s01), "+v"(s23));
+    const float t_g = s01 + s23;
     float before = 0.0f, total = 0.0f;                     // sum of the lower column groups / of all four, in group order
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
