@@ -28,3 +28,11 @@ def spin():
     env.step_autoreset_n(acts, 20, slots=slots); ev.record()
     while not ev.query(): pass
 print("20-step launch + event spin: call(total), sync us", t(spin))
+# the launch's fixed cost: kernel time of a K-step launch (per-step output slots) for several K -> slope (per step) and intercept
+acts64 = torch.randint(0, 11, (64, 8192, 4), device="cuda", dtype=torch.int32)
+slots64 = env.new_step_slots(64)
+ks = [1, 2, 4, 8, 12, 16, 20, 24, 32, 48, 64]
+us = [env.kernel_time_ms(acts64, 40 * k, k, slots=slots64) * 1e3 for k in ks]
+print("K-step launch, kernel us:", {k: round(u, 2) for k, u in zip(ks, us)})
+print("  per-step slope 32 -> 64: %.3f us; intercept at K = 20: %.2f us" % ((us[-1] - us[-3]) / 32, us[6] - 20 * (us[-1] - us[-3]) / 32))
+print("env:", {k: os.environ.get(k) for k in ("ROC_ACTIVE_WAIT_TIMEOUT", "HSA_ENABLE_INTERRUPT", "HIP_FORCE_SPIN")})

@@ -24,19 +24,20 @@ def main():
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # steps per launch (stamps 2..7 = the LAST step's)
+    over = {"gen_min_agents": int(sys.argv[4])} if len(sys.argv) > 4 else {}   # worlds with gen_min..N agents present
 
     class Cfg(EnvConfig):
         def __init__(self):
             self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
             EnvConfig.__init__(self)
-    env = BatchedCollisionAvoidanceEnv(W, Cfg(), seed=7)
+    env = BatchedCollisionAvoidanceEnv(W, Cfg(), seed=7, **over)
     lib = _lib.lib()
     lib.cavoid_debug_trace.argtypes = [C.c_void_p]
     waves = (W + (64 // N) - 1) // (64 // N) + 8
     trace = torch.zeros((waves, 16), dtype=torch.int64, device="cuda")
     acts = torch.randint(0, 11, (32, W, N), device="cuda", dtype=torch.int32)
     env.reset()
-    for _ in range(3):
+    for _ in range(10):                                        # (past the first, synchronised wave of restarts)
         env.step_autoreset_n(acts)
     torch.cuda.synchronize()
     assert lib.cavoid_debug_trace(C.c_void_p(trace.data_ptr())) == 0
