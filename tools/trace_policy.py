@@ -59,7 +59,7 @@ def main():
     late = us[:, 0] > 20
     if (t[:, 12] > 0).all():
         seg = np.diff(t[:, 8:13], axis=1) / 100.0
-        print("LSTM step 1 (gemm 5 chunks, barrier, cell update, barrier) us p50:", np.round(np.median(seg, axis=0), 2).tolist())
+        print("LSTM step 1 (gemm 3 chunks, barrier, cell update, barrier) us p50:", np.round(np.median(seg, axis=0), 2).tolist())
     print("prologue us p50 %.1f; shader clock p50 %.0f MHz (s_memtime cycles / wall-clock time)" % (
         np.median((t[:, 5] - t[:, 0]) / 100.0), np.median(t[:, 6] / dur)))
     for xc in range(8):
