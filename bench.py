@@ -425,6 +425,7 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (the launcher's environment normally has it: dmabuf IPC for RCCL across processes)
     import torch
     import torch.distributed as dist
 

@@ -48,7 +48,7 @@ __host__ __device__ inline size_t actor_env_lds_bytes(int n_agents, int tile_flo
 // env.step of ONE tile by ONE wavefront + the Experience bookkeeping of the tile's slots (the env step's lane mapping: one lane
 // per slot): the statements of env_kernel<MODE_STEP_AUTORESET>, rollout_push_kernel and rollout_episode_kernel.  obs_t: the
 // observation the actions were chosen on; the step writes the next one into obs_n.
-template <int N, bool RVO>
+template <int N, bool RVO, bool EARLY>
 __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState &s, const PoolRec *pool, const RolloutCfg &rc, const RolloutState &rs,
                                                     const RolloutIO &rio_arg, const ActorIO &io, const float *obs_t, float *obs_n, double *lds_tab,
                                                     float *wbase, int lane, int64_t tile, int32_t step, int blk) {
@@ -61,19 +61,28 @@ __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState 
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = w0 + lw, a = w * N + i;
     const bool in_range = lane < wpw * N && w < c.num_worlds;
-    // (measured and dropped: the bookkeeping's two dependent reads -- the slot's counters, then its pending rewards -- issued under
-    //  the env step through a hook in env_tile; every lane then loads its pending rewards every step instead of the flushing lanes
-    //  once per T_max steps: actor loop 41.4 -> 49.8 us per env step, step_push 15.3 -> 23.3 us)
+    // The bookkeeping's first trip to memory -- the slot's counters, is_learning of the state acted on, the policy's value and action:
+    // nothing the env step changes -- is issued in front of the env step and lands under it.  (Measured and dropped: ALSO its second
+    // trip, the pending rewards, issued under the env step through a hook in env_tile; every lane then loads its pending rewards
+    // every step instead of the flushing lanes once per T_max steps: actor loop 41.4 -> 49.8 us per env step, step_push 15.3 -> 23.3 us.)
+    // EARLY = false: the instantiations whose env step has no eight registers to spare across it (the fused actor kernel's 256-register
+    // budget with many agents per world) keep the reads behind the step.
+    RolloutSlot slot_in{0, 0, false, 0.0};
+    float learn_f = 0.0f, value = 0.0f;                                // is_learning of the state acted on (ProcessAgent.py:130)
+    int action = 0;
+    auto first_trip = [&]() {
+        slot_in = rollout_slot_load(rs, a, in_range);
+        if (in_range) { learn_f = obs_t[a * ow]; value = io.values[a]; action = io.actions[a]; }
+    };
+    if (EARLY) first_trip();
     env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
-    const bool learning = in_range && obs_t[a * ow] > 0.5f;          // is_learning of the state acted on (ProcessAgent.py:130)
+    if (!EARLY) first_trip();
+    const bool learning = in_range && learn_f > 0.5f;
     const int base = lane < wpw * N ? lw * N : 0;
     const int n_learning = __popcll(__ballot(learning) & (((1ull << N) - 1ull) << base));
-    float value = 0.0f;
-    int action = 0;
-    if (in_range) { value = io.values[a]; action = io.actions[a]; }
     RolloutIO rio = rio_arg;
     rollout_push_slot(rc, rs, rio, a, in_range ? w : 0, i, in_range, learning, n_learning, so.done, so.game_over, so.reward, value,
-                      action, step, blk);
+                      action, step, blk, slot_in);
     // episode_log_q.put: the totals above were accumulated with atomics by this wavefront's own lanes -- drain them;
     // rollout_close_episode reads the sums at the cache the atomics went to
     if (__ballot(in_range && so.game_over) != 0ull) {
@@ -170,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
 
         if (wave_in_block == 0) {
             // ---- env.step of the tile, then the Experience bookkeeping of its slots ---------------------------------------
-            actor_env_push_tile<N, RVO>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, lds_tab, wbase, lane, tile, step, blk);
+            actor_env_push_tile<N, RVO, (N <= (RVO ? 9 : 13))>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, lds_tab, wbase, lane, tile, step, blk);
         } else {
             // ---- meanwhile: the step's state rows -> the time-major experience store -----------------------------------------
             rollout_copy_rows(rc, obs_t, rio_arg.x, a0, rows, blk, tid - 64, 192);
@@ -207,7 +216,7 @@ __global__ void __launch_bounds__(256) step_push_kernel(const KCfg c, const KSta
     const int per_wave_floats = lds_floats_fixed(N) + tile_floats + c.rvo_lds_floats;
     double *lds_tab = reinterpret_cast<double *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + lds_floats_block() + (size_t)wave_in_block * per_wave_floats;
-    actor_env_push_tile<N, RVO>(c, s, pool, rc, rs, rio_arg, io, io.obs[0], io.obs[1], lds_tab, wbase, lane, tile, step, blk);
+    actor_env_push_tile<N, RVO, true>(c, s, pool, rc, rs, rio_arg, io, io.obs[0], io.obs[1], lds_tab, wbase, lane, tile, step, blk);
 }
 
 #ifdef CAVOID_ACTOR_KERNELS      /* the non-template kernel is compiled by cavoid_actor.hip only */

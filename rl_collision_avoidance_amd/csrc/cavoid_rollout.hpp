@@ -102,15 +102,22 @@ __device__ __forceinline__ void rollout_copy_rows(const RolloutCfg &c, const flo
 // One slot's bookkeeping for one env step (ProcessAgent.run_episode's body for agent i of world w, :149-211): the append, the
 // flush rule, the backward n-step return, the episode totals.  Inputs are VALUES (the stand-alone kernel reads them from the
 // step's output tensors, the fused actor kernel has them in registers); the rings are written in place.
+// (the slot's counters are VALUES too: rollout_slot_load reads them -- the fused kernels issue that read in front of the env step,
+//  so that the bookkeeping's first trip to memory runs under it)
+struct RolloutSlot { int len, since; bool trained; double score; };
+__device__ __forceinline__ RolloutSlot rollout_slot_load(const RolloutState &s, int64_t a, bool in_range) {
+    RolloutSlot q{0, 0, false, 0.0};
+    if (in_range) { q.len = s.len[a]; q.since = s.since_flush[a]; q.trained = s.trained[a] != 0; q.score = s.score[a]; }
+    return q;
+}
 __device__ __forceinline__ void rollout_push_slot(const RolloutCfg &c, const RolloutState &s, const RolloutIO &io, int64_t a, int64_t w, int i,
                                                   bool in_range, bool learning, int n_learning, bool done, bool over, float reward,
-                                                  float value, int action, int32_t step, int blk) {
+                                                  float value, int action, int32_t step, int blk, const RolloutSlot &slot_in) {
     const int D = c.obs_width - 1, L = c.time_max + 1, RL = c.ring_len;
     const int64_t slots = c.num_slots;
-    int len = 0, since = 0;
-    bool trained = false;
-    double score = 0.0;
-    if (in_range) { len = s.len[a]; since = s.since_flush[a]; trained = s.trained[a] != 0; score = s.score[a]; }
+    int len = slot_in.len, since = slot_in.since;
+    bool trained = slot_in.trained;
+    double score = slot_in.score;
     const bool was_trained = trained;
 
     int n_rows = 0;            // rows of the main chunk
@@ -228,13 +235,16 @@ __device__ __forceinline__ void rollout_push_slot(const RolloutCfg &c, const Rol
 
 // close a finished episode of world w: episode_log_q.put((now, total_reward, total_length)) (:243)
 __device__ __forceinline__ void rollout_close_episode(const RolloutCfg &c, const RolloutState &s, const RolloutIO &io, int64_t w) {
+    // (read where the flush atomics accumulated them: agent-scope loads go to the L2, not to a stale L1 line -- the fused
+    //  actor kernel closes an episode in the launch, and on the CU, that has just added to these totals.  Issued in front of the
+    //  log slot's returning atomic: one trip to the L2 instead of two in a row)
+    const double total_reward = __hip_atomic_load(s.ep_reward + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int total_length = __hip_atomic_load(s.ep_length + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int slot = atomicAdd(io.ep_count, 1);
     if (slot < c.ep_capacity) {
         io.ep_out[3 * slot + 0] = (float)w;
-        // (read where the flush atomics accumulated them: agent-scope loads go to the L2, not to a stale L1 line -- the fused
-        //  actor kernel closes an episode in the launch, and on the CU, that has just added to these totals)
-        io.ep_out[3 * slot + 1] = (float)__hip_atomic_load(s.ep_reward + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        io.ep_out[3 * slot + 2] = (float)__hip_atomic_load(s.ep_length + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        io.ep_out[3 * slot + 1] = (float)total_reward;
+        io.ep_out[3 * slot + 2] = (float)total_length;
     } else {
         atomicAdd(io.ep_count + 1, 1);
     }
@@ -277,7 +287,7 @@ __global__ void __launch_bounds__(256) rollout_push_kernel(const RolloutCfg c, c
         // are adjacent lanes but may straddle a wavefront edge, so read the is_learning column directly
         for (int k = 0; k < N; ++k) n_learning += io.prev_obs[(w * N + k) * c.obs_width] > 0.5f ? 1 : 0;
     }
-    rollout_push_slot(c, s, io, a, w, i, in_range, learning, n_learning, done, over, reward, value, action, step, blk);
+    rollout_push_slot(c, s, io, a, w, i, in_range, learning, n_learning, done, over, reward, value, action, step, blk, rollout_slot_load(s, a, in_range));
 }
 
 // second, tiny pass (one lane per world, after the push kernel): close finished episodes.
