@@ -27,6 +27,9 @@
 
 namespace cavoid {
 
+#ifndef CAVOID_COPY_U
+#define CAVOID_COPY_U 32        // loads in flight per lane of step_push_kernel's row-copy wavefronts
+#endif
 struct ActorIO {
     float *obs[2];            // [W,N,1+D] each: step t acts on obs[t & 1]; the env writes the next observation into obs[(t+1) & 1]
     float *rewards;           // [W,N]   the env's step outputs; after the launch they hold the LAST step's
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(256) step_push_kernel(const KCfg c, const KSta
         const int64_t a0 = tile * c.wpw * N;
         int64_t worlds_here = c.num_worlds - tile * c.wpw;
         worlds_here = worlds_here > c.wpw ? c.wpw : (worlds_here < 0 ? 0 : worlds_here);
-        rollout_copy_rows(rc, io.obs[0], rio_arg.x, a0, (int)worlds_here * N, blk, lane, 64);
+        rollout_copy_rows<CAVOID_COPY_U>(rc, io.obs[0], rio_arg.x, a0, (int)worlds_here * N, blk, lane, 64);
         return;
     }
     const int tile_need = (c.tile_rows * c.width + 3) & ~3;

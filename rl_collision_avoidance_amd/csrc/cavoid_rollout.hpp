@@ -76,6 +76,9 @@ constexpr int kMaxRing = 32;   // T_max + 1 <= 32: the backward pass runs in reg
 
 // the step's state rows -> x[blk]: a coalesced sweep of `rows` contiguous slots starting at slot a0 by the `nlanes` lanes
 // (lane = 0 .. nlanes-1) of the caller's group (a wavefront; the fused actor kernel uses three)
+// U loads in flight per lane, then U stores: every round is a dependent trip to memory for the copying wavefront (a wavefront alone
+// with a tile of 10-agent worlds: 4080 values = 8 rounds at U = 8)
+template <int U = 8>
 __device__ __forceinline__ void rollout_copy_rows(const RolloutCfg &c, const float *prev_obs, float *x, int64_t a0, int rows, int blk,
                                                   int lane, int nlanes) {
     const int D = c.obs_width - 1;
@@ -83,16 +86,16 @@ __device__ __forceinline__ void rollout_copy_rows(const RolloutCfg &c, const flo
     const uint32_t inv_d = (uint32_t)((1ull << 32) / (uint32_t)D) + 1u;   // idx / D by multiply-shift (idx < 2^16)
     const float *src = prev_obs + a0 * c.obs_width;
     float *dst = x + ((int64_t)blk * c.num_slots + a0) * D;
-    for (int i0 = lane; i0 < total; i0 += nlanes * 8) {          // 8 loads in flight per lane, then 8 stores
-        float v[8];
+    for (int i0 = lane; i0 < total; i0 += nlanes * U) {
+        float v[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int idx = i0 + nlanes * u;
             const int r = (int)(((uint64_t)(uint32_t)idx * inv_d) >> 32), q = idx - r * D;
             v[u] = idx < total ? src[r * c.obs_width + 1 + q] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int idx = i0 + nlanes * u;
             if (idx < total) dst[idx] = v[u];
         }

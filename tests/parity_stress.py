@@ -2,6 +2,7 @@
 """Large seeded parity sweep: HIP path vs the float64 C oracle over many seeds / shapes, counting flag
 mismatches (must be 0) and the worst observation / reward / state deviation.  Evidence for DESIGN.md."""
 import json
+import collections
 import os
 import sys
 import time
@@ -51,6 +52,8 @@ def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1, slots=False, po
     width = env.obs_width
     OBS_BAR, STATE_BAR = 1e-5, 1e-9
     suspects = set()                                       # worlds that left the oracle inside the current launch
+    # (worlds with ORCA agents: the oracle's states and the actions of the last launches, for the classifier's drift test)
+    history = collections.deque(maxlen=max(1, 32 // max(chunk, 1)))
 
     def hip_state():
         f64, f32, fl = [x.cpu().numpy() for x in env.get_state()]
@@ -102,7 +105,8 @@ def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1, slots=False, po
             verdict, at = "real", -1
             if start is not None:
                 (h64, h32, hfl, hep0), st0, ep0 = start
-                verdict, at = classify_divergence(make_env, ocfg, ogen, seed, N, w, (h64[:, sl], h32[:, sl], hfl[sl], hep0[w]), st0, ep0, acts[:, w])
+                verdict, at = classify_divergence(make_env, ocfg, ogen, seed, N, w, (h64[:, sl], h32[:, sl], hfl[sl], hep0[w]), st0, ep0, acts[:, w],
+                                                  history=list(history) if rvo > 0 else None)
             print("   world %d left the oracle in the launch at step %d: %s (first diverging step %d)" % (w, t0, verdict, t0 + at), flush=True)
             if verdict == "tie":
                 worst["ties"] += 1
@@ -110,6 +114,9 @@ def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1, slots=False, po
                 st.f64[:, sl], st.f32[:, sl], st.flags[sl], ep[w] = f64[:, sl], f32[:, sl], fl[sl], hep[w]
             else:
                 worst["unexplained"] += 1
+                if end is not None:                        # counted once: the oracle's copy goes on from HIP's (the run has failed anyway)
+                    f64, f32, fl, hep = end
+                    st.f64[:, sl], st.f32[:, sl], st.flags[sl], ep[w] = f64[:, sl], f32[:, sl], fl[sl], hep[w]
         if end is not None:
             f64, f32, fl, hep = end
             worst["flag_mismatch"] += int((fl != st.flags).sum())
@@ -118,6 +125,8 @@ def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1, slots=False, po
             if worst["flag_mismatch"] or worst["episode_mismatch"]:        # an unexplained world stays wrong: re-synchronise so that it is counted once
                 st.f64[:], st.f32[:], st.flags[:], ep[:] = f64, f32, fl, hep
         suspects.clear()
+        if rvo > 0 and start is not None:
+            history.append((start[1], start[2], acts))
     env.close()
     worst["agent_steps"] = int(W * N * steps)
     return worst

@@ -2,6 +2,8 @@
 arguments a test hands to ``BatchedCollisionAvoidanceEnv``, and the replay of recorded per-step inputs through
 ``oracle/rollout_oracle.run_episode`` (itself bit-pinned to the reference's own ``ProcessAgent``,
 /root/reference/ga3c/GA3C/ProcessAgent.py:105-211) against the rows a device-side rollout emitted."""
+import os
+
 import numpy as np
 
 from oracle import c_oracle as co
@@ -105,7 +107,40 @@ def replay_rollout(rec, rows, episodes, reflush, gamma, t_max):
 
 
 # ---- ties of a scripted policy vs real divergences -------------------------------------------------------------------------
-def classify_divergence(make_env, ocfg, ogen, seed, N, w, hip0, st0, ep0, acts_w, trials=63, eps=1e-13, pos_tol=1e-9):
+def _explain(ocfg, ogen, seed, w, N, pre_s, pre_e, a, s, e, h, spread, eps, trials):
+    """Diagnostics of a divergence the classifier calls real (CAVOID_STRESS_EXPLAIN=1): per agent, how far HIP's post-step state is from
+    the oracle's; the oracle's action BEFORE its float32 cast (the step re-run with actions_fp32 = 0) and how close it sits to a
+    float32 rounding boundary; how far +-eps moves that un-cast action (the conditioning of the agent's programme)."""
+    h64, h32, hfl, hep = h
+    pol = (pre_s.flags >> 8) & 7
+    print("      flags equal %s, episode equal %s; oracle's own spread under +-%g: %.3g" % (np.array_equal(hfl, s.flags), np.array_equal(hep, e), eps, spread))
+    o2 = type(ocfg).from_buffer_copy(ocfg)
+    o2.actions_fp32 = 0
+    s64, e64 = pre_s.copy(), pre_e.copy()
+    co.step_autoreset(o2, ogen, seed, s64, e64, a, world_offset=w)
+    wrap = lambda x: (x + np.pi) % (2 * np.pi) - np.pi
+    prng = np.random.default_rng(2)
+    moved = np.zeros(N)
+    for _ in range(trials):
+        s2, e2 = pre_s.copy(), pre_e.copy()
+        s2.f64[0] += prng.choice([-eps, eps], N); s2.f64[1] += prng.choice([-eps, eps], N); s2.f64[2] += prng.choice([-eps, 0.0, eps], N)
+        co.step_autoreset(o2, ogen, seed, s2, e2, a, world_offset=w)
+        moved = np.maximum(moved, np.abs(wrap(s2.f64[2] - s64.f64[2])))
+    for j in range(N):
+        d = [float(h64[0, j] - s.f64[0, j]), float(h64[1, j] - s.f64[1, j]), float(wrap(h64[2, j] - s.f64[2, j]))]
+        if max(abs(x) for x in d) == 0.0:
+            continue
+        a1 = float(wrap(s64.f64[2, j] - pre_s.f64[2, j]))                       # the oracle's heading change, not cast to float32
+        f = np.float32(a1)
+        other = np.nextafter(f, np.float32(np.inf if a1 > float(f) else -np.inf))
+        mid, ulp = 0.5 * (float(f) + float(other)), abs(float(other) - float(f))
+        a1_o, a1_h = float(wrap(s.f64[2, j] - pre_s.f64[2, j])), float(wrap(h64[2, j] - pre_s.f64[2, j]))
+        print("      agent %d policy %d: HIP - oracle  dpx %.3g dpy %.3g dheading %.3g;  heading change: oracle un-cast %.17g, oracle %.9g, HIP %.9g "
+              "(float32 ulp %.3g; un-cast value %.3g ulp from the rounding boundary; +-eps moves it by %.3g rad)"
+              % (j, pol[j], d[0], d[1], d[2], a1, a1_o, a1_h, ulp, abs(a1 - mid) / ulp, moved[j]))
+
+
+def classify_divergence(make_env, ocfg, ogen, seed, N, w, hip0, st0, ep0, acts_w, trials=63, eps=1e-13, pos_tol=1e-9, history=None):
     """A world whose HIP results left the oracle's: is it a TIE of the ORCA linear programme (the optimal velocity jumps between
     two vertices of the feasible region when the positions move by the ~1e-13 m the two transcendental libraries differ by anyway),
     or a real difference between the two implementations?  Decided by code, not by hand:
@@ -126,6 +161,13 @@ def classify_divergence(make_env, ocfg, ogen, seed, N, w, hip0, st0, ep0, acts_w
                       scenarios, world 161, the round-3 kernels too): HIP's answer is then none of the oracle's perturbed answers
                       but lies INSIDE their spread (same flags, same episode, no further from the oracle than +-eps moves the
                       oracle itself);
+                      -- or, with ``history`` (the oracle's whole-batch states and the actions of the launches BEFORE this one,
+                      oldest first: [(st, ep, acts [n, W, N]), ...]), inside the spread of the oracle's own trajectories started
+                      ``eps`` apart at the oldest of those launches and rolled through the same actions to the diverging step:
+                      a DRIFT -- several moderately ill-conditioned steps in a row (each amplifying by 10 .. 100) carry the
+                      libraries' 1e-16 past ``pos_tol`` without any single step being a jump; the one-step test then sees
+                      two pre-step states that already differ by 1e-10 and an innocent step (seen twice in 5.9 G agent-steps:
+                      stress passes 30 .. 59, N = 10 box scenarios with ORCA agents, seeds 844 / 851);
       ("real", step)  anything else -- including a world without such an agent, whatever the perturbations say;
       ("none", -1)    the replay shows no divergence (the batch-level mismatch was not reproduced: treat as real).
     ``make_env(num_worlds, world_offset)`` builds a HIP env configured like the one under test."""
@@ -180,6 +222,38 @@ def classify_divergence(make_env, ocfg, ogen, seed, N, w, hip0, st0, ep0, acts_w
             if (np.array_equal(hfl, s.flags) and np.array_equal(hep, e) and np.array_equal(h32[:4], s.f32[:4])
                     and float(np.abs(h64[:3] - s.f64[:3]).max()) <= spread):
                 return "tie", k
+            # a DRIFT: the oracle against itself over the launches before this one (see the docstring)
+            if history and np.array_equal(hfl, s.flags) and np.array_equal(hep, e) and np.array_equal(h32[:4], s.f32[:4]):
+                def roll(hist, perturb):
+                    st_h, ep_h0, _ = hist[0]
+                    s2 = co.State(st_h.f64[:, sl].copy(), st_h.f32[:, sl].copy(), st_h.flags[sl].copy())
+                    e2 = np.array([ep_h0[w]], np.uint32)
+                    if perturb:
+                        s2.f64[0] += prng.choice([-eps, eps], N)
+                        s2.f64[1] += prng.choice([-eps, eps], N)
+                        s2.f64[2] += prng.choice([-eps, 0.0, eps], N)
+                    for _, _, acts_l in hist:
+                        for kk in range(acts_l.shape[0]):
+                            co.step_autoreset(ocfg, ogen, seed, s2, e2, np.ascontiguousarray(acts_l[kk, w], np.int32).reshape(1, N), world_offset=w)
+                    for kk in range(k + 1):
+                        co.step_autoreset(ocfg, ogen, seed, s2, e2, np.ascontiguousarray(acts_w[kk], np.int32).reshape(1, N), world_offset=w)
+                    return s2, e2
+                # the longest stretch of history from which the oracle reproduces its own state bit for bit (the stress re-synchronises
+                # the oracle's copy of a world to HIP's after a tie: a stretch across such a point is not the oracle's trajectory)
+                for j in range(len(history)):
+                    s2, e2 = roll(history[j:], False)
+                    if np.array_equal(s2.f64, s.f64) and np.array_equal(s2.flags, s.flags) and np.array_equal(e2, e):
+                        far = 0.0
+                        for _ in range(trials):
+                            s2, e2 = roll(history[j:], True)
+                            if np.array_equal(s2.flags, s.flags) and np.array_equal(e2, e):
+                                far = max(far, float(np.abs(s2.f64[:3] - s.f64[:3]).max()))
+                        if float(np.abs(h64[:3] - s.f64[:3]).max()) <= far:
+                            return "tie", k
+                        spread = max(spread, far)
+                        break
+            if os.environ.get("CAVOID_STRESS_EXPLAIN"):
+                _explain(ocfg, ogen, seed, w, N, pre_s, pre_e, a, s, e, h, spread, eps, trials)
             return "real", k
         return "none", -1
     finally:

@@ -2,14 +2,14 @@
 repo=$PWD; export TMPDIR=/tmp
 if [ -z "$SKIP_ACTOR" ]; then
 for rep in 1 2 3; do
-  for v in base pf pf2; do
+  for v in pf2 cu32; do
     CAVOID_LIB=$repo/.ab/lib$v.so python tools/actbench.py 8192 4 16 2>&1 | grep steps_per | sed "s/^/$v N=4  /"
     CAVOID_LIB=$repo/.ab/lib$v.so python tools/actbench.py 8192 10 16 2>&1 | grep steps_per | sed "s/^/$v N=10 /"
   done
 done
 fi
 for rep in 1 2; do
-for v in base pf pf2; do
+for v in pf2 cu32; do
   for n in 4 10; do
     rm -rf /tmp/rp_$v$n; mkdir -p /tmp/rp_$v$n
     (cd /tmp && CAVOID_LIB=$repo/.ab/lib$v.so timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_$v$n -o x -- python $repo/tools/robench.py 8192 $n 600 > /dev/null 2>&1)
