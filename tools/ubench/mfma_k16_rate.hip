@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int KIND>
 __global__ void __launch_bounds__(256) stream(float *out, long long *clk, int iters) {
     f32x4 acc[16];
-    for (int k = 0; k < 16; ++k) acc[k] = f32x4{1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (int k = 0; k < 16; ++k) acc[k] = f32x4{1.f + k, 2.f * k, 3.f - k, (float)(threadIdx.x + k)};   // (distinct: identical chains would be merged)
     f16x8 a8, b8; f16x4 a4, b4;
     for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(0.5f + e); b8[e] = (_Float16)(0.25f * e); }
     for (int e = 0; e < 4; ++e) { a4[e] = a8[e]; b4[e] = b8[e]; }
@@ -18,12 +18,13 @@ __global__ void __launch_bounds__(256) stream(float *out, long long *clk, int it
     for (int it = 0; it < iters; ++it)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            if (KIND == 32) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[k], 0, 0, 0);
-            else acc[k] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[k], 0, 0, 0);
+            // (inline asm: left to the compiler the accumulators wander between register files inside the loop)
+            if (KIND == 32) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a8), "v"(b8));
+            else asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a4), "v"(b4));
         }
     const long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0;
-    for (int k = 0; k < 16; ++k) s += acc[k][0];
+    for (int k = 0; k < 16; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
