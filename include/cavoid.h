@@ -223,13 +223,23 @@ int cavoid_step_autoreset_packed(cavoid_env *env, const int32_t *actions, int64_
  * `producer_stream` (the step that wrote `send`); it returns at once.  cavoid_gather_wait(slot) makes a stream wait
  * for the last gather begun in that slot (no host synchronisation).  Two slots: with send / recv double-buffered and
  * slot = t % 2, step t+1 (writing the other buffer) overlaps gather t; before step t+2 re-uses the buffers the
- * producer stream waits on the slot.  With nranks == 1 the gather is a device copy.
+ * producer stream waits on the slot.  With nranks == 1 the gather is a device copy (unless CAVOID_COMM_FORCE_RCCL, below).
  * Errors: CAVOID_ECOMM (see cavoid_last_comm_error). */
 typedef struct cavoid_comm cavoid_comm;
 #define CAVOID_COMM_ID_BYTES 128
 #define CAVOID_COMM_SLOTS 2
 int cavoid_comm_unique_id(void *id_out);
 int cavoid_comm_create(const void *unique_id, int32_t nranks, int32_t rank, int device, cavoid_comm **out);
+/* flags: CAVOID_COMM_FORCE_RCCL = a ONE-rank communicator is a real RCCL communicator too (ncclCommInitRank with nranks = 1;
+ * cavoid_gather_begin issues ncclAllGather, cavoid_gatherv_begin a grouped ncclSend / ncclRecv to itself) instead of the device
+ * copy -- a development switch that lets a 1-GPU box execute the very calls a multi-rank communicator makes.  unique_id may be
+ * NULL for one rank (an id is made internally).  cavoid_comm_create = this with flags 0, or CAVOID_COMM_FORCE_RCCL when the
+ * environment variable CAVOID_COMM_FORCE_RCCL is set to anything but "" / "0".  Unknown flag bits: CAVOID_EINVAL. */
+#define CAVOID_COMM_FORCE_RCCL 1u
+int cavoid_comm_create_ex(const void *unique_id, int32_t nranks, int32_t rank, int device, uint32_t flags, cavoid_comm **out);
+/* what the handle is: any of the out pointers may be NULL.  uses_rccl = 1 when the gathers go through RCCL (0 = one rank, device
+ * copy); rccl_version = ncclGetVersion() of the library bound (0 when uses_rccl is 0). */
+int cavoid_comm_info(const cavoid_comm *comm, int32_t *nranks, int32_t *rank, int32_t *uses_rccl, int32_t *rccl_version);
 void cavoid_comm_destroy(cavoid_comm *comm);
 int cavoid_gather_begin(cavoid_comm *comm, int32_t slot, const float *send, float *recv, int64_t floats_per_rank,
                         void *producer_stream);

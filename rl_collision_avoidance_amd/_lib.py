@@ -22,6 +22,7 @@ F_POLICY_SHIFT = 8
 F_POLICY_MASK = 7
 POLICY_EXTERNAL, POLICY_STATIC, POLICY_NONCOOP, POLICY_RVO, POLICY_FROZEN_NET = 0, 1, 2, 3, 4
 F_DONE_MASK = 7
+COMM_FORCE_RCCL = 1
 
 
 class CavoidCfg(C.Structure):
@@ -113,6 +114,8 @@ SYMBOLS = [
     ("cavoid_step_autoreset_packed", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P]),
     ("cavoid_comm_unique_id", C.c_int, [_P]),
     ("cavoid_comm_create", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int, C.POINTER(_P)]),
+    ("cavoid_comm_create_ex", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int, C.c_uint32, C.POINTER(_P)]),
+    ("cavoid_comm_info", C.c_int, [_P] + [C.POINTER(C.c_int32)] * 4),
     ("cavoid_comm_destroy", None, [_P]),
     ("cavoid_gather_begin", C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, _P]),
     ("cavoid_gatherv_begin", C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(C.c_int64), C.c_int32, _P]),

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types and constants only: the library itself is bound lazily (see rccl())
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -36,6 +37,9 @@ struct RcclApi {
     ncclResult_t (*gather_recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*group_start)(void);
     ncclResult_t (*group_end)(void);
+    ncclResult_t (*get_version)(int *);
+    ncclResult_t (*comm_count)(const ncclComm_t, int *);
+    ncclResult_t (*comm_user_rank)(const ncclComm_t, int *);
 };
 static const RcclApi *rccl() {
     static RcclApi api{};
@@ -53,6 +57,7 @@ static const RcclApi *rccl() {
         bind(api.get_unique_id, "ncclGetUniqueId"); bind(api.comm_init_rank, "ncclCommInitRank"); bind(api.comm_destroy, "ncclCommDestroy");
         bind(api.all_gather, "ncclAllGather"); bind(api.gather_send, "ncclSend"); bind(api.gather_recv, "ncclRecv");
         bind(api.group_start, "ncclGroupStart"); bind(api.group_end, "ncclGroupEnd");
+        bind(api.get_version, "ncclGetVersion"); bind(api.comm_count, "ncclCommCount"); bind(api.comm_user_rank, "ncclCommUserRank");
         state = ok ? 1 : -1;
     }
     return state == 1 ? &api : nullptr;
@@ -73,7 +78,7 @@ static const RcclApi *rccl() {
 struct cavoid_comm {
     int device = 0;
     int32_t nranks = 1, rank = 0;
-    ncclComm_t comm = nullptr;      // null when nranks == 1 (the gather is a device copy)
+    ncclComm_t comm = nullptr;      // null when nranks == 1 and RCCL was not forced (the gather is then a device copy)
     hipStream_t stream = nullptr;   // the communicator's own stream
     hipEvent_t ev_ready[CAVOID_COMM_SLOTS] = {}, ev_done[CAVOID_COMM_SLOTS] = {};
     bool pending[CAVOID_COMM_SLOTS] = {};
@@ -90,9 +95,19 @@ extern "C" int cavoid_comm_unique_id(void *id_out) {
     return CAVOID_OK;
 }
 
-extern "C" int cavoid_comm_create(const void *unique_id, int32_t nranks, int32_t rank, int device, cavoid_comm **out) {
+// CAVOID_COMM_FORCE_RCCL (flag, or the environment variable of the same name for cavoid_comm_create): a ONE-rank communicator goes
+// through ncclCommInitRank / ncclAllGather / the grouped self send-recv too instead of the device copy -- the same calls a
+// multi-rank communicator makes, so that a 1-GPU box executes the binding, the stream protocol and the RCCL entry points.
+static bool force_rccl_env() {
+    const char *v = std::getenv("CAVOID_COMM_FORCE_RCCL");
+    return v && v[0] && !(v[0] == '0' && !v[1]);
+}
+
+extern "C" int cavoid_comm_create_ex(const void *unique_id, int32_t nranks, int32_t rank, int device, uint32_t flags, cavoid_comm **out) {
     if (!out) return CAVOID_EINVAL;
     *out = nullptr;
+    if (flags & ~(uint32_t)CAVOID_COMM_FORCE_RCCL) return CAVOID_EINVAL;
+    const bool with_rccl = nranks > 1 || (flags & CAVOID_COMM_FORCE_RCCL);
     if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !unique_id)) return CAVOID_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CAVOID_ENODEVICE;
@@ -109,19 +124,49 @@ extern "C" int cavoid_comm_create(const void *unique_id, int32_t nranks, int32_t
         cavoid_comm_destroy(c);
         return CAVOID_EHIP;
     }
-    if (nranks > 1) {
-        ncclUniqueId id;
-        std::memcpy(&id, unique_id, sizeof(id));
+    if (with_rccl) {
         const RcclApi *api = rccl();
-        ncclResult_t r = api ? api->comm_init_rank(&c->comm, nranks, id, rank) : ncclSystemError;
+        ncclUniqueId id;
+        ncclResult_t r = api ? ncclSuccess : ncclSystemError;
+        if (r == ncclSuccess) {
+            if (unique_id) std::memcpy(&id, unique_id, sizeof(id));
+            else r = api->get_unique_id(&id);                  // (forced one-rank communicator without an id: make one here)
+        }
+        if (r == ncclSuccess) r = api->comm_init_rank(&c->comm, nranks, id, rank);
+        int n = -1, me = -1;
+        if (r == ncclSuccess) r = api->comm_count(c->comm, &n);
+        if (r == ncclSuccess) r = api->comm_user_rank(c->comm, &me);
+        if (r == ncclSuccess && (n != nranks || me != rank)) r = ncclInternalError;     // the communicator is not the one asked for
         if (r != ncclSuccess) {
             g_last_comm_error = (int)r;
+            if (c->comm) (void)api->comm_destroy(c->comm);
             c->comm = nullptr;
             cavoid_comm_destroy(c);
             return CAVOID_ECOMM;
         }
     }
     *out = c;
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_comm_create(const void *unique_id, int32_t nranks, int32_t rank, int device, cavoid_comm **out) {
+    return cavoid_comm_create_ex(unique_id, nranks, rank, device, force_rccl_env() ? CAVOID_COMM_FORCE_RCCL : 0u, out);
+}
+
+extern "C" int cavoid_comm_info(const cavoid_comm *c, int32_t *nranks, int32_t *rank, int32_t *uses_rccl, int32_t *rccl_version) {
+    if (!c) return CAVOID_EINVAL;
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
+    if (uses_rccl) *uses_rccl = c->comm != nullptr;
+    if (rccl_version) {
+        *rccl_version = 0;
+        if (c->comm) {
+            RCCL_OR_FAIL(api);
+            int v = 0;
+            COMM_TRY(api->get_version(&v));
+            *rccl_version = v;
+        }
+    }
     return CAVOID_OK;
 }
 
@@ -143,7 +188,7 @@ extern "C" int cavoid_gather_begin(cavoid_comm *c, int32_t slot, const float *se
     hipStream_t prod = static_cast<hipStream_t>(producer_stream);
     HIP_TRY(hipEventRecord(c->ev_ready[slot], prod));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ready[slot], 0));
-    if (c->nranks == 1) {
+    if (!c->comm) {
         if (floats_per_rank > 0 && send != recv)
             HIP_TRY(hipMemcpyAsync(recv, send, (size_t)floats_per_rank * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     } else {
@@ -174,15 +219,18 @@ extern "C" int cavoid_gatherv_begin(cavoid_comm *c, int32_t slot, const float *s
     HIP_TRY(hipEventRecord(c->ev_ready[slot], prod));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ready[slot], 0));
     const int64_t mine = counts[c->rank];
-    if (receiver && mine > 0 && send != recv + my_off)
+    // my own shard: a device copy -- except on a forced one-rank communicator, where it travels as a grouped ncclSend / ncclRecv to
+    // myself so that the point-to-point entry points really run
+    const bool self_p2p = c->comm && c->nranks == 1;
+    if (receiver && mine > 0 && send != recv + my_off && !self_p2p)
         HIP_TRY(hipMemcpyAsync(recv + my_off, send, (size_t)mine * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    if (c->nranks > 1) {
+    if (c->comm) {
         RCCL_OR_FAIL(api);
         COMM_TRY(api->group_start());
         ncclResult_t bad = ncclSuccess;
         int64_t off = 0;
         for (int p = 0; p < c->nranks; ++p) {
-            if (p != c->rank) {
+            if (p != c->rank || self_p2p) {
                 if (mine > 0 && (root < 0 || root == p)) {               // p wants my shard
                     ncclResult_t r = api->gather_send(send, (size_t)mine, ncclFloat, p, c->comm, c->stream);
                     if (r != ncclSuccess) bad = r;

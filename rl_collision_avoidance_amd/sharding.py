@@ -106,28 +106,38 @@ class NativeGather(object):
 
     SLOTS = 2
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, force_rccl: Optional[bool] = None):
+        """force_rccl: a ONE-rank communicator goes through RCCL too (`cavoid_comm_create_ex(..., CAVOID_COMM_FORCE_RCCL)`:
+        ncclCommInitRank, ncclAllGather, grouped self send / recv) instead of the device copy; None = the environment variable
+        CAVOID_COMM_FORCE_RCCL decides.  Multi-rank communicators always are RCCL communicators."""
+        import os
         from . import _lib
         self._libmod = _lib
         self._lib = _lib.lib()
         self.device = torch.device(device)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
+        if force_rccl is None:
+            force_rccl = os.environ.get("CAVOID_COMM_FORCE_RCCL", "0") not in ("", "0")
         ident = torch.zeros(128, dtype=torch.uint8)
-        if self.size > 1:
+        if self.size > 1 or force_rccl:
             if self.rank == 0:
                 buf = (C.c_ubyte * 128)()
                 _lib.check(self._lib.cavoid_comm_unique_id(buf), "cavoid_comm_unique_id")
                 ident = torch.tensor(list(buf), dtype=torch.uint8)
-            backend = dist.get_backend(group)
-            carrier = ident.to(self.device) if backend == "nccl" else ident
-            dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ident = carrier.cpu()
+            if self.size > 1:
+                backend = dist.get_backend(group)
+                carrier = ident.to(self.device) if backend == "nccl" else ident
+                dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ident = carrier.cpu()
         raw = (C.c_ubyte * 128)(*ident.tolist())
         handle = C.c_void_p()
-        _lib.check(self._lib.cavoid_comm_create(raw, self.size, self.rank, self.device.index or 0, C.byref(handle)),
-                   "cavoid_comm_create")
+        _lib.check(self._lib.cavoid_comm_create_ex(raw, self.size, self.rank, self.device.index or 0,
+                                                   _lib.COMM_FORCE_RCCL if force_rccl else 0, C.byref(handle)), "cavoid_comm_create_ex")
         self._h = handle
+        vals = [C.c_int32() for _ in range(4)]
+        _lib.check(self._lib.cavoid_comm_info(handle, *[C.byref(v) for v in vals]), "cavoid_comm_info")
+        self.uses_rccl, self.rccl_version = bool(vals[2].value), int(vals[3].value)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -175,7 +185,7 @@ class ShardedEnv(object):
     """This rank's shard of a `total_worlds`-world env (one process per GPU)."""
 
     def __init__(self, total_worlds: int, config=None, device=None, seed: int = 0, group=None, transport: Optional[str] = None,
-                 **cfg_overrides):
+                 force_rccl: Optional[bool] = None, **cfg_overrides):
         """transport: "native" = `cavoid_gather*` (RCCL behind the C ABI, own stream, overlapped) -- the default whenever the process
         group runs on nccl or there is one rank; "torch" = the same hand-over through `torch.distributed` (`gather_blocks`:
         synchronous; gloo dry runs of the N > 1 path on one device, and the only form a gloo group can carry)."""
@@ -186,6 +196,7 @@ class ShardedEnv(object):
         if transport not in ("native", "torch"):
             raise ValueError("transport must be 'native' or 'torch'")
         self.transport = transport
+        self.force_rccl = force_rccl
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.total_worlds = int(total_worlds)
@@ -219,7 +230,7 @@ class ShardedEnv(object):
         (`cavoid_gatherv_begin`)."""
         from .batched_env import StepSlots
         e = self.env
-        self._native = NativeGather(e.device, self.group) if self.transport == "native" else False
+        self._native = NativeGather(e.device, self.group, self.force_rccl) if self.transport == "native" else False
         self._steps, self._root = int(steps), int(root)
         self._counts = [shard_range(self.total_worlds, r, self.size)[1] for r in range(self.size)]
         self._even = all(c == self._counts[0] for c in self._counts)
@@ -241,6 +252,8 @@ class ShardedEnv(object):
         if self.transport == "torch":
             return "torch.distributed %s (%s)" % ("all_gather_into_tensor" if self._root < 0 else "gather to rank %d" % self._root,
                                                   dist.get_backend(self.group) if dist.is_initialized() else "single rank")
+        if not self._native.uses_rccl:
+            return "device copy on the communicator's stream (one rank; %s)" % ("cavoid_gather_begin" if self._even and self._root < 0 else "cavoid_gatherv_begin")
         if self._even and self._root < 0:
             return "ncclAllGather (cavoid_gather_begin: equal shards, every rank receives; blocks of %d step(s))" % self._steps
         return "point-to-point RCCL group (cavoid_gatherv_begin: %s shards, %s)" % (
