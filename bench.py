@@ -18,11 +18,17 @@ region; the shard-only rate is reported under "extra".  Weak scaling: every rank
 (RNG keyed on global world ids).  `python bench.py --gpus N` without a launcher starts its own N ranks
 (torch.distributed.run, 127.0.0.1).  Rank 0 prints ONE JSON line.
 
-roofline: `achieved` / `frac` are priced on the bytes the timed launch form really moves per agent-step (K-step
-launch: action in, observation row + reward + done (+ game_over) out; the world state stays in registers), `traffic`
-is the PMC measurement of the same launches, `frac_contract` keeps SURVEY section 8d's 192 / 360 B figure (which
-includes a state round trip a K-step launch does not make), and `one_step_launch` is the same set of figures for the
-closed-loop form (one step per launch: state in and out every step).
+N > 1 forms: `--gather all` (default: every rank receives every shard, configs[2]), `--gather root` (only the trainer rank
+receives), `--gather none` (shard-only: no exchange); `--gather-every K` = env steps per launch-and-gather block.  Whatever form
+`value` is, the other two are measured briefly in the same run and all three are reported under extra.configs2_gather.forms with
+their xGMI link figures (bytes per link and step, the link-bound time at 153 GB/s per link and direction, achieved fraction).
+
+roofline: `achieved` / `frac` (= `frac_contract`) are SURVEY section 8d's contract figure -- 192 / 360 algorithmic bytes per
+agent-step x the agent-steps of one launch / the launch's HIP-event duration / 8 TB/s; `achieved_moved` / `frac_moved` are priced
+on the bytes the timed launch form really moves per agent-step (K-step launch: action in, observation row + reward + done
+(+ game_over) out; the world state stays in registers: 117.25 B at N = 4), `traffic` is the PMC measurement of the same
+launches, and `one_step_launch` is the same set of figures for the closed-loop form (one step per launch: state in and out
+every step).
 """
 from __future__ import annotations
 
@@ -37,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6300 achievable
+XGMI_LINK_GBS = 153.0          # one xGMI link, one direction (7 links per GPU, fully connected mesh of 8)
 
 
 def algorithmic_bytes_per_agent_step(M: int) -> int:
@@ -397,8 +404,15 @@ def main() -> None:
     ap.add_argument("--worlds", type=int, default=8192, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--slices", type=int, default=64, help="distinct pre-generated action slices = max steps per launch")
-    ap.add_argument("--no-gather", action="store_true",
-                    help="N>1: skip the extra measurement of the per-step RCCL all-gather of (obs,reward,done) (configs[2])")
+    ap.add_argument("--gather", default="all", choices=["all", "root", "none"],
+                    help="N>1: the exchange inside the timed region -- all = every rank receives every shard's packed (obs|reward|done) records "
+                         "(configs[2]), root = only rank 0 (the trainer rank) does, none = shard-only")
+    ap.add_argument("--no-gather", action="store_true", help="= --gather none")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="N>1: env steps per launch-and-gather block (0 = the largest divisor of --steps that fits --slices)")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="N=1: put the exchange inside the timed region too, through a forced ONE-rank RCCL communicator (development: "
+                         "executes ncclAllGather / the grouped send-recv on a 1-GPU box)")
     ap.add_argument("--sweep", action="store_true", help="add a worlds-per-GPU saturation sweep to the JSON line")
     ap.add_argument("--full-loop", action="store_true",
                     help="also time BASELINE configs[4]: batched env + NetworkVP_rnn policy + rollout bookkeeping + Adam steps")
@@ -406,6 +420,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the brief configs[4] extra of the default N = 1 run")
     ap.add_argument("--no-configs3", action="store_true", help="skip the brief configs[3] (10 agents x 8192 worlds) extra")
+    ap.add_argument("--no-fresh-scenarios", action="store_true",
+                    help="skip the brief extra that times the same step with a fresh scenario generated in-kernel at every restart (no pool)")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live with rocprofv3 --pmc")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 code path)")
@@ -497,16 +513,20 @@ def main() -> None:
             done += n
 
     def form_figures(name, n_agents, Wl, spl, launch_ms, one_step):
-        """roofline figures of one launch form: priced on the bytes it really moves, the contract figure beside it"""
+        """roofline figures of one launch form: `achieved` / `frac` = SURVEY section 8d's contract bytes, `*_moved` = the bytes it
+        really moves"""
         M = n_agents - 1
         moved = moved_bytes_per_agent_step(M, n_agents, one_step) * Wl * n_agents * spl
         contract = algorithmic_bytes_per_agent_step(M) * Wl * n_agents * spl
-        achieved = moved / (launch_ms * 1e-3) / 1e9
+        achieved = contract / (launch_ms * 1e-3) / 1e9
+        achieved_moved = moved / (launch_ms * 1e-3) / 1e9
         return {"kernel": name, "steps_per_launch": spl, "kernel_us": launch_ms * 1e3, "kernel_us_per_step": launch_ms * 1e3 / spl,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_contract": achieved / HBM_PEAK_GBS,
+                "contract_bytes_per_agent_step": algorithmic_bytes_per_agent_step(M), "contract_bytes_per_launch": contract,
+                "achieved_moved": achieved_moved, "frac_moved": achieved_moved / HBM_PEAK_GBS,
                 "moved_bytes_per_agent_step": moved_bytes_per_agent_step(M, n_agents, one_step), "moved_bytes_per_launch": moved,
-                "frac_contract": contract / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "contract_bytes_per_agent_step": algorithmic_bytes_per_agent_step(M), "traffic": None}
+                "traffic": None}
 
     def bound_of(fig, Wl, n_agents):
         """what the evidence says limits the kernel: HBM only when the measured traffic really is most of the pipe"""
@@ -541,7 +561,10 @@ def main() -> None:
             form["bound"] = bound_of(form, Wl, n_agents)
 
     env, acts = make(W)
-    gather_in_metric = world_size > 1 and not args.no_gather
+    gather_mode = "none" if args.no_gather else args.gather
+    exchange_possible = world_size > 1 or args.force_rccl      # (N = 1: only as a development run through a forced RCCL communicator)
+    gather_in_metric = exchange_possible and gather_mode != "none"
+    gather_root = 0 if gather_mode == "root" else -1
     slots = None if (args.overwrite_outputs or gather_in_metric) else env.new_step_slots(min(args.slices, max(args.steps, 1)))
     sh = None
     extra = {}
@@ -551,43 +574,58 @@ def main() -> None:
     # auto-reset (part of env.step's job here) is inside the number whatever --warmup is.
     preroll = 0 if args.no_preroll else max(0, 256 - args.warmup)
     comm_status = None
-    if gather_in_metric:
+    # launches of `spl` steps: --gather-every, or the largest divisor of K that fits the action slices (K steps = whole launches)
+    spl = args.gather_every if args.gather_every > 0 else max(d for d in range(1, min(args.slices, args.steps) + 1) if args.steps % d == 0)
+    spl = max(1, min(spl, args.slices))
+    if exchange_possible and args.steps % spl:
+        raise SystemExit("--gather-every %d must divide --steps %d (the K timed steps are whole launch-and-gather blocks)" % (spl, args.steps))
+    acts_l = acts[:spl].contiguous()
+
+    def run_steps_gather(k):
+        for _ in range(-(-k // spl)):
+            sh.gathered_blocks(sh.step_and_gather(acts_l if spl > 1 else acts_l[0], root=sh._root))   # (waits for it; rank-major views, no copy)
+
+    def coll_device():
+        return device if (world_size > 1 and args.backend == "nccl") else "cpu"
+    if exchange_possible:
         try:
             # configs[2]: this rank's shard of a (world_size x W)-world env; every launch writes packed records into per-step slots
-            # and their gather to every rank is begun on the communicator's stream -- launch t+1 runs while gather t is on the wire.
-            # nccl: cavoid_gather* (RCCL behind the C ABI); gloo dry run (CPU tests / --share-device): the same blocks through
-            # torch.distributed (ShardedEnv picks the transport from the process group's backend).
+            # and their gather (to every rank, or to the trainer rank) is begun on the communicator's stream -- launch t+1 runs while
+            # gather t is on the wire.  nccl: cavoid_gather* (RCCL behind the C ABI); gloo dry run (CPU tests / --share-device): the
+            # same blocks through torch.distributed (ShardedEnv picks the transport from the process group's backend).
             from rl_collision_avoidance_amd.sharding import ShardedEnv
             env.close()
-            sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7)
+            sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7, force_rccl=True if args.force_rccl else None)
             sh.reset()
             env = sh.env
-            # launches of `spl` steps: the largest divisor of K that fits the action slices, so that K steps are whole launches
-            spl = max(d for d in range(1, min(args.slices, args.steps) + 1) if args.steps % d == 0)
-            acts_l = acts[:spl].contiguous()
-
-            def run_steps_gather(k):
-                for _ in range(-(-k // spl)):
-                    sh.gathered_blocks(sh.step_and_gather(acts_l if spl > 1 else acts_l[0]))   # (waits for it; rank-major views, no copy)
             run_steps(env, acts, preroll, None)
-            run_steps_gather(args.warmup)
+            if gather_in_metric:
+                sh.set_gather(spl, gather_root)
+                run_steps_gather(args.warmup)
+            else:
+                slots = None if args.overwrite_outputs else env.new_step_slots(min(args.slices, max(args.steps, 1)))
+                run_steps(env, acts, args.warmup, slots)
             sync_all()
             failed = None
         except Exception as exc:      # noqa: BLE001 -- a broken exchange must not cost the shard-only number: say so and time that
             failed = repr(exc)
         # what every rank's communicator set-up (ncclCommInitRank behind cavoid_comm_create, or the gloo stand-in) came to
         comm_status = [None] * world_size
-        try:
-            dist.all_gather_object(comm_status, "ok" if failed is None else failed)
-        except Exception as exc:      # noqa: BLE001
-            comm_status = ["status exchange failed: %r" % (exc,)]
-        # every rank takes the same branch: one rank's failure sends all of them to the shard-only measurement
-        flag = torch.tensor([0 if failed is None else 1], dtype=torch.int32, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
+        if world_size > 1:
+            try:
+                dist.all_gather_object(comm_status, "ok" if failed is None else failed)
+            except Exception as exc:      # noqa: BLE001
+                comm_status = ["status exchange failed: %r" % (exc,)]
+            # every rank takes the same branch: one rank's failure sends all of them to the shard-only measurement
+            flag = torch.tensor([0 if failed is None else 1], dtype=torch.int32, device=coll_device())
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            any_failed = bool(int(flag.item()))
+        else:
+            comm_status, any_failed = ["ok" if failed is None else failed], failed is not None
+        if any_failed:
             extra["configs2_gather"] = {"error": failed or "another rank failed", "comm_init_per_rank": comm_status,
-                                        "note": "the gather failed before the timed region: value is the SHARD-ONLY rate"}
-            gather_in_metric = False
+                                        "note": "the exchange failed before the timed region: value is the SHARD-ONLY rate"}
+            gather_in_metric, exchange_possible = False, False
             if sh is not None:
                 try:
                     sh.close()
@@ -596,7 +634,9 @@ def main() -> None:
                 sh = None
             env, acts = make(W)
             slots = None if args.overwrite_outputs else env.new_step_slots(min(args.slices, max(args.steps, 1)))
-    if not gather_in_metric:
+            run_steps(env, acts, preroll, slots)
+            run_steps(env, acts, args.warmup, slots)
+    if sh is None and "configs2_gather" not in extra:
         run_steps(env, acts, preroll, slots)
         run_steps(env, acts, args.warmup, slots)
 
@@ -620,18 +660,18 @@ def main() -> None:
         return dt
 
     times, restarts = [], []
-    reps = max(1, args.reps)
+    reps = max(1, args.reps) | 1
     r = 0
     while r < reps:
         before = episodes_started()
         times.append(timed_once())
         restarts.append(episodes_started() - before)
         if r == 0 and reps > 3:                              # bound the whole measurement to ~5 s of timed work (same count on every rank)
-            reps = max(3, min(reps, int(5.0 / max(times[0], 1e-9)) + 1))
+            reps = max(3, min(reps, int(5.0 / max(times[0], 1e-9)) + 1)) | 1      # odd: the median is a repetition that really ran
             if world_size > 1:
                 t = torch.tensor([reps], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                reps = int(t.item())
+                reps = int(t.item()) | 1
         r += 1
     order = sorted(range(len(times)), key=lambda i: times[i])
     mid = order[len(order) // 2]
@@ -678,23 +718,67 @@ def main() -> None:
                      100.0 * min(1.0, null_us / max(1e-9, (wall_us - kern_us) * args.steps)))) if not gather_in_metric else
                 "with the gather inside the timed region the wall clock is step + exchange, not the step kernel alone"}
 
-    if gather_in_metric:
-        # the same K steps WITHOUT the gather (every rank its own shard, per-step slots, a barrier only): what the exchange costs
+    value_path = sh.gather_form if (sh is not None and gather_in_metric) else "no exchange inside the timed region"
+    if sh is not None:
+        # every hand-over form beside the one `value` is: the same K steps, barrier + synchronize on both sides, MAX over ranks,
+        # median of 3 -- all (every rank receives), root (the trainer rank receives), none (shard-only, no exchange) -- each with its
+        # xGMI link figures, so that a SCALE run shows the three curves and what the wire allows
         try:
-            run_steps(env, acts, min(args.warmup, 64), slots)
-            sync_all()
-            tg = time.perf_counter()
-            run_steps(env, acts, args.steps, slots)
-            sync_all()
-            t_shard = time.perf_counter() - tg
-            rec = W * N * (env.obs_width + 2) * 4
+            rec = W * N * (env.obs_width + 2) * 4                       # bytes of one rank's packed records per env step
+            forms = {}
+
+            def time_form(mode):
+                if mode == gather_mode:
+                    return elapsed
+                if mode == "none":
+                    sl = slots if slots is not None else env.new_step_slots(min(args.slices, max(args.steps, 1)))
+                    fn = lambda: run_steps(env, acts, args.steps, sl)                  # noqa: E731
+                else:
+                    sh.set_gather(spl, 0 if mode == "root" else -1)
+                    fn = lambda: run_steps_gather(args.steps)                           # noqa: E731
+                fn()
+                ts = []
+                for _ in range(3):
+                    sync_all()
+                    t0 = time.perf_counter()
+                    fn()
+                    sync_all()
+                    dt = time.perf_counter() - t0
+                    if world_size > 1:
+                        t = torch.tensor([dt], dtype=torch.float64, device=coll_device())
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        dt = float(t.item())
+                    ts.append(dt)
+                return sorted(ts)[1]
+            for mode in ("all", "root", "none"):
+                dt = time_form(mode)
+                # busiest link, one direction: all = every rank sends its shard to each peer over that peer's own link; root = each
+                # link INTO the trainer rank carries one shard; none = nothing travels
+                link_bytes = 0 if (mode == "none" or world_size == 1) else rec
+                us = dt * 1e6 / args.steps
+                bound_us = link_bytes / (XGMI_LINK_GBS * 1e3)
+                forms[mode] = {"agent_steps_per_s": world_size * W * N * args.steps / dt, "ms_per_step": dt * 1e3 / args.steps,
+                               "bytes_per_link_per_step": link_bytes, "link_bound_us_per_step": bound_us,
+                               "link_GBps_achieved": (link_bytes / (us * 1e-6) / 1e9) if link_bytes else 0.0,
+                               "xgmi_frac": (bound_us / us) if link_bytes else None,
+                               "bytes_received_per_step": {"all": (world_size - 1) * rec, "root": (world_size - 1) * rec, "none": 0}[mode],
+                               "receivers": {"all": "every rank", "root": "rank 0 (the trainer rank)", "none": "nobody"}[mode]}
+            rccl = bool(sh._native) and bool(getattr(sh._native, "uses_rccl", False))
             extra["configs2_gather"] = {
-                "path": sh.gather_form, "transport": sh.transport, "comm_init_per_rank": comm_status,
-                "steps_per_launch": spl, "bytes_sent_per_rank_per_step": rec, "bytes_received_per_rank_per_step": (world_size - 1) * rec,
-                "agent_steps_per_s_with_gather": value, "ms_per_step_with_gather": ms_per_step,
-                "agent_steps_per_s_shard_only": world_size * W * N * args.steps / t_shard, "ms_per_step_shard_only": t_shard * 1e3 / args.steps,
-                "note": "value = the with-gather rate (BASELINE configs[2]); no multi-GPU scaling curve has been measured by the builder "
-                        "(1-GPU boxes only): the driver's run is the first execution across devices"}
+                "value_is": gather_mode, "forms": forms,
+                "path": value_path,
+                "transport": sh.transport, "uses_rccl": rccl, "rccl_version": getattr(sh._native, "rccl_version", 0) if rccl else 0,
+                "comm_init_per_rank": comm_status, "steps_per_launch": spl,
+                "bytes_sent_per_rank_per_step": rec, "bytes_received_per_rank_per_step": (world_size - 1) * rec,
+                "xgmi_link_peak_GBps": XGMI_LINK_GBS,
+                "agent_steps_per_s_with_gather": forms["all"]["agent_steps_per_s"], "ms_per_step_with_gather": forms["all"]["ms_per_step"],
+                "agent_steps_per_s_shard_only": forms["none"]["agent_steps_per_s"], "ms_per_step_shard_only": forms["none"]["ms_per_step"],
+                "note": "xgmi_frac = link-bound time / measured time per step = achieved GB/s on the busiest link / %.0f: what the wire allows is "
+                        "(8192 x 4 x 116 B = 3.8 MB per link and step) / 153 GB/s = 24.8 us per env step whatever the form, against ~1.5 us of "
+                        "compute -- an every-step hand-over of ALL observations is wire-bound by construction; the shard-only form is the "
+                        "env.step scaling curve.  Under --backend gloo / --share-device (dry runs) nothing crosses a link: the figures then "
+                        "only exercise the code path.  No multi-GPU run has been made by the builder (1-GPU boxes): the driver's is the first."
+                        % XGMI_LINK_GBS}
         except Exception as exc:      # noqa: BLE001 -- report, never lose the headline
             extra["configs2_gather"] = {"error": repr(exc)}
 
@@ -733,18 +817,38 @@ def main() -> None:
         except Exception as exc:      # noqa: BLE001
             extra["configs3_n10"] = {"error": repr(exc)}
 
-    if rank == 0 and args.sweep:
-        # transparency: the same step with NO scenario pool (every restart runs GEN v1 in-kernel, exact (world,
-        # episode) scenarios) -- the pool only moves scenario generation (E2) off the step's critical path
-        try:
-            e0, a0 = make(W, N, gen_pool_size=0)
-            s0 = None if args.overwrite_outputs else e0.new_step_slots(a0.shape[0])
-            run_steps(e0, a0, 128, s0)
-            extra["no_scenario_pool"] = kernel_figures(e0, a0, N, W, 256, s0)
-            del s0
-            e0.close()
-        except Exception as exc:      # noqa: BLE001
-            extra["no_scenario_pool"] = {"error": repr(exc)}
+    if rank == 0 and not args.no_fresh_scenarios:
+        # the reference's reset semantics (TEST_CASE_FN = get_testcase_random, run-ws/config.yaml:281-283: a NEW random scenario at every
+        # reset, ProcessAgent.py:107): the same K-step timed region with NO scenario pool -- every restart generates its scenario inside the
+        # step kernel, exact (seed, global world id, episode) streams -- for GEN v1 (rings) and GEN v2 (boxes, rejection sampling)
+        fresh = {}
+        for label, over in (("gen_v1_ring", {"gen_pool_size": 0}), ("gen_v2_box", {"gen_pool_size": 0, "gen_mode": 1})):
+            try:
+                e0, a0 = make(W, N, **over)
+                s0 = None if args.overwrite_outputs else e0.new_step_slots(min(args.slices, max(args.steps, 1)))
+                run_steps(e0, a0, preroll + args.warmup, s0)
+                ts, rs = [], []
+                for _ in range(5):
+                    before = int(e0.episode.to(torch.int64).sum().item())
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    run_steps(e0, a0, args.steps, s0)
+                    torch.cuda.synchronize(device)
+                    ts.append(time.perf_counter() - t0)
+                    rs.append(int(e0.episode.to(torch.int64).sum().item()) - before)
+                mid0 = sorted(range(5), key=lambda i: ts[i])[2]
+                f0 = kernel_figures(e0, a0, N, W, max(args.steps, 256), s0)
+                fresh[label] = {"value": W * N * args.steps / ts[mid0], "unit": "agent-steps/s", "ms_per_step": ts[mid0] * 1e3 / args.steps,
+                                "restarts_in_timed_region": rs[mid0], "timed_reps": 5, "roofline": f0,
+                                "vs_pool_headline_kernel_us_per_step": [f0["kernel_us_per_step"], roofline["kernel_us_per_step"]]}
+                del s0
+                e0.close()
+                del e0, a0
+            except Exception as exc:      # noqa: BLE001
+                fresh[label] = {"error": repr(exc)}
+        fresh["note"] = ("gen_pool_size = 0: the scenario of every restarting world is generated in the step kernel (the reference makes a new "
+                         "random test case per reset); same K, same launch form and per-step output slots as the headline, this rank's GPU only")
+        extra["no_scenario_pool"] = fresh
 
     if args.full_loop or not args.no_full_loop:
         # configs[4] beside the headline (a brief version: actors only + the fused-trainer loop, ~15 s; the PyTorch comparison
@@ -769,8 +873,8 @@ def main() -> None:
             one = f["one_step_launch"]
             sweep.append({"worlds": Ws, "kernel_us_per_step": f["kernel_us_per_step"], "steps_per_launch": f["steps_per_launch"],
                           "agent_steps_per_s": Ws * N / (f["kernel_us_per_step"] * 1e-6), "GBps": f["achieved"], "frac": f["frac"],
-                          "frac_contract": f["frac_contract"], "one_step_launch_us": one["kernel_us"], "one_step_launch_frac": one["frac"],
-                          "one_step_launch_frac_contract": one["frac_contract"]})
+                          "frac_moved": f["frac_moved"], "one_step_launch_us": one["kernel_us"], "one_step_launch_frac": one["frac"],
+                          "one_step_launch_frac_moved": one["frac_moved"]})
             e2.close()
             del e2, a2, s2
         extra["saturation_sweep"] = sweep
@@ -782,14 +886,18 @@ def main() -> None:
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE %s: %d agents x %d worlds per GPU, unicycle dynamics, GEN v1 synthetic scenarios, "
-                               "uniform random actions pre-staged on the device, in-kernel auto-reset; launches of up to %d steps "
+                               "uniform random actions pre-staged on the device, in-kernel auto-reset -- a finished world RESTARTS BY GATHERING "
+                               "one of 65536 scenarios pre-generated outside the timed region (the same step with a fresh scenario generated "
+                               "in-kernel at every restart, GEN v1 and GEN v2: extra.no_scenario_pool); launches of up to %d steps "
                                "(world state in registers between the steps of a launch); %s%s"
                                % (which, N, W, args.slices,
                                   "every step overwrites one output slot" if args.overwrite_outputs else
                                   "every step's obs / reward / done / game_over written into its own output slot [K,W,N,.]",
-                                  "; + all-gather of the packed records to every rank inside the timed region (configs[2])" if gather_in_metric else ""),
+                                  ("; + the gather of the packed records to %s inside the timed region (configs[2])"
+                                   % ("every rank" if gather_root < 0 else "rank 0, the trainer rank")) if gather_in_metric else ""),
                    "worlds_per_gpu": W, "agents_per_world": N, "obs_width": env.obs_width, "steps_per_launch": min(args.slices, args.steps),
-                   "parallelism": ("worlds sharded over %d GPU(s), one gather of (obs|reward|done) per launch (RCCL over xGMI)" % world_size)
+                   "parallelism": ("worlds sharded over %d GPU(s), one gather of (obs|reward|done) per launch to %s (RCCL over xGMI)"
+                                   % (world_size, "every rank" if gather_root < 0 else "rank 0"))
                                   if gather_in_metric else ("worlds sharded over %d GPU(s), no data-path collective" % world_size)},
         "roofline": roofline, "timing": timing,
     }

@@ -227,10 +227,11 @@ class ShardedEnv(object):
         """Buffers of the native hand-over: per slot a send buffer of `steps` packed records of this shard and, on the
         receiving ranks, a recv buffer of rank-major blocks [rank][steps, count_r, N, width+2].  Equal shards to every rank go
         through ONE ncclAllGather; ragged shards or a single receiving rank (`root`) through the point-to-point gather
-        (`cavoid_gatherv_begin`)."""
+        (`cavoid_gatherv_begin`).  Called again with another (steps, root) it keeps the communicator and re-makes the buffers."""
         from .batched_env import StepSlots
         e = self.env
-        self._native = NativeGather(e.device, self.group, self.force_rccl) if self.transport == "native" else False
+        if self._native is None:
+            self._native = NativeGather(e.device, self.group, self.force_rccl) if self.transport == "native" else False
         self._steps, self._root = int(steps), int(root)
         self._counts = [shard_range(self.total_worlds, r, self.size)[1] for r in range(self.size)]
         self._even = all(c == self._counts[0] for c in self._counts)
@@ -242,6 +243,14 @@ class ShardedEnv(object):
                       else None for _ in range(NativeGather.SLOTS)]
         self._blocks = [None] * NativeGather.SLOTS          # transport "torch": the received blocks of each slot
         self._floats = [steps * c * rec for c in self._counts]
+
+    def set_gather(self, steps: int = 1, root: int = -1) -> None:
+        """Choose (or change) the hand-over form: `steps` env steps per launch-and-gather block, to every rank (root < 0) or to
+        one.  Every gather in flight is waited for; the communicator is kept (one per process), only the buffers are re-made."""
+        if self._native:
+            torch.cuda.synchronize(self.env.device)
+        self._native_setup(steps, root)
+        self._t = 0
 
     @property
     def gather_form(self) -> str:
@@ -265,7 +274,7 @@ class ShardedEnv(object):
         runs while this gather is on the wire.  `root >= 0`: only that rank receives (the trainer rank).  Returns the slot;
         `gathered(slot)` makes the current stream wait for it and returns the records of ALL worlds."""
         steps = 1 if actions.dim() == 2 else int(actions.shape[0])
-        if self._native is None:
+        if self._native is None or self._send is None:
             self._native_setup(steps, root)
         if steps != self._steps or root != self._root:
             raise ValueError("step_and_gather was set up for %d step(s) per launch, root %d" % (self._steps, self._root))

@@ -13,18 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(args, timeout, attempts=2):
-    """(Up to two attempts: N processes starting N HIP contexts on ONE device and a TCP rendezvous between them failed once in
-    about ten runs of the whole suite on a fresh box -- once, never twice in a row, never with its message kept; the first
-    attempt's stderr is printed so that the next occurrence leaves a trace.  What the tests pin is the code path, not the box.)"""
+def _run(args, timeout):
+    """ONE attempt (round 4 retried once: a failure seen "once in about ten runs" whose message was never kept.  Round 5 hunted it
+    with tools/launch_flake_hunt.py -- consecutive launches of exactly these commands, everything a failing attempt prints kept:
+    30 / 30 of the 8-rank rendezvous on the CPU box and 20 / 20 + 100 / 100 of the 8-rank dry run on MI355X boxes passed,
+    profiles/r05_a_launch_flake_hunt_*.json -- so the retry is gone and a failure shows its stderr here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    for attempt in range(attempts):
-        out = subprocess.run([sys.executable, BENCH] + args, env=env, cwd=ROOT, timeout=timeout, stdout=subprocess.PIPE,
-                             stderr=subprocess.PIPE, text=True)
-        if out.returncode == 0:
-            break
-        print("bench.py %s: attempt %d failed (rc %d):\n%s" % (" ".join(args), attempt + 1, out.returncode, out.stderr[-3000:]), file=sys.stderr)
-    assert out.returncode == 0, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, BENCH] + args, env=env, cwd=ROOT, timeout=timeout, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, "bench.py %s failed (rc %d):\n%s" % (" ".join(args), out.returncode, out.stderr[-6000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]            # ONE JSON line, from rank 0 only
     return json.loads(lines[0])
@@ -61,8 +58,21 @@ def test_bench_two_rank_dry_run_on_one_device():
     assert g["agent_steps_per_s_with_gather"] == line["value"] and g["agent_steps_per_s_shard_only"] > 0
     assert "gather" in line["config"]["parallelism"]
     r = line["roofline"]
-    assert r["bound"] in ("latency", "valu-issue", "hbm") and 0 < r["frac"] < r["frac_contract"]
+    # roofline.frac IS the SURVEY 8d contract fraction (192 B per agent-step); the bytes the form really moves are frac_moved
+    assert r["bound"] in ("latency", "valu-issue", "hbm") and 0 < r["frac_moved"] < r["frac"] == r["frac_contract"]
+    assert abs(r["achieved"] - 192 * 2048 * 4 * r["steps_per_launch"] / (r["kernel_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert r["one_step_launch"]["steps_per_launch"] == 1 and 0 < r["one_step_launch"]["frac"]
+    # the three hand-over forms, each with its link figures; value is the every-rank form
+    assert g["value_is"] == "all" and set(g["forms"]) == {"all", "root", "none"}
+    rec = 2048 * 4 * 29 * 4
+    for mode, f in g["forms"].items():
+        assert f["agent_steps_per_s"] > 0 and f["bytes_per_link_per_step"] == (0 if mode == "none" else rec)
+        assert (f["xgmi_frac"] is None) if mode == "none" else (abs(f["link_bound_us_per_step"] - rec / 153e3) < 1e-9 and f["xgmi_frac"] > 0)
+    assert g["forms"]["all"]["agent_steps_per_s"] == line["value"]
+    # the reference's reset semantics beside the pooled headline: a fresh scenario generated in-kernel at every restart
+    for label in ("gen_v1_ring", "gen_v2_box"):
+        f = line["extra"]["no_scenario_pool"][label]
+        assert "error" not in f and f["value"] > 0 and f["restarts_in_timed_region"] > 0, f
 
 
 @pytest.mark.gpu
@@ -71,12 +81,38 @@ def test_bench_eight_rank_dry_run_on_one_device():
     inside the timed region -- as a dry run on ONE device over gloo (no 8-GPU node is available to the builder: this is the
     closest execution of the N = 8 code path; RCCL itself runs first on the driver's node)."""
     line = _run(["--gpus", "8", "--backend", "gloo", "--share-device", "--steps", "20", "--warmup", "5", "--worlds", "1024", "--reps", "3",
-                 "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc"], 1500)
+                 "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"], 1500)
     assert line["n_gpus"] == 8 and line["steps"] == 20 and line["scaling"] == "weak" and line["value"] > 0
     g = line["extra"]["configs2_gather"]
     assert "error" not in g, g
     assert g["comm_init_per_rank"] == ["ok"] * 8 and g["transport"] == "torch" and "all_gather" in g["path"]
     assert g["bytes_received_per_rank_per_step"] == 7 * 1024 * 4 * 29 * 4 and g["steps_per_launch"] == 20
+    assert g["value_is"] == "all" and g["forms"]["root"]["receivers"].startswith("rank 0") and g["forms"]["none"]["agent_steps_per_s"] > 0
     t = line["timing"]
     assert t["timed_reps"] == 3 and t["ms_per_step_min"] <= t["ms_per_step_median"] <= t["ms_per_step_max"]
     assert t["preroll_steps"] == 251 and t["restarts_in_timed_region"] > 0      # the auto-reset path is inside the timed region
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["root", "none"])
+def test_bench_two_rank_dry_run_other_gather_forms(mode):
+    line = _run(["--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "40", "--warmup", "8", "--worlds", "1024", "--reps", "3",
+                 "--gather", mode, "--gather-every", "8", "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc",
+                 "--no-fresh-scenarios"], 900)
+    g = line["extra"]["configs2_gather"]
+    assert "error" not in g, g
+    assert g["value_is"] == mode and g["steps_per_launch"] == 8 and g["forms"][mode]["agent_steps_per_s"] == line["value"]
+    assert ("rank 0" in line["config"]["parallelism"]) if mode == "root" else ("no data-path collective" in line["config"]["parallelism"])
+
+
+@pytest.mark.gpu
+def test_bench_one_gpu_with_the_exchange_through_forced_rccl():
+    """N = 1 development form: the gather inside the timed region through a forced one-rank RCCL communicator (ncclAllGather on the
+    communicator's stream) -- the N > 1 code path of the bench with the native transport, on the one GPU there is."""
+    line = _run(["--gpus", "1", "--force-rccl", "--steps", "40", "--warmup", "8", "--worlds", "2048", "--reps", "5", "--no-cpu-baseline",
+                 "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"], 900)
+    g = line["extra"]["configs2_gather"]
+    assert "error" not in g, g
+    assert g["transport"] == "native" and g["uses_rccl"] and g["rccl_version"] >= 20000 and "ncclAllGather" in g["path"]
+    assert g["comm_init_per_rank"] == ["ok"] and g["forms"]["all"]["agent_steps_per_s"] == line["value"]
+    assert g["forms"]["all"]["bytes_per_link_per_step"] == 0          # one rank: nothing crosses a link
