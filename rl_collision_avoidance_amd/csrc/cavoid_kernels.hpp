@@ -504,10 +504,42 @@ __device__ __forceinline__ void neighbour_features(const Ego &e, float pxf, floa
     //  kernel -- matrix instructions of the CU's other workgroup sharing the SIMD -- the low lane of that fma, v_par, came out
     //  wrong now and then, run to run, for the neighbours whose mul and fma sat a few instructions apart; never in the env-only
     //  kernels.  tools/repro_actor_case.py; the barriers keep the two chains out of the vectoriser's sight.)
+#if !defined(CAVOID_DEV_PKFORM)
     float t_par = q.vyf * pyf, t_orth = q.vxf * pyf;
     asm volatile("" : "+v"(t_par), "+v"(t_orth));
     f[2] = __builtin_fmaf(q.vxf, pxf, t_par);
     f[3] = __builtin_fmaf(q.vyf, pxf, -t_orth);
+#elif CAVOID_DEV_PKFORM == 0
+    // development (tools/experiments/pk_opsel_bisect.sh): the round-4 source, left to the vectoriser
+    f[2] = __builtin_fmaf(q.vxf, pxf, q.vyf * pyf);
+    f[3] = __builtin_fmaf(q.vyf, pxf, -(q.vxf * pyf));
+#else
+    // development: the packed pair spelled out -- (vx, vy) * (py, py), then (vx, vy) * (px, px) + swap(product) with the high half
+    // negated -- with what the bisect varies between and around the two instructions
+    typedef float pkf2 __attribute__((ext_vector_type(2)));
+    pkf2 v2 = {q.vxf, q.vyf}, py2 = {pyf, pyf}, px2 = {pxf, pxf}, t2, r2;
+#define CAVOID_PK_STR2(x) #x
+#define CAVOID_PK_STR(x) CAVOID_PK_STR2(x)
+#if CAVOID_DEV_PKFORM == 1          /* swapped-halves fma, CAVOID_DEV_PKNOPS wait states between the two (-1: none) */
+    asm volatile(
+#if defined(CAVOID_DEV_PKDRAIN)
+        "s_waitcnt lgkmcnt(0)\n\t"
+#endif
+        "v_pk_mul_f32 %1, %2, %3\n\t"
+#if CAVOID_DEV_PKNOPS >= 0
+        "s_nop " CAVOID_PK_STR(CAVOID_DEV_PKNOPS) "\n\t"
+#endif
+        "v_pk_fma_f32 %0, %2, %4, %1 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]"
+        : "=&v"(r2), "=&v"(t2) : "v"(v2), "v"(py2), "v"(px2));
+#elif CAVOID_DEV_PKFORM == 2        /* the same arithmetic, the swap made by two moves: no op_sel on the packed fma */
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t2) : "v"(v2), "v"(py2));
+    pkf2 s2 = {t2.y, t2.x};
+    asm volatile("" : "+v"(s2));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[0,0,1]" : "=v"(r2) : "v"(v2), "v"(px2), "v"(s2));
+#endif
+    f[2] = r2.x;
+    f[3] = r2.y;
+#endif
     f[4] = q.r;
 }
 
