@@ -837,7 +837,7 @@ def main() -> None:
                     ts.append(time.perf_counter() - t0)
                     rs.append(int(e0.episode.to(torch.int64).sum().item()) - before)
                 mid0 = sorted(range(5), key=lambda i: ts[i])[2]
-                f0 = kernel_figures(e0, a0, N, W, max(args.steps, 256), s0)
+                f0 = kernel_figures(e0, a0, N, W, args.steps, s0)
                 fresh[label] = {"value": W * N * args.steps / ts[mid0], "unit": "agent-steps/s", "ms_per_step": ts[mid0] * 1e3 / args.steps,
                                 "restarts_in_timed_region": rs[mid0], "timed_reps": 5, "roofline": f0,
                                 "vs_pool_headline_kernel_us_per_step": [f0["kernel_us_per_step"], roofline["kernel_us_per_step"]]}

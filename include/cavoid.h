@@ -307,7 +307,11 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
  * CAVOID_EUNSUPPORTED (use the step-by-step entry points): holonomic dynamics, CAVOID_POLICY_F32 / a non-default
  * CAVOID_POLICY_PRODUCTS, rvo_enabled with so many agents per world (> 12) that the ORCA lines do not fit into the LDS the
  * policy lends the env step.  Frozen-network agents (CAVOID_POLICY_FROZEN_NET) act by a SECOND network: cavoid_actor_run_mix carries it;
- * this entry point refuses an env whose generator makes such agents. */
+ * this entry point refuses an env whose generator makes such agents (gen_frozen_fraction > 0 with gen_nonlearning_fraction > 0).  The
+ * refusal looks at the GENERATOR's fractions only: frozen-network agents put into the worlds some other way -- cavoid_set_state, or a
+ * scenario pool filled under another configuration -- are NOT detected here and would be handed the learner's sampled action; callers
+ * that inject such agents must use cavoid_actor_run_mix.
+ * Side effect: like every entry point that launches, the call leaves the CALLER's current HIP device set to the env's device. */
 typedef struct cavoid_rollout_buffers {
     int32_t struct_size;             /* sizeof(cavoid_rollout_buffers) */
     int32_t reserved;
@@ -389,6 +393,15 @@ int cavoid_policy_create(int32_t max_other, int32_t num_actions, int device, cav
 void cavoid_policy_destroy(cavoid_policy *p);
 int cavoid_policy_load(cavoid_policy *p, const cavoid_policy_weights *w, void *stream);
 int cavoid_policy_seed(cavoid_policy *p, uint64_t seed, void *stream);
+/* what the handle is (fixed at cavoid_policy_create: the environment switches CAVOID_POLICY_F32 / CAVOID_POLICY_PRODUCTS are read there,
+ * never again): use_split = 1 when inference runs on the operand-split kernel (0: the float32-MFMA kernel); split_products = 16 for the
+ * default float16 two-piece form, 3 / 4 / 5 for bf16 pieces.  RANGE LIMIT of the default form: a float16 piece saturates at +-65504, so a
+ * weight beyond that (after the LSTM gate columns' scale of log2 e / 2 log2 e) is CLAMPED at load and the network then differs from the
+ * reference's float32 predictor; clamped_weights = how many weights of the last cavoid_policy_load were (0 for every sane checkpoint;
+ * reading it synchronises `stream`).  A caller that finds it non-zero should re-create the handle with CAVOID_POLICY_PRODUCTS=3 (bf16
+ * pieces: float32's range) or CAVOID_POLICY_F32=1.  Inputs and hidden activations beyond +-65504 saturate in the kernel the same way.
+ * Any out pointer may be NULL. */
+int cavoid_policy_info(cavoid_policy *p, void *stream, int32_t *use_split, int32_t *split_products, int32_t *clamped_weights);
 int cavoid_policy_forward(cavoid_policy *p, const float *x, int64_t rows, int64_t row_stride, float *p_out, float *v_out,
                           int32_t *actions_out, int32_t greedy, void *stream);
 /* as cavoid_policy_forward, for the rows row_index[0 .. *row_count) only (device-side list and count: the launch geometry

@@ -135,6 +135,7 @@ SYMBOLS = [
     ("cavoid_policy_destroy", None, [_P]),
     ("cavoid_policy_load", C.c_int, [_P, C.POINTER(CavoidPolicyWeights), _P]),
     ("cavoid_policy_seed", C.c_int, [_P, C.c_uint64, _P]),
+    ("cavoid_policy_info", C.c_int, [_P, _P] + [C.POINTER(C.c_int32)] * 3),
     ("cavoid_policy_forward", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32, _P]),
     ("cavoid_policy_train", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, C.c_float, C.c_float, C.POINTER(CavoidPolicyTrainBuffers), _P]),
     ("cavoid_timer_begin", C.c_int, [_P, _P]),

@@ -32,6 +32,7 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     const size_t o_sfrag = carve((size_t)kSpPackFrags * sizeof(uint4)), o_sbias = carve(kBiasFloats * sizeof(float));
     const size_t o_avg = carve(h->in_size * sizeof(float)), o_std = carve(h->in_size * sizeof(float));
     const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t)), o_tick = carve(kPolCuSlots * sizeof(uint32_t));
+    const size_t o_clamp = carve(sizeof(uint32_t));
     if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return CAVOID_ENOMEM; }
     if (hipMemset(h->slab, 0, off) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP; }
     unsigned char *b = static_cast<unsigned char *>(h->slab);
@@ -43,6 +44,7 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
     h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
+    h->clamped_weights = reinterpret_cast<uint32_t *>(b + o_clamp);
     // 70 KB of LDS per 64-row workgroup: above the 64 KB static limit, so it is dynamic and opted into here
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_lds_bytes(4)) != hipSuccess ||
@@ -91,8 +93,9 @@ extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights 
     {   // the inference kernel's copy, fragment order: every weight split into two float16 pieces (22 bits; the default form) or
         // three bf16 pieces (exact; CAVOID_POLICY_PRODUCTS = 3 / 4 / 5)
         constexpr int64_t items = kSpOffHead / 3 + kSpChWide * 64;
+        HIP_TRY(hipMemsetAsync(h->clamped_weights, 0, sizeof(uint32_t), s));
         hipLaunchKernelGGL(policy_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k, h->sfrags, h->sbias,
-                           h->split_products == kSpF16 ? 1 : 0);
+                           h->split_products == kSpF16 ? 1 : 0, h->clamped_weights);
         HIP_TRY(hipGetLastError());
     }
     h->normalize = w->avg != nullptr;
@@ -102,6 +105,22 @@ extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights 
     }
     h->min_policy = w->min_policy;
     h->loaded = true;
+    return CAVOID_OK;
+}
+
+extern "C" int cavoid_policy_info(cavoid_policy *h, void *stream, int32_t *use_split, int32_t *split_products, int32_t *clamped_weights) {
+    if (!h) return CAVOID_EINVAL;
+    if (use_split) *use_split = h->use_split ? 1 : 0;
+    if (split_products) *split_products = h->split_products;
+    if (clamped_weights) {                                  // (the one host read-back: waits for the load enqueued on `stream`)
+        uint32_t n = 0;
+        if (h->loaded) {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            HIP_TRY(hipMemcpyAsync(&n, h->clamped_weights, sizeof(n), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        *clamped_weights = (int32_t)(n > 0x7fffffffu ? 0x7fffffffu : n);
+    }
     return CAVOID_OK;
 }
 

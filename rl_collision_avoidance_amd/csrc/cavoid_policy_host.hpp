@@ -23,6 +23,7 @@ struct cavoid_policy {
     bool use_split = true;           // CAVOID_POLICY_F32=1: run inference on the float32-MFMA kernel instead (A/B runs)
     float *bias = nullptr, *avg = nullptr, *std = nullptr;
     int32_t *step_counter = nullptr;
+    uint32_t *clamped_weights = nullptr;   // device counter: weights the float16 split saturated at the last cavoid_policy_load
     uint32_t *blocks_done = nullptr, *cu_tickets = nullptr;
     int row_tiles = 4;               // 16-row tiles per workgroup (64 rows, 2 workgroups per CU); the 32-row / 4-per-CU
                                      // instantiation was measured and dropped: 175 vs 132 us

@@ -139,7 +139,9 @@ __device__ __forceinline__ float split_weight(const PolicyWeights &w, int layer,
 }
 
 #ifdef CAVOID_POLICY_KERNELS     /* the non-template kernels are compiled by cavoid_policy_capi.hip only */
-__global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags, float *sbias, const int f16) {
+// `clamped` (may be null): incremented for every weight the float16 form saturates at +-65504 (after the LSTM gates' log2 e scale)
+__global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeights w, uint4 *frags, float *sbias, const int f16,
+                                                                uint32_t *clamped) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one (layer, chunk, column tile, lane): all 3 planes
     constexpr int64_t kWide = kSpOffHead / 3, kAll = kWide + kSpChWide * 64;
     if (f < kBiasFloats) {                                                 // the biases in packed column order (as policy_pack_kernel), LSTM gates scaled
@@ -180,8 +182,11 @@ __global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeig
     for (int e = 0; e < 8; e += 2) {
         uint32_t a1, a2, a3, b1, b2, b3;
         if (f16) {
-            split3_f16(split_weight(w, layer, c, g, e, col), a1, a2, a3);
-            split3_f16(split_weight(w, layer, c, g, e + 1, col), b1, b2, b3);
+            const float w0 = split_weight(w, layer, c, g, e, col), w1 = split_weight(w, layer, c, g, e + 1, col);
+            const int beyond = (int)!(__builtin_fabsf(w0) <= kSpF16Max) + (int)!(__builtin_fabsf(w1) <= kSpF16Max);   // (NaN counts)
+            if (beyond && clamped) atomicAdd(clamped, (uint32_t)beyond);
+            split3_f16(w0, a1, a2, a3);
+            split3_f16(w1, b1, b2, b3);
         } else {
             split3(split_weight(w, layer, c, g, e, col), a1, a2, a3);
             split3(split_weight(w, layer, c, g, e + 1, col), b1, b2, b3);

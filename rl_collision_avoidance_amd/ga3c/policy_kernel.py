@@ -32,8 +32,12 @@ class FusedPolicy(object):
         h = C.c_void_p()
         _lib.check(self._lib.cavoid_policy_create(self.max_others, self.num_actions, dev.index or 0, C.byref(h)), "cavoid_policy_create")
         self._h = h
+        # the inference form is fixed at creation (CAVOID_POLICY_F32 / CAVOID_POLICY_PRODUCTS are read by cavoid_policy_create only)
+        use_split, products = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.cavoid_policy_info(h, None, C.byref(use_split), C.byref(products), None), "cavoid_policy_info")
+        self.inference_form = ("split", int(products.value)) if use_split.value else ("f32", 0)
         self.seed(seed)
-        self.refresh()
+        self.refresh(check_range=True)
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
@@ -53,9 +57,18 @@ class FusedPolicy(object):
     def seed(self, seed: int) -> None:
         _lib.check(self._lib.cavoid_policy_seed(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1)), self._stream()), "cavoid_policy_seed")
 
-    def refresh(self, with_backward: bool = False) -> None:
+    def clamped_weights(self) -> int:
+        """How many weights of the last ``refresh`` the default float16-split form had to clamp to +-65504 (include/cavoid.h,
+        cavoid_policy_info; always 0 for the bf16 / float32 forms).  Synchronises the current stream."""
+        n = C.c_int32()
+        _lib.check(self._lib.cavoid_policy_info(self._h, self._stream(), None, None, C.byref(n)), "cavoid_policy_info")
+        return int(n.value)
+
+    def refresh(self, with_backward: bool = False, check_range: bool = False) -> None:
         """Re-pack the module's current parameters (after a trainer step / checkpoint load).  ``with_backward`` also
-        packs the transposed copies the fused trainer pass needs."""
+        packs the transposed copies the fused trainer pass needs.  ``check_range`` (the constructor and checkpoint loads use it; it
+        costs a stream synchronisation): fail loudly when a weight lies beyond the float16 split's +-65504 instead of running a
+        network that silently differs from the reference's float32 predictor."""
         n = self.net
         w = _lib.CavoidPolicyWeights()
         w.struct_size = C.sizeof(_lib.CavoidPolicyWeights)
@@ -69,6 +82,12 @@ class FusedPolicy(object):
                      "fc1_kernel", "fc1_bias", "p_kernel", "p_bias", "v_kernel", "v_bias"):
             setattr(w, name, ptr(getattr(n, name)))
         _lib.check(self._lib.cavoid_policy_load(self._h, C.byref(w), self._stream()), "cavoid_policy_load")
+        if check_range and self.inference_form == ("split", 16):
+            bad = self.clamped_weights()
+            if bad:
+                raise ValueError("%d weight(s) lie beyond +-65504 (after the LSTM gates' log2 e scale): the default float16-split inference "
+                                 "form would clamp them.  Create the policy with CAVOID_POLICY_PRODUCTS=3 (bf16 pieces, float32's range) or "
+                                 "CAVOID_POLICY_F32=1 in the environment." % bad)
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         t = t.detach()

@@ -208,7 +208,6 @@ class BatchedRollout(object):
     @property
     def fused_unavailable_reason(self) -> Optional[str]:
         """Why ``step()`` / the hipGraph form must be used instead of the fused actor kernel (None: it applies)."""
-        import os
         cfg = self.env.cfg
         # (skip_finished -- the step-by-step path's row list of the agents that still need an action -- does not matter here: the
         #  kernel runs every row of a tile anyway, and what finished agents are given as action / value is never used)
@@ -220,8 +219,15 @@ class BatchedRollout(object):
             return "holonomic (velocity) actions"
         if self.frozen_policy is not None and not getattr(self.frozen_policy, "accepts_strided_obs", False):
             return "the frozen-network agents' policy is not a FusedPolicy"
-        if os.environ.get("CAVOID_POLICY_F32", "0") not in ("", "0") or os.environ.get("CAVOID_POLICY_PRODUCTS", "16") not in ("", "16"):
-            return "a non-default inference form (CAVOID_POLICY_F32 / CAVOID_POLICY_PRODUCTS)"
+        if self.frozen_policy is None and cfg.gen_frozen_fraction > 0.0 and cfg.gen_nonlearning_fraction > 0.0:
+            # (cavoid_actor_run refuses exactly this with CAVOID_EUNSUPPORTED: those agents act by THEIR network)
+            return "the env generates frozen-network agents but no frozen_policy was given"
+        # the inference form is a property of the policy HANDLE, fixed at cavoid_policy_create (the environment switches are read there,
+        # not here: changing them afterwards changes nothing)
+        for who, pol in (("policy", self.policy), ("frozen policy", self.frozen_policy)):
+            if pol is not None and getattr(pol, "inference_form", ("split", 16)) != ("split", 16):
+                return "the %s runs a non-default inference form %r (CAVOID_POLICY_F32 / CAVOID_POLICY_PRODUCTS at its creation)" % (
+                    who, pol.inference_form)
         return None
 
     @property

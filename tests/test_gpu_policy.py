@@ -447,3 +447,59 @@ def test_float16_pieces_saturate_instead_of_overflowing():
     with torch.no_grad():
         _, p_ref, v_ref = net.forward(mid)
     assert (p - p_ref).abs().max().item() <= P_TOL and ((v - v_ref).abs() <= V_TOL + V_TOL * v_ref.abs()).all()
+
+
+def test_weights_beyond_float16_range_are_reported_not_silently_clamped(monkeypatch):
+    """the default float16 split clamps a weight at +-65504.  The load counts what it clamped (cavoid_policy_info) and the host
+    side refuses such a network loudly; the bf16-piece form (float32's range) takes it; the handle knows its own inference form."""
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(3, seed=5)
+    pol = FusedPolicy(net)
+    assert pol.inference_form == ("split", 16) and pol.clamped_weights() == 0
+    with torch.no_grad():
+        net.layer2_kernel[3, 7] = 1.0e5
+        net.lstm_kernel[0, 1] = -5.0e4            # inside +-65504 as stored, beyond it once the gate column's log2 e scale is applied
+    pol.refresh()                                   # the hot path does not check (no synchronisation) ...
+    assert pol.clamped_weights() == 2             # ... but the count is there
+    with pytest.raises(ValueError, match="65504"):
+        pol.refresh(check_range=True)
+    with pytest.raises(ValueError, match="65504"):
+        FusedPolicy(net)
+    monkeypatch.setenv("CAVOID_POLICY_PRODUCTS", "3")
+    wide = FusedPolicy(net)                         # bf16 pieces: no range limit, no complaint
+    assert wide.inference_form == ("split", 3) and wide.clamped_weights() == 0
+    monkeypatch.delenv("CAVOID_POLICY_PRODUCTS")
+    assert wide.inference_form == ("split", 3)      # fixed at creation: the environment no longer matters
+
+
+def test_fused_actor_availability_follows_the_handles_not_the_environment(monkeypatch):
+    """`fused_available` must say no (with the reason) where cavoid_actor_run would return CAVOID_EUNSUPPORTED -- a policy
+    handle created under another inference form, or an env that generates frozen-network agents without a frozen policy -- and must not
+    be fooled by environment variables set AFTER the handle was made."""
+    from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+    from rl_collision_avoidance_amd.config import EnvConfig
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+    net = _net(3, seed=9)
+    env = BatchedCollisionAvoidanceEnv(128, EnvConfig(), device="cuda:0", seed=1)
+    pol = FusedPolicy(net)
+    roll = BatchedRollout(env, pol)
+    assert roll.fused_available
+    monkeypatch.setenv("CAVOID_POLICY_PRODUCTS", "5")                # too late for `pol`: it stays on the default form
+    assert roll.fused_available
+    other = FusedPolicy(net)                                         # created under the switch
+    roll5 = BatchedRollout(env, other)
+    assert not roll5.fused_available and "non-default inference form" in roll5.fused_unavailable_reason
+    monkeypatch.delenv("CAVOID_POLICY_PRODUCTS")
+    assert not roll5.fused_available                                 # still the handle's form
+    roll.close(); roll5.close(); env.close()
+    # an env that generates frozen-network agents cannot even get a rollout without their network (nothing can fall through to the
+    # fused kernel handing those agents the learner's sample); should the env's cfg change under a live rollout, the reason says so
+    env2 = BatchedCollisionAvoidanceEnv(128, EnvConfig(), device="cuda:0", seed=1, gen_nonlearning_fraction=0.5, gen_frozen_fraction=0.5)
+    with pytest.raises(ValueError, match="frozen_policy"):
+        BatchedRollout(env2, pol)
+    env3 = BatchedCollisionAvoidanceEnv(128, EnvConfig(), device="cuda:0", seed=1)
+    roll3 = BatchedRollout(env3, pol)
+    env3.cfg.gen_nonlearning_fraction, env3.cfg.gen_frozen_fraction = 0.5, 0.5
+    assert not roll3.fused_available and "frozen-network agents" in roll3.fused_unavailable_reason and "one launch per phase" in roll3.actor_path
+    roll3.close(); env3.close(); env2.close()

@@ -21,7 +21,7 @@ build)
   ;;
 run)
   out=gpurun_out/pk_bisect; mkdir -p $out
-  for v in pk_base pk_c pk_a pk_n0 pk_n1 pk_n3 pk_n7 pk_d pk_m; do
+  for v in ${VARIANTS:-pk_base pk_c pk_a pk_n0 pk_n1 pk_n3 pk_n7 pk_d pk_m pk_s pk_sn pk_cz}; do
     [ -f .ab/lib$v.so ] || continue
     for rep in 1 2 3; do
       echo "== $v rep $rep" | tee -a $out/log.txt

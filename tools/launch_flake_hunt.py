@@ -29,7 +29,7 @@ def main():
         args = ["--gpus", str(a.gpus), "--backend", "gloo", "--rendezvous-only"]
     else:
         args = ["--gpus", str(a.gpus), "--backend", "gloo", "--share-device", "--steps", "20", "--warmup", "5", "--worlds", "1024", "--reps", "3",
-                "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc"]
+                "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     rows = []
     for i in range(a.runs):
