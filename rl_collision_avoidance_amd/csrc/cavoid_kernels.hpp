@@ -499,84 +499,24 @@ constexpr int kFeat = 5;   // p_par, p_orth, v_par, v_orth, r_other
 __device__ __forceinline__ void neighbour_features(const Ego &e, float pxf, float pyf, double rx, double ry, const OtherState &q, float (&f)[kFeat]) {
     f[0] = (float)__builtin_fma(rx, e.prll_x, ry * e.prll_y);
     f[1] = (float)__builtin_fma(ry, e.prll_x, -(rx * e.prll_y));
-    // (scalar float32 on purpose: left to itself the compiler packs the two dot products into v_pk_mul_f32 + v_pk_fma_f32 whose
-    //  third operand reads the product pair with its halves SWAPPED (op_sel:[0,0,1] op_sel_hi:[1,0,0]).  Inside the fused actor
-    //  kernel -- matrix instructions of the CU's other workgroup sharing the SIMD -- the low lane of that fma, v_par, came out
-    //  wrong now and then, run to run, for the neighbours whose mul and fma sat a few instructions apart; never in the env-only
-    //  kernels.  tools/repro_actor_case.py; the barriers keep the two chains out of the vectoriser's sight.)
+    // (scalar float32 on purpose.  Left to itself the compiler packs the dot products of the THIRD neighbour into
+    //      v_pk_mul_f32 t, (py, -py), (vx, vy) op_sel:[0,1] op_sel_hi:[1,0]     -- its SECOND source read with the halves swapped --
+    //  and on gfx950 a v_pk_mul_f32 / v_pk_add_f32 whose LOW result takes the HIGH half of its second source (op_sel[1] = 1) reads that
+    //  operand as 0 in lanes 48..63 now and then while another wavefront's MFMAs issue on the same SIMD: inside the fused actor kernel --
+    //  two workgroups per CU, the other one in its policy phase -- v_par came out as vx*px alone, run to run.  Round 5 found the instruction
+    //  by replacing it, and only it, with two v_mul_f32 in the compiler's assembly (tools/experiments/pk_isa_patch.py mul3_scalar), and
+    //  reproduces it in 60 lines: tools/ubench/pk_mul_src1_swap.hip, profiles/r05_b_pk_src1_swap_hazard.txt; the first-source and
+    //  third-source swaps, v_pk_mov_b32 and the swapped-halves v_pk_fma_f32 round 4 suspected are exact.  The barriers keep the chains out
+    //  of the vectoriser's sight; tests/test_binary_guard.py fails the build if ANY packed float32 instruction with a low-half swap
+    //  comes back.  -DCAVOID_DEV_PKFORM=0 restores the vectorised form for the bisect tools.)
 #if !defined(CAVOID_DEV_PKFORM)
     float t_par = q.vyf * pyf, t_orth = q.vxf * pyf;
     asm volatile("" : "+v"(t_par), "+v"(t_orth));
     f[2] = __builtin_fmaf(q.vxf, pxf, t_par);
     f[3] = __builtin_fmaf(q.vyf, pxf, -t_orth);
-#elif CAVOID_DEV_PKFORM == 0
-    // development (tools/experiments/pk_opsel_bisect.sh): the round-4 source, left to the vectoriser
+#else
     f[2] = __builtin_fmaf(q.vxf, pxf, q.vyf * pyf);
     f[3] = __builtin_fmaf(q.vyf, pxf, -(q.vxf * pyf));
-#else
-    // development: the packed pair spelled out -- (vx, vy) * (py, py), then (vx, vy) * (px, px) + swap(product) with the high half
-    // negated -- with what the bisect varies between and around the two instructions
-    typedef float pkf2 __attribute__((ext_vector_type(2)));
-    pkf2 v2 = {q.vxf, q.vyf}, py2 = {pyf, pyf}, px2 = {pxf, pxf}, t2, r2;
-#define CAVOID_PK_STR2(x) #x
-#define CAVOID_PK_STR(x) CAVOID_PK_STR2(x)
-#if CAVOID_DEV_PKFORM == 1          /* swapped-halves fma, CAVOID_DEV_PKNOPS wait states between the two (-1: none) */
-    asm volatile(
-#if defined(CAVOID_DEV_PKDRAIN)
-        "s_waitcnt lgkmcnt(0)\n\t"
-#endif
-        "v_pk_mul_f32 %1, %2, %3\n\t"
-#if CAVOID_DEV_PKNOPS >= 0
-        "s_nop " CAVOID_PK_STR(CAVOID_DEV_PKNOPS) "\n\t"
-#endif
-        "v_pk_fma_f32 %0, %2, %4, %1 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]"
-        : "=&v"(r2), "=&v"(t2) : "v"(v2), "v"(py2), "v"(px2));
-#elif CAVOID_DEV_PKFORM == 2        /* the same arithmetic, the swap made by two moves: no op_sel on the packed fma */
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t2) : "v"(v2), "v"(py2));
-    pkf2 s2 = {t2.y, t2.x};
-    asm volatile("" : "+v"(s2));
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[0,0,1]" : "=v"(r2) : "v"(v2), "v"(px2), "v"(s2));
-#elif CAVOID_DEV_PKFORM == 3        /* the swapped-halves pair as TWO asm statements: the scheduler is free to put work between them */
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t2) : "v"(v2), "v"(py2));
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]" : "=v"(r2) : "v"(v2), "v"(px2), "v"(t2));
-#elif CAVOID_DEV_PKFORM == 4        /* two statements, the swap moved into the MUL's source (old registers): the fma reads the fresh pair straight */
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t2) : "v"(v2), "v"(py2));   // (vy*py, -vx*py)
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r2) : "v"(v2), "v"(px2), "v"(t2));
-#elif CAVOID_DEV_PKFORM == 5        /* the pair, then an LDS read INTO the fma's third source pair right behind it (write after read) */
-    {
-        int zero = 0;
-        asm volatile(
-            "v_pk_mul_f32 %1, %2, %3\n\t"
-            "v_pk_fma_f32 %0, %2, %4, %1 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]\n\t"
-#if defined(CAVOID_DEV_PKGAP)
-            "s_nop 7\n\ts_nop 7\n\t"
-#endif
-            "ds_read_b64 %1, %5\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(r2), "=&v"(t2) : "v"(v2), "v"(py2), "v"(px2), "v"(zero) : "memory");
-    }
-#elif CAVOID_DEV_PKFORM == 6        /* as 5, the swap in the mul's old sources: a straight fma, then the LDS read into its third source */
-    {
-        int zero = 0;
-        asm volatile(
-            "v_pk_mul_f32 %1, %2, %3 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-            "v_pk_fma_f32 %0, %2, %4, %1\n\t"
-            "ds_read_b64 %1, %5\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(r2), "=&v"(t2) : "v"(v2), "v"(py2), "v"(px2), "v"(zero) : "memory");
-    }
-#elif CAVOID_DEV_PKFORM == 7        /* the swapped-halves fma IN PLACE: its destination pair is its third source pair (what the compiler
-                                       made of neighbour slots 1 and 2 -- v_pk_fma_f32 v[34:35], v[38:39], v[82:83], v[34:35] op_sel:[0,0,1]) */
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t2) : "v"(v2), "v"(py2));
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]" : "+v"(t2) : "v"(v2), "v"(px2));
-    r2 = t2;
-#elif CAVOID_DEV_PKFORM == 8        /* in place WITHOUT the swap (the swap made in the mul's old sources) */
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t2) : "v"(v2), "v"(py2));
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t2) : "v"(v2), "v"(px2));
-    r2 = t2;
-#endif
-    f[2] = r2.x;
-    f[3] = r2.y;
 #endif
     f[4] = q.r;
 }

@@ -1,11 +1,15 @@
 """Guards on the SHIPPED binary (CPU suite: llvm-objdump needs no GPU).
 
-The packed-float32 operand-swap hazard: a `v_pk_{fma,mul,add}_f32` whose `op_sel:[...]` makes a LOW
-result lane read the HIGH half of an operand gave run-to-run wrong values inside the fused actor kernel in round 4.  The sources keep
-every such chain scalar behind `asm` fences; this test is what makes that a property of the binary and not of today's compiler
-mood: every gfx950 code object of the in-tree `libcavoid_hip.so` is disassembled and must hold no packed-float32 instruction with a
-low-half swap (`op_sel_hi` broadcasts are fine and common).  A compiler bump or an innocent edit that re-introduces the pattern fails
-here, in seconds, instead of in a soak."""
+The packed-float32 operand-swap hazard (profiles/r05_b_pk_bisect.txt): on gfx950 a `v_pk_mul_f32` /
+`v_pk_add_f32` whose LOW result takes the HIGH half of its SECOND source (`op_sel:[0,1]`) reads that operand as 0 in lanes 48..63 now
+and then while another wavefront's MFMAs issue on the same SIMD -- stand-alone reproduction tools/ubench/pk_mul_src1_swap.hip; inside
+the fused actor kernel it gave run-to-run wrong observations in round 4.  The sources keep every such chain scalar behind `asm`
+fences; this test is what makes that a property of the binary and not of today's compiler mood: every gfx950 code object of the
+in-tree `libcavoid_hip.so` is disassembled and must hold NO packed-float32 arithmetic instruction whose `op_sel` lets a low result
+read a high half -- of any source: the first- and third-source swaps measured exact, but nothing here needs them either, and a
+guard that has to know which operand positions a part gets wrong is a guard that ages (`op_sel_hi` broadcasts are fine and
+common; `v_pk_mov_b32 op_sel:[1,0]`, measured exact, is what the compiler uses to move halves about and is not arithmetic).  A
+compiler bump or an innocent edit that re-introduces the pattern fails here, in seconds, instead of in a soak."""
 import os
 import re
 import shutil
@@ -67,10 +71,13 @@ def test_no_packed_float32_instruction_reads_a_swapped_low_half():
 
 
 def test_the_census_recognises_the_pattern():
-    """the regexes against the round-4 offender and its harmless relatives"""
+    """the regexes against the instruction that really misbehaves, round 4's suspect and their harmless relatives"""
+    culprit = "v_pk_mul_f32 v[34:35], v[86:87], v[42:43] op_sel:[0,1] op_sel_hi:[1,0]"
+    assert packed_f32_census(culprit) == (1, [culprit])
     offender = "v_pk_fma_f32 v[10:11], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_hi:[0,0,1]"
     fine = ["v_pk_fma_f32 v[10:11], v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0,1]", "v_pk_mul_f32 v[0:1], v[2:3], v[4:5]",
-            "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,0] op_sel_hi:[1,0]", "v_pk_fma_f16 v1, v2, v3, v4 op_sel:[0,0,1]"]
+            "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,0] op_sel_hi:[1,0]", "v_pk_fma_f16 v1, v2, v3, v4 op_sel:[0,0,1]",
+            "v_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]"]
     assert packed_f32_census(offender) == (1, [offender])
     assert packed_f32_census("\n".join(fine)) == (3, [])
     assert packed_f32_census("v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]")[1]
