@@ -919,9 +919,21 @@ def main() -> None:
         sh.close()
     else:
         env.close()
+    # ONE JSON line, and the LAST thing on stdout: RCCL prints a version banner through C stdio at its first communicator (buffered when
+    # stdout is a pipe or a file, i.e. it would surface at process exit, BEHIND the line) -- every rank flushes its C streams, then a
+    # barrier, then rank 0 prints
+    def flush_c_stdio():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:      # noqa: BLE001
+            pass
+        sys.stdout.flush()
+    flush_c_stdio()
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
+        flush_c_stdio()
     if rank == 0:
         print(json.dumps(line), flush=True)
 

@@ -116,3 +116,16 @@ def test_bench_one_gpu_with_the_exchange_through_forced_rccl():
     assert g["transport"] == "native" and g["uses_rccl"] and g["rccl_version"] >= 20000 and "ncclAllGather" in g["path"]
     assert g["comm_init_per_rank"] == ["ok"] and g["forms"]["all"]["agent_steps_per_s"] == line["value"]
     assert g["forms"]["all"]["bytes_per_link_per_step"] == 0          # one rank: nothing crosses a link
+
+
+@pytest.mark.gpu
+def test_the_json_line_is_the_last_line_of_stdout_even_with_rccl_banners():
+    """RCCL prints a version banner through C stdio at its first communicator; with stdout a pipe it is buffered and used to surface at
+    process exit, BEHIND the JSON line.  The line must be the last thing a run prints."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-rccl", "--steps", "20", "--warmup", "5", "--worlds", "1024", "--reps", "3",
+                          "--no-cpu-baseline", "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"], env=env, cwd=ROOT, timeout=900,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert lines and lines[-1].startswith("{") and json.loads(lines[-1])["n_gpus"] == 1, lines[-3:]
