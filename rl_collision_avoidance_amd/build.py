@@ -138,11 +138,38 @@ def build_fault(verbose: bool = False) -> str:
     return _link(objs, os.path.join(PKG_DIR, "libcavoid_hip_fault.so"), verbose)
 
 
+def build_ulp_fault(kind: int, verbose: bool = False) -> str:
+    """Development variants with ONE ulp-scale arithmetic fault in the env step (-DCAVOID_DEV_ULP_FAULT=kind: 1 = a float32 product in
+    the pair pass's distance, 2 = the position update contracted into fused multiply-adds, 3 = the sort key's centimetre bucket through
+    float32, 4 = a float32 product in the ORCA policy's squared distance), for tests/test_gpu_tie_classifier.py: what the parity harness and its tie classifier say about faults of the size the
+    classifier excuses.  Only the env kernels' translation units are recompiled (dev-only N = 4, 10); never loaded by the product."""
+    from concurrent.futures import ThreadPoolExecutor
+    objs = _compile_objects([], "", False, verbose)
+    jobs, swap = [], {}
+    for name in ("cavoid_capi.hip", "cavoid_multistep.hip", "cavoid_rvo.hip", "cavoid_relay.hip"):
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJ_DIR, name.replace(".hip", ".ulp%d.o" % kind))
+        deps = [src, os.path.join(ROOT, "include", "cavoid.h")] + [os.path.join(CSRC, h) for h in HEADERS[name]]
+        if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+            jobs.append([hipcc()] + FLAGS + EXTRA_FLAGS.get(name, []) + ["-DCAVOID_DEV_ULP_FAULT=%d" % kind, "-DCAVOID_DEV_ONLY_N", "-c", src, "-o", obj])
+        swap[os.path.join(OBJ_DIR, name.replace(".hip", ".o"))] = obj
+    if jobs:
+        if verbose:
+            for j in jobs:
+                print(" ".join(j), flush=True)
+        with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+            list(pool.map(subprocess.check_call, jobs))
+    return _link([swap.get(o, o) for o in objs], os.path.join(PKG_DIR, "libcavoid_hip_ulp%d.so" % kind), verbose)
+
+
 if __name__ == "__main__":
     import sys
     if "--trace" in sys.argv:
         print(build_trace(verbose=True))
     elif "--fault" in sys.argv:
         print(build_fault(verbose=True))
+    elif "--ulp-faults" in sys.argv:
+        for kind in (1, 2, 3, 4):
+            print(build_ulp_fault(kind, verbose=True))
     else:
         print(build(force=True, verbose=True))

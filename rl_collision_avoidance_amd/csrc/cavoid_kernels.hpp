@@ -555,7 +555,11 @@ __device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, co
         const OtherState q = st.other(o);
         const float rjf = q.r;
         const double rx = q.px - a.px, ry = q.py - a.py;
+#if defined(CAVOID_DEV_ULP_FAULT) && CAVOID_DEV_ULP_FAULT == 1     /* injected fault (tests/test_gpu_tie_classifier.py): one float32 product in the distance */
+        const double d = sqrt_dist2((double)((float)rx * (float)rx) + ry * ry);
+#else
         const double d = sqrt_dist2(rx * rx + ry * ry);
+#endif
         const bool other = present && (rjf >= 0.0f);
         bool collides = other;
         if (SW) {
@@ -571,7 +575,11 @@ __device__ __forceinline__ void pair_pass_impl(const KCfg &c, const Agent &a, co
         // the observation's gap, host-side association (d - r_host) - r_other; rint(gap*100) is
         // order-isomorphic to round(gap, 2) and integer-valued: exact in int32 (|gap| < 1e7 m)
         const double gap_o = d - ri - (double)rjf;
+#if defined(CAVOID_DEV_ULP_FAULT) && CAVOID_DEV_ULP_FAULT == 3     /* injected fault: the centimetre bucket of the sort key through float32 */
+        uint32_t hi = kKeyBias - (uint32_t)(int)rintf((float)gap_o * 100.0f);
+#else
         uint32_t hi = kKeyBias - (uint32_t)(int)rint(gap_o * 100.0);
+#endif
         // U7a flipped (order by the exact gap): the float32 rounding of the gap, one bit dropped -- monotonic, so different values
         // order exactly as the float64 gaps; equal ones fall back to the exact comparison (assemble_obs, tie_first)
         uint32_t lo = orderable((float)(ry * e.tx - rx * e.ty));
@@ -1077,7 +1085,11 @@ __device__ __forceinline__ void rvo_action(const KCfg &c, const Agent &a, int i,
         const float rjf = lds_r[j];
         if (jj == i || rjf < 0.0f) continue;
         const double rpx = lds_px[j] - a.px, rpy = lds_py[j] - a.py, rvx = hvx - lds_vx[j], rvy = hvy - lds_vy[j];
+#if defined(CAVOID_DEV_ULP_FAULT) && CAVOID_DEV_ULP_FAULT == 4     /* injected fault: one float32 product in the ORCA policy's squared distance */
+        const double dist_sq = (double)((float)rpx * (float)rpx) + rpy * rpy;
+#else
         const double dist_sq = rpx * rpx + rpy * rpy;
+#endif
         const double comb = c.cold->rvo_radius_scale * (double)a.radius + c.cold->rvo_radius_scale * (double)rjf, comb_sq = comb * comb;
         double dx, dy, ucx, ucy;
         if (dist_sq > comb_sq) {
@@ -1344,7 +1356,11 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
             nh = wrap_angle(dh + a.heading, c.switches);
             double sn = 0.0, cs = 1.0;
             if (!(CAVOID_SKIP & 32)) sincos_bounded(nh, &sn, &cs);
+#if defined(CAVOID_DEV_ULP_FAULT) && CAVOID_DEV_ULP_FAULT == 2     /* injected fault: the position update contracted into fused multiply-adds */
+            npx = __builtin_fma(a0 * cs, c.dt, a.px); npy = __builtin_fma(a0 * sn, c.dt, a.py);
+#else
             npx = a.px + a0 * cs * c.dt; npy = a.py + a0 * sn * c.dt;
+#endif
             nvx = a0 * cs; nvy = a0 * sn; nsp = a0;
         }
         a.px = moving ? npx : a.px; a.py = moving ? npy : a.py; a.heading = moving ? nh : a.heading;

@@ -134,6 +134,9 @@ def run(N, W, steps, seed, nonl, sort, mode=0, rvo=0.0, chunk=1, slots=False, po
 
 def main():
     """usage: python tests/parity_stress.py [seed offset ...]   (one pass over the case list per offset; default: one pass, offset 0)"""
+    if len(sys.argv) >= 3 and sys.argv[1] == "--one":      # one case, its result as a JSON line: --one '[N, W, steps, seed, nonl, sort, mode, rvo, chunk, slots, pool]'
+        print("RESULT " + json.dumps(run(*json.loads(sys.argv[2]))), flush=True)
+        return
     offsets = [int(x) for x in sys.argv[1:]] or [0]
     t0 = time.time()
     total = {"obs": 0.0, "rew": 0.0, "state": 0.0, "flag_mismatch": 0, "done_mismatch": 0, "episode_mismatch": 0, "ties": 0, "unexplained": 0, "agent_steps": 0}
