@@ -822,7 +822,11 @@ def main() -> None:
         # reset, ProcessAgent.py:107): the same K-step timed region with NO scenario pool -- every restart generates its scenario inside the
         # step kernel, exact (seed, global world id, episode) streams -- for GEN v1 (rings) and GEN v2 (boxes, rejection sampling)
         fresh = {}
-        for label, over in (("gen_v1_ring", {"gen_pool_size": 0}), ("gen_v2_box", {"gen_pool_size": 0, "gen_mode": 1})):
+        # ... and with the scenario LOOK-AHEAD (cavoid_cfg::gen_lookahead): the same fresh, exact scenarios (bitwise: tests/test_gpu_lookahead.py),
+        # generated by a small refill kernel in front of every K-step launch instead of inside the step -- the refill is inside these times
+        for label, over in (("gen_v1_ring", {"gen_pool_size": 0}), ("gen_v2_box", {"gen_pool_size": 0, "gen_mode": 1}),
+                            ("gen_v1_ring_lookahead", {"gen_pool_size": 0, "gen_lookahead": 128}),
+                            ("gen_v2_box_lookahead", {"gen_pool_size": 0, "gen_mode": 1, "gen_lookahead": 128})):
             try:
                 e0, a0 = make(W, N, **over)
                 s0 = None if args.overwrite_outputs else e0.new_step_slots(min(args.slices, max(args.steps, 1)))
@@ -846,8 +850,10 @@ def main() -> None:
                 del e0, a0
             except Exception as exc:      # noqa: BLE001
                 fresh[label] = {"error": repr(exc)}
-        fresh["note"] = ("gen_pool_size = 0: the scenario of every restarting world is generated in the step kernel (the reference makes a new "
-                         "random test case per reset); same K, same launch form and per-step output slots as the headline, this rank's GPU only")
+        fresh["note"] = ("gen_pool_size = 0: the scenario of every restarting world is a fresh generator scenario (the reference makes a new random test "
+                         "case per reset) -- generated in the step kernel (gen_v1_ring, gen_v2_box), or by the look-ahead refill in front of each launch "
+                         "(*_lookahead: same scenarios bit for bit, restart = a gather; `value` includes the refill kernel, `roofline` is the step kernel "
+                         "alone); same K, same per-step output slots as the headline, this rank's GPU only")
         extra["no_scenario_pool"] = fresh
 
     if args.full_loop or not args.no_full_loop:
@@ -887,8 +893,8 @@ def main() -> None:
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE %s: %d agents x %d worlds per GPU, unicycle dynamics, GEN v1 synthetic scenarios, "
                                "uniform random actions pre-staged on the device, in-kernel auto-reset -- a finished world RESTARTS BY GATHERING "
-                               "one of 65536 scenarios pre-generated outside the timed region (the same step with a fresh scenario generated "
-                               "in-kernel at every restart, GEN v1 and GEN v2: extra.no_scenario_pool); launches of up to %d steps "
+                               "one of 65536 scenarios pre-generated outside the timed region (the same step with a FRESH scenario at every restart -- "
+                               "generated in-kernel, or by the exact look-ahead refill -- GEN v1 and GEN v2: extra.no_scenario_pool); launches of up to %d steps "
                                "(world state in registers between the steps of a launch); %s%s"
                                % (which, N, W, args.slices,
                                   "every step overwrites one output slot" if args.overwrite_outputs else

@@ -102,7 +102,8 @@ typedef struct cavoid_cfg {
     int32_t sort_round_gap;    /* U7a: 1 (default) neighbours are ordered by the gap rounded to centimetres; 0: by the exact gap */
     int32_t sort_tie_lateral;  /* U7b: 1 (default) equal (rounded) gaps are ordered by the lateral offset p_orth, then agent index;
                                    0: by agent index alone (a stable sort on the gap) */
-    int32_t _pad0;
+    int32_t gen_lookahead;     /* R (power of two, 0 = off; needs gen_pool_size == 0): a FRESH scenario per episode without the generator on the step's
+                                * critical path -- see "scenario look-ahead" below.  (this word was padding up to ABI 3: zero = off) */
     double dt;                 /* DT 0.2 */
     double near_goal_threshold;/* 0.2 */
     double max_time_ratio;     /* 2.0 */
@@ -126,6 +127,11 @@ typedef struct cavoid_cfg {
      * path (cf. the reference env's fixed test-case sets, NUM_TEST_CASES run-ws/config.yaml:136-138).
      * 0 = every episode runs the generator in-kernel with counter (gw, ep).  Default 65536. */
     int32_t gen_pool_size;
+    /* scenario look-ahead (gen_pool_size == 0 and gen_lookahead = R > 0): every world owns a ring of R pre-generated scenarios of ITS OWN next
+     * episodes -- slot e % R holds the generator's scenario of (global world, episode e), the very one the in-kernel generator would make --
+     * refilled by a small kernel in front of the stepping launches (only the slots consumed since the last refill are generated), so a
+     * restart is a gather, as with the pool, but every episode is the fresh, exact scenario of gen_pool_size = 0 (bitwise: tests).  A launch
+     * may hold at most R - 1 steps (a world can restart at most once per step): more is CAVOID_EUNSUPPORTED.  Memory: W * R * N * 64 bytes. */
     /* GEN v2 (gen_mode = 1): starts and goals uniform in a box (half side ~ U(gen_box_small) for worlds of fewer than
      * gen_box_large_from agents, ~ U(gen_box_large) otherwise), agents placed one after the other by rejection sampling
      * against those already placed (starts and goals at least r_i + r_j + getting_close_range apart, trips of at least

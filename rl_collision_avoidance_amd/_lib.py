@@ -32,7 +32,7 @@ class CavoidCfg(C.Structure):
         ("max_agents", C.c_int32), ("max_other", C.c_int32), ("sort_method", C.c_int32), ("dynamics", C.c_int32),
         ("actions_fp32", C.c_int32), ("timeout_enabled", C.c_int32), ("num_actions", C.c_int32), ("evaluate_mode", C.c_int32),
         ("time_budget_from_goal_edge", C.c_int32), ("wrap_closed_end", C.c_int32), ("done_agents_collide", C.c_int32),
-        ("sort_round_gap", C.c_int32), ("sort_tie_lateral", C.c_int32), ("_pad0", C.c_int32),
+        ("sort_round_gap", C.c_int32), ("sort_tie_lateral", C.c_int32), ("gen_lookahead", C.c_int32),
         ("dt", C.c_double), ("near_goal_threshold", C.c_double), ("max_time_ratio", C.c_double),
         ("collision_dist", C.c_double), ("getting_close_range", C.c_double), ("reward_at_goal", C.c_double),
         ("reward_collision", C.c_double), ("reward_getting_close", C.c_double), ("reward_time_step", C.c_double),

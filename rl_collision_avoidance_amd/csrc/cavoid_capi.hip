@@ -114,6 +114,8 @@ static int validate(const cavoid_cfg *c) {
     if (!(c->dt > 0.0)) return CAVOID_EINVAL;
     if (c->gen_min_agents < 1 || c->gen_max_agents > c->max_agents || c->gen_min_agents > c->gen_max_agents) return CAVOID_EINVAL;
     if (c->gen_pool_size < 0 || c->gen_pool_size > (1 << 24)) return CAVOID_EINVAL;
+    if (c->gen_lookahead != 0 && (c->gen_pool_size != 0 || c->gen_lookahead < 2 || c->gen_lookahead > 4096 || (c->gen_lookahead & (c->gen_lookahead - 1))))
+        return CAVOID_EINVAL;                                                    /* look-ahead: no hashed pool beside it, R a power of two */
     if (c->gen_mode < 0 || c->gen_mode > 1) return CAVOID_EINVAL;
     if (c->gen_mode == 1 && !(c->gen_box_small[0] > 0.0 && c->gen_box_small[1] >= c->gen_box_small[0] &&
                               c->gen_box_large[0] > 0.0 && c->gen_box_large[1] >= c->gen_box_large[0] && c->gen_min_trip >= 0.0))
@@ -188,6 +190,17 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
             e->pool_episode = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(e->pool_slab) + recs);
         }
     }
+    if (rc == CAVOID_OK && cfg->gen_lookahead > 0) {                                  // scenario look-ahead: W rings of R records + filled_hi [W]
+        e->ahead_R = cfg->gen_lookahead;
+        e->pool_size = (int64_t)W * e->ahead_R;                                          // (> 0: the restart paths gather, as from a pool)
+        const size_t recs = (size_t)e->pool_size * (size_t)cfg->max_agents * sizeof(PoolRec);
+        if (hipMalloc(&e->pool_slab, recs + W * sizeof(uint32_t)) != hipSuccess) rc = CAVOID_ENOMEM;
+        else {
+            e->pool = static_cast<PoolRec *>(e->pool_slab);
+            e->ahead_hi = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(e->pool_slab) + recs);
+            if (hipMemset(e->ahead_hi, 0xFF, W * sizeof(uint32_t)) != hipSuccess) rc = CAVOID_EHIP;
+        }
+    }
     if (rc != CAVOID_OK) { g_last_hip_error = (int)hipGetLastError(); cavoid_destroy(e); return rc; }
     e->d_actions = reinterpret_cast<double *>(static_cast<unsigned char *>(e->slab) + o_act);
     if (hipMemset(e->st.episode, 0xFF, W * sizeof(uint32_t)) != hipSuccess ||
@@ -235,7 +248,8 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.max_other = cfg->max_other; k.width = 6 + 7 * cfg->max_other;
     k.sort_method = cfg->sort_method; k.dynamics = cfg->dynamics; k.actions_fp32 = cfg->actions_fp32;
     k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
-    k.pool_size = cfg->gen_pool_size;
+    k.pool_size = cfg->gen_lookahead > 0 ? (int32_t)(e->pool_size > 0x7fffffffLL ? 0x7fffffffLL : e->pool_size) : cfg->gen_pool_size;   // (look-ahead: only its sign is used)
+    k.ahead = cfg->gen_lookahead;
     k.evaluate_mode = cfg->evaluate_mode ? 1 : 0;
     k.stream_obs = (double)num_worlds * cfg->max_agents * (6 + 7 * cfg->max_other) * sizeof(float) > 16.0 * 1048576.0 ? 1 : 0;   // (measured: 10 x 262144 one step 213 -> 193 us, 4 x 65536 25.2 -> 24.5 us)
     if (const char *ov = std::getenv("CAVOID_STREAM_OBS")) k.stream_obs = std::atoi(ov) != 0;
@@ -255,10 +269,10 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     // latency mode (at most ~2 full wavefronts per SIMD): multi-step launches keep every lane's NEXT pool record in
     // registers (64 B read per agent per LAUNCH and per restart), so a restart never costs a dependent trip to
     // memory.  Single-step launches gather on demand unless CAVOID_PREFETCH_POOL=1 (then +64 B per agent-step).
-    e->latency_mode = (num_worlds * cfg->max_agents <= 64 * 2048 && cfg->gen_pool_size > 0) ? 1 : 0;
+    e->latency_mode = (num_worlds * cfg->max_agents <= 64 * 2048 && (cfg->gen_pool_size > 0 || cfg->gen_lookahead > 0)) ? 1 : 0;
     if (const char *ov = std::getenv("CAVOID_PREFETCH_POOL")) {
         const int v = std::atoi(ov);
-        e->latency_mode = (v != 0 && cfg->gen_pool_size > 0) ? 1 : 0;
+        e->latency_mode = (v != 0 && (cfg->gen_pool_size > 0 || cfg->gen_lookahead > 0)) ? 1 : 0;
         e->prefetch_single = e->latency_mode;
     }
     k.prefetch_pool = e->latency_mode;
@@ -327,9 +341,44 @@ static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_sta
     return launch_on<MODE>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
 }
 
+// scenario look-ahead (cavoid.h, gen_lookahead): every world's ring must hold the scenarios of the episodes the next n_steps steps can start
+// (at most one restart per world and step) + the one a restarted world prefetches.  A K-step launch, a launch being captured into a hipGraph
+// and the fused actor launches refill in front of EVERY launch (steady state: the few episodes consumed since the last refill, ~4 us); one-step
+// launches refill when the guaranteed cover runs out (every R - 2 steps).
+int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
+    if (!e || e->ahead_R <= 0) return CAVOID_OK;
+    if (n_steps + 1 > e->ahead_R) return CAVOID_EUNSUPPORTED;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool always = n_steps > 1 || cap != hipStreamCaptureStatusNone;
+    if (!always && e->ahead_budget >= n_steps + 1) { e->ahead_budget -= n_steps; return CAVOID_OK; }
+    const int64_t waves = (e->W + e->k.wpw - 1) / e->k.wpw;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define CAVOID_AHEAD_CASE(NN) case NN: hipLaunchKernelGGL((ahead_fill_kernel<NN>), grid, block, 0, s, e->k, e->st.episode, e->ahead_hi, e->pool, e->ahead_R); break;
+    switch (e->cfg.max_agents) {
+#ifdef CAVOID_DEV_ONLY_N
+        CAVOID_AHEAD_CASE(4) CAVOID_AHEAD_CASE(10)
+#else
+        CAVOID_AHEAD_CASE(1) CAVOID_AHEAD_CASE(2) CAVOID_AHEAD_CASE(3) CAVOID_AHEAD_CASE(4) CAVOID_AHEAD_CASE(5) CAVOID_AHEAD_CASE(6)
+        CAVOID_AHEAD_CASE(7) CAVOID_AHEAD_CASE(8) CAVOID_AHEAD_CASE(9) CAVOID_AHEAD_CASE(10) CAVOID_AHEAD_CASE(11) CAVOID_AHEAD_CASE(12)
+        CAVOID_AHEAD_CASE(13) CAVOID_AHEAD_CASE(14) CAVOID_AHEAD_CASE(15) CAVOID_AHEAD_CASE(16)
+#endif
+        default: return CAVOID_EUNSUPPORTED;
+    }
+#undef CAVOID_AHEAD_CASE
+    HIP_TRY(hipGetLastError());
+    e->ahead_budget = always ? 0 : e->ahead_R - n_steps;       // (a captured / multi-step sequence never relies on a budget)
+    return CAVOID_OK;
+}
+
 // (re)fill the scenario pool for the current seed: the RESET kernel run over the pool buffer as
 // worlds 0..P-1 of episode k.pool_epoch, generator (GEN v1 or v2) in-kernel
 static int fill_pool(cavoid_env *e, hipStream_t s) {
+    if (e->ahead_R > 0) {                                      // look-ahead rings: nothing of the old seed / episodes stays valid
+        e->ahead_budget = 0;
+        HIP_TRY(hipMemsetAsync(e->ahead_hi, 0xFF, (size_t)e->W * sizeof(uint32_t), s));
+        return CAVOID_OK;
+    }
     if (e->pool_size <= 0) return CAVOID_OK;
     HIP_TRY(hipMemsetAsync(e->pool_episode, 0xFF, (size_t)e->pool_size * sizeof(uint32_t), s));
     KCfg k = e->k;
@@ -407,6 +456,7 @@ extern "C" int cavoid_reset(cavoid_env *e, const uint8_t *world_mask, float *obs
     if (!e) return CAVOID_EINVAL;
     KIO io = plain_io(e, obs, nullptr, nullptr, nullptr);
     io.mask = world_mask;
+    if (int rc = cavoid_ahead_prepare(e, 1, static_cast<hipStream_t>(stream))) return rc;     // (a reset starts every masked world's NEXT episode)
     return launch<MODE_RESET>(e, io, static_cast<hipStream_t>(stream));
 }
 
@@ -414,6 +464,7 @@ extern "C" int cavoid_reset_packed(cavoid_env *e, const uint8_t *world_mask, flo
     if (!e || !packed) return CAVOID_EINVAL;
     KIO io = packed_io(e, packed, nullptr);
     io.mask = world_mask;
+    if (int rc = cavoid_ahead_prepare(e, 1, static_cast<hipStream_t>(stream))) return rc;
     return launch<MODE_RESET>(e, io, static_cast<hipStream_t>(stream));
 }
 
@@ -465,6 +516,7 @@ static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64
     io.actions = actions;
     io.action_stride = action_stride;
     io.n_steps = n_steps;
+    if (int rc = cavoid_ahead_prepare(e, n_steps, s)) return rc;
     if (n_steps > 1 || e->prefetch_single)                      // the in-launch step loop lives in cavoid_multistep.hip
         return cavoid_launch_multistep(e, io, e->latency_mode != 0, s, ev_start, ev_stop);
     return launch<MODE_STEP_AUTORESET>(e, io, s, ev_start, ev_stop);

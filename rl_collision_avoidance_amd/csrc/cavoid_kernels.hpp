@@ -80,6 +80,7 @@ struct KCfg {
     int32_t gen_mode, rvo_enabled;
     uint32_t pool_epoch;         // the pool holds generator worlds 0..P-1 of this episode index
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
+    int32_t ahead;               // R > 0: the "pool" is the look-ahead ring (slot ep % R of this world: exact fresh scenarios), not the hashed pool
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
     int32_t wpw;                 // worlds per wavefront, 1..floor(64/N): small batches spread over more, emptier wavefronts
@@ -952,6 +953,8 @@ __device__ __forceinline__ void store_agent(const KState &s, int64_t k, const Ag
 // reduced to [0, P) by multiply-shift (no division).  Cheap on purpose: it sits on the critical path
 // of every wavefront in which a world restarts.  (GEN v1 itself keeps Philox4x32-10.)
 __device__ __forceinline__ uint32_t pool_index(const KCfg &c, uint32_t gw, uint32_t ep) {
+    if (c.ahead > 0)                                            // look-ahead ring: this world's own slot of episode ep (R a power of two)
+        return (gw - (uint32_t)c.world_offset) * (uint32_t)c.ahead + (ep & (uint32_t)(c.ahead - 1));
     uint64_t z = ((uint64_t)c.seed_hi << 32 | c.seed_lo) + 0x9E3779B97F4A7C15ull * ((uint64_t)gw + 1ull) +
                  0xC2B2AE3D27D4EB4Full * ((uint64_t)ep + 1ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -978,6 +981,55 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, 
     } else {
         generate_agent<N>(c, gw, ep, i, a);
     }
+}
+
+// ---- scenario look-ahead (cavoid_cfg::gen_lookahead = R): refill of every world's ring with the scenarios of its NEXT episodes ----------
+// One lane per (world, agent), the env step's lane mapping.  filled_hi[w] = the highest episode whose scenario is in world w's ring
+// (slots of episodes (filled_hi - R, filled_hi] are valid; 0xFFFFFFFF = nothing yet); the launch generates episodes
+// max(filled_hi, episode) + 1 .. episode + need -- in the steady state the one or two a world consumed since the last refill -- with the
+// generator of (seed, GLOBAL world id, episode): GEN v1 per lane, GEN v2 wave-cooperatively, exactly what the in-kernel restart of
+// gen_pool_size = 0 computes (tests/test_gpu_lookahead.py holds the two bitwise equal).
+template <int N>
+__global__ void __launch_bounds__(256) ahead_fill_kernel(const KCfg c, const uint32_t *episode, uint32_t *filled_hi, PoolRec *ahead, const int need) {
+    __shared__ double sh_d[4][4][64];
+    __shared__ float sh_r[4][64];
+    const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wave_in_block;
+    const int wpw = c.wpw, lanes_used = wpw * N;
+    const int lw = lane / N, i = lane - lw * N;
+    const int64_t w = wave * wpw + lw;
+    const bool active = lane < lanes_used && w < c.num_worlds;
+    const int base = lane < lanes_used ? lw * N : 0;
+    uint32_t ep = 0u, fh = 0u;
+    if (active) {
+        ep = episode[w];
+        fh = filled_hi[w];
+        if (fh == 0xFFFFFFFFu || (int32_t)(fh - ep) < 0) fh = ep;      // nothing valid ahead of this world's current episode
+    }
+    const uint32_t target = ep + (uint32_t)need;
+    int missing = active ? (int)(int32_t)(target - fh) : 0;
+    missing = missing < 0 ? 0 : missing;
+    int trips = missing;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(trips, o, 64); trips = v > trips ? v : trips; }
+    const uint32_t gw = (uint32_t)(c.world_offset + w);
+    for (int k = 0; k < trips; ++k) {                           // (wave-uniform)
+        const uint32_t e = fh + 1u + (uint32_t)k;
+        const bool fresh = active && k < missing;
+        Agent a;
+        absent_agent(a);
+        if (c.gen_mode == 1) generate_world_v2<N>(c, gw, e, i, base, lane, fresh, sh_d[wave_in_block][0], sh_d[wave_in_block][1], sh_d[wave_in_block][2],
+                                                  sh_d[wave_in_block][3], sh_r[wave_in_block], a);
+        else if (fresh) generate_agent<N>(c, gw, e, i, a);
+        if (fresh) {
+            PoolRec r;
+            r.px = a.px; r.py = a.py; r.heading = a.heading; r.t_rem = a.t_rem;
+            r.gx = a.gx; r.gy = a.gy; r.radius = a.radius; r.pref = a.pref;
+            r.flags = a.flags; r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+            ahead[((int64_t)w * c.ahead + (int64_t)(e & (uint32_t)(c.ahead - 1))) * N + i] = r;
+        }
+    }
+    if (active && i == 0 && missing > 0) filled_hi[w] = target;
 }
 
 // ---- RVO scripted policy: ORCA, van den Berg et al., "Reciprocal n-body collision avoidance"

@@ -18,6 +18,9 @@ struct cavoid_env {
     cavoid::PoolRec *pool = nullptr;     // pre-generated scenarios (GEN v1 worlds 0..P-1, episode 0), 64-byte records
     uint32_t *pool_episode = nullptr;   // [P] scratch episode counters for the fill launch
     int64_t pool_size = 0;
+    int ahead_R = 0;                    // scenario look-ahead (cfg.gen_lookahead): `pool` is then every world's ring of R records, filled by ahead_fill_kernel
+    uint32_t *ahead_hi = nullptr;       // [W] highest episode in each world's ring (0xFFFFFFFF: none)
+    int ahead_budget = 0;               // restarts per world the ring is still guaranteed to cover without a refill
     void *slab = nullptr;
     void *pool_slab = nullptr;
     double *d_actions = nullptr;
@@ -110,6 +113,9 @@ static inline int launch_pipe(cavoid_env *e, const KIO &io, hipStream_t s, hipEv
 
 }  // namespace cavoid
 
+// scenario look-ahead: make sure every world's ring covers the restarts `n_steps` more steps can bring (a no-op without look-ahead);
+// CAVOID_EUNSUPPORTED when n_steps + 1 > R (cavoid_capi.hip)
+int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s);
 // env_relay_kernel (cavoid_relay.hip): CAVOID_EUNSUPPORTED when the batch is too large for it or its LDS does not fit
 int cavoid_launch_relay(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-step auto-reset launch (cavoid_multistep.hip): prefetch != 0 -> MODE_STEP_AUTORESET_PF, else MODE_STEP_AUTORESET_N

@@ -70,7 +70,7 @@ def test_bench_two_rank_dry_run_on_one_device():
         assert (f["xgmi_frac"] is None) if mode == "none" else (abs(f["link_bound_us_per_step"] - rec / 153e3) < 1e-9 and f["xgmi_frac"] > 0)
     assert g["forms"]["all"]["agent_steps_per_s"] == line["value"]
     # the reference's reset semantics beside the pooled headline: a fresh scenario generated in-kernel at every restart
-    for label in ("gen_v1_ring", "gen_v2_box"):
+    for label in ("gen_v1_ring", "gen_v2_box", "gen_v1_ring_lookahead", "gen_v2_box_lookahead"):
         f = line["extra"]["no_scenario_pool"][label]
         assert "error" not in f and f["value"] > 0 and f["restarts_in_timed_region"] > 0, f
 
