@@ -34,6 +34,7 @@ static int actor_run(cavoid_env *e, cavoid_policy *h, cavoid_policy *frozen, cav
         return frozen->loaded ? CAVOID_EUNSUPPORTED : CAVOID_EINVAL;
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_a = cavoid_ahead_prepare(e, n_steps, static_cast<hipStream_t>(stream))) return rc_a;     // (scenario look-ahead: the rings cover n_steps restarts)
+    cavoid_ahead_consumed(e, n_steps);
     const KCfg &k = e->k;
     // ORCA agents / box scenarios generated inside the step: the env step's RVO instantiation (as cavoid_step_autoreset routes them)
     const bool rvo_form = e->cfg.rvo_enabled || (e->cfg.gen_mode == 1 && e->pool_size <= 0);
@@ -100,6 +101,7 @@ extern "C" int cavoid_step_push(cavoid_env *e, cavoid_rollout *r, const cavoid_r
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc_a = cavoid_ahead_prepare(e, 1, s)) return rc_a;
+    cavoid_ahead_consumed(e, 1);
     RolloutCfg rc = r->c;
     rc.dup_capacity = b->dup_capacity; rc.ep_capacity = b->ep_capacity;
     RolloutIO rio{};

@@ -250,6 +250,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
     k.pool_size = cfg->gen_lookahead > 0 ? (int32_t)(e->pool_size > 0x7fffffffLL ? 0x7fffffffLL : e->pool_size) : cfg->gen_pool_size;   // (look-ahead: only its sign is used)
     k.ahead = cfg->gen_lookahead;
+    k.ahead_hi = e->ahead_hi;
     k.evaluate_mode = cfg->evaluate_mode ? 1 : 0;
     k.stream_obs = (double)num_worlds * cfg->max_agents * (6 + 7 * cfg->max_other) * sizeof(float) > 16.0 * 1048576.0 ? 1 : 0;   // (measured: 10 x 262144 one step 213 -> 193 us, 4 x 65536 25.2 -> 24.5 us)
     if (const char *ov = std::getenv("CAVOID_STREAM_OBS")) k.stream_obs = std::atoi(ov) != 0;
@@ -342,16 +343,22 @@ static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_sta
 }
 
 // scenario look-ahead (cavoid.h, gen_lookahead): every world's ring must hold the scenarios of the episodes the next n_steps steps can start
-// (at most one restart per world and step) + the one a restarted world prefetches.  A K-step launch, a launch being captured into a hipGraph
-// and the fused actor launches refill in front of EVERY launch (steady state: the few episodes consumed since the last refill, ~4 us); one-step
-// launches refill when the guaranteed cover runs out (every R - 2 steps).
+// (at most one restart per world and step) + the one a restarted world prefetches.  The host keeps a guaranteed-cover budget: a refill launch
+// (ahead_fill_kernel: only the episodes consumed since the last refill are generated, ~6 us) goes in front of a stepping launch when the budget
+// does not cover it -- one per ~R / K launches of K steps, one per R - 2 one-step launches.  A sequence captured into a hipGraph always carries
+// the refill (a no-op when nothing is missing), and once such a graph exists every launch does (replays consume episodes the host does not see).
+// (Measured and dropped, profiles/r05_e_lookahead.txt: the refill on a side stream beside the previous launch -- the cross-stream event wait costs
+// what the refill launch costs; the refill inside env_relay_kernel, by its loader role in idle time -- +5 % on the kernel -- or by extra
+// workgroups of the same launch -- they displace tile workgroups, which must all be resident.)
 int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
     if (!e || e->ahead_R <= 0) return CAVOID_OK;
     if (n_steps + 1 > e->ahead_R) return CAVOID_EUNSUPPORTED;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
-    const bool always = n_steps > 1 || cap != hipStreamCaptureStatusNone;
-    if (!always && e->ahead_budget >= n_steps + 1) { e->ahead_budget -= n_steps; return CAVOID_OK; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    // a sequence being captured into a hipGraph cannot rely on host-side bookkeeping at replay time: it always carries the refill
+    if (capturing) e->ahead_always = true;
+    if (!e->ahead_always && e->ahead_primed && e->ahead_budget >= n_steps + 1) return CAVOID_OK;
     const int64_t waves = (e->W + e->k.wpw - 1) / e->k.wpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
 #define CAVOID_AHEAD_CASE(NN) case NN: hipLaunchKernelGGL((ahead_fill_kernel<NN>), grid, block, 0, s, e->k, e->st.episode, e->ahead_hi, e->pool, e->ahead_R); break;
@@ -367,8 +374,13 @@ int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
     }
 #undef CAVOID_AHEAD_CASE
     HIP_TRY(hipGetLastError());
-    e->ahead_budget = always ? 0 : e->ahead_R - n_steps;       // (a captured / multi-step sequence never relies on a budget)
+    if (!capturing) { e->ahead_primed = true; e->ahead_budget = e->ahead_R; }
     return CAVOID_OK;
+}
+// after a stepping launch of n_steps steps: what the rings are still guaranteed to cover (a world restarts at most once per step)
+void cavoid_ahead_consumed(cavoid_env *e, int32_t n_steps) {
+    if (!e || e->ahead_R <= 0) return;
+    e->ahead_budget = e->ahead_budget > n_steps ? e->ahead_budget - n_steps : 0;
 }
 
 // (re)fill the scenario pool for the current seed: the RESET kernel run over the pool buffer as
@@ -376,6 +388,7 @@ int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
 static int fill_pool(cavoid_env *e, hipStream_t s) {
     if (e->ahead_R > 0) {                                      // look-ahead rings: nothing of the old seed / episodes stays valid
         e->ahead_budget = 0;
+        e->ahead_primed = false;
         HIP_TRY(hipMemsetAsync(e->ahead_hi, 0xFF, (size_t)e->W * sizeof(uint32_t), s));
         return CAVOID_OK;
     }
@@ -457,6 +470,7 @@ extern "C" int cavoid_reset(cavoid_env *e, const uint8_t *world_mask, float *obs
     KIO io = plain_io(e, obs, nullptr, nullptr, nullptr);
     io.mask = world_mask;
     if (int rc = cavoid_ahead_prepare(e, 1, static_cast<hipStream_t>(stream))) return rc;     // (a reset starts every masked world's NEXT episode)
+    cavoid_ahead_consumed(e, 1);
     return launch<MODE_RESET>(e, io, static_cast<hipStream_t>(stream));
 }
 
@@ -465,6 +479,7 @@ extern "C" int cavoid_reset_packed(cavoid_env *e, const uint8_t *world_mask, flo
     KIO io = packed_io(e, packed, nullptr);
     io.mask = world_mask;
     if (int rc = cavoid_ahead_prepare(e, 1, static_cast<hipStream_t>(stream))) return rc;
+    cavoid_ahead_consumed(e, 1);
     return launch<MODE_RESET>(e, io, static_cast<hipStream_t>(stream));
 }
 
@@ -517,9 +532,11 @@ static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64
     io.action_stride = action_stride;
     io.n_steps = n_steps;
     if (int rc = cavoid_ahead_prepare(e, n_steps, s)) return rc;
-    if (n_steps > 1 || e->prefetch_single)                      // the in-launch step loop lives in cavoid_multistep.hip
-        return cavoid_launch_multistep(e, io, e->latency_mode != 0, s, ev_start, ev_stop);
-    return launch<MODE_STEP_AUTORESET>(e, io, s, ev_start, ev_stop);
+    const int rc = (n_steps > 1 || e->prefetch_single)           // the in-launch step loop lives in cavoid_multistep.hip
+                       ? cavoid_launch_multistep(e, io, e->latency_mode != 0, s, ev_start, ev_stop)
+                       : launch<MODE_STEP_AUTORESET>(e, io, s, ev_start, ev_stop);
+    cavoid_ahead_consumed(e, n_steps);
+    return rc;
 }
 
 extern "C" int cavoid_step_autoreset(cavoid_env *e, const int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {

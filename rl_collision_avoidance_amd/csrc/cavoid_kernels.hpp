@@ -81,6 +81,7 @@ struct KCfg {
     uint32_t pool_epoch;         // the pool holds generator worlds 0..P-1 of this episode index
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     int32_t ahead;               // R > 0: the "pool" is the look-ahead ring (slot ep % R of this world: exact fresh scenarios), not the hashed pool
+    uint32_t *ahead_hi;          // [W] highest episode in each world's ring (look-ahead only; kernels that refill their own rings keep it current)
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
     int32_t wpw;                 // worlds per wavefront, 1..floor(64/N): small batches spread over more, emptier wavefronts
@@ -989,12 +990,11 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, 
 // max(filled_hi, episode) + 1 .. episode + need -- in the steady state the one or two a world consumed since the last refill -- with the
 // generator of (seed, GLOBAL world id, episode): GEN v1 per lane, GEN v2 wave-cooperatively, exactly what the in-kernel restart of
 // gen_pool_size = 0 computes (tests/test_gpu_lookahead.py holds the two bitwise equal).
+// one wavefront's share of the refill: `wave` = index of the 64-lane tile of (world, agent) slots, scratch = 4 x 64 doubles + 64 floats of
+// wave-private LDS (GEN v2 only).  A device function so that kernels can carry refill work beside their own (env_relay_kernel's extra blocks).
 template <int N>
-__global__ void __launch_bounds__(256) ahead_fill_kernel(const KCfg c, const uint32_t *episode, uint32_t *filled_hi, PoolRec *ahead, const int need) {
-    __shared__ double sh_d[4][4][64];
-    __shared__ float sh_r[4][64];
-    const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wave_in_block;
+__device__ __forceinline__ void ahead_fill_wave(const KCfg &c, const uint32_t *episode, uint32_t *filled_hi, PoolRec *ahead, const int need,
+                                                const int64_t wave, const int lane, double *sc_d, float *sc_r) {
     const int wpw = c.wpw, lanes_used = wpw * N;
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = wave * wpw + lw;
@@ -1018,8 +1018,7 @@ __global__ void __launch_bounds__(256) ahead_fill_kernel(const KCfg c, const uin
         const bool fresh = active && k < missing;
         Agent a;
         absent_agent(a);
-        if (c.gen_mode == 1) generate_world_v2<N>(c, gw, e, i, base, lane, fresh, sh_d[wave_in_block][0], sh_d[wave_in_block][1], sh_d[wave_in_block][2],
-                                                  sh_d[wave_in_block][3], sh_r[wave_in_block], a);
+        if (c.gen_mode == 1) generate_world_v2<N>(c, gw, e, i, base, lane, fresh, sc_d, sc_d + 64, sc_d + 128, sc_d + 192, sc_r, a);
         else if (fresh) generate_agent<N>(c, gw, e, i, a);
         if (fresh) {
             PoolRec r;
@@ -1030,6 +1029,14 @@ __global__ void __launch_bounds__(256) ahead_fill_kernel(const KCfg c, const uin
         }
     }
     if (active && i == 0 && missing > 0) filled_hi[w] = target;
+}
+
+template <int N>
+__global__ void __launch_bounds__(256) ahead_fill_kernel(const KCfg c, const uint32_t *episode, uint32_t *filled_hi, PoolRec *ahead, const int need) {
+    __shared__ double sh_d[4][4 * 64];
+    __shared__ float sh_r[4][64];
+    const int wave_in_block = threadIdx.x >> 6;
+    ahead_fill_wave<N>(c, episode, filled_hi, ahead, need, (int64_t)blockIdx.x * 4 + wave_in_block, threadIdx.x & 63, sh_d[wave_in_block], sh_r[wave_in_block]);
 }
 
 // ---- RVO scripted policy: ORCA, van den Berg et al., "Reciprocal n-body collision avoidance"

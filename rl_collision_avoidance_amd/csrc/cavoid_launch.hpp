@@ -21,6 +21,9 @@ struct cavoid_env {
     int ahead_R = 0;                    // scenario look-ahead (cfg.gen_lookahead): `pool` is then every world's ring of R records, filled by ahead_fill_kernel
     uint32_t *ahead_hi = nullptr;       // [W] highest episode in each world's ring (0xFFFFFFFF: none)
     int ahead_budget = 0;               // restarts per world the ring is still guaranteed to cover without a refill
+    bool ahead_primed = false;          // the rings have been filled once for the current seed / episodes
+    bool ahead_always = false;          // a hipGraph holding stepping launches of this env exists: replays consume episodes the host does not see,
+                                        // so from then on every launch carries the refill (a no-op when nothing is missing)
     void *slab = nullptr;
     void *pool_slab = nullptr;
     double *d_actions = nullptr;
@@ -116,6 +119,7 @@ static inline int launch_pipe(cavoid_env *e, const KIO &io, hipStream_t s, hipEv
 // scenario look-ahead: make sure every world's ring covers the restarts `n_steps` more steps can bring (a no-op without look-ahead);
 // CAVOID_EUNSUPPORTED when n_steps + 1 > R (cavoid_capi.hip)
 int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s);
+void cavoid_ahead_consumed(cavoid_env *e, int32_t n_steps);     // call after the stepping launch that cavoid_ahead_prepare(n_steps) preceded
 // env_relay_kernel (cavoid_relay.hip): CAVOID_EUNSUPPORTED when the batch is too large for it or its LDS does not fit
 int cavoid_launch_relay(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-step auto-reset launch (cavoid_multistep.hip): prefetch != 0 -> MODE_STEP_AUTORESET_PF, else MODE_STEP_AUTORESET_N
