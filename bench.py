@@ -782,6 +782,30 @@ def main() -> None:
         except Exception as exc:      # noqa: BLE001 -- report, never lose the headline
             extra["configs2_gather"] = {"error": repr(exc)}
 
+    # "also report vs a measured device-copy ceiling" -- a 1 GiB device-to-device copy on this box (read + write bytes / time)
+    def measured_copy_GBps():
+        try:
+            n = 1 << 28
+            a, b = torch.empty(n, dtype=torch.float32, device=device), torch.empty(n, dtype=torch.float32, device=device)
+            a.fill_(1.0)
+            b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize(device)
+            del a, b
+            return 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        except Exception:      # noqa: BLE001 -- a reporting aid
+            return None
+    if rank == 0:
+        copy_gbps = measured_copy_GBps()
+        if copy_gbps:
+            roofline["measured_copy_GBps"] = copy_gbps
+            roofline["frac_of_measured_copy"] = roofline["achieved"] / copy_gbps
+            roofline["one_step_launch"]["frac_of_measured_copy"] = roofline["one_step_launch"]["achieved"] / copy_gbps
     if rank == 0 and world_size == 1 and not args.no_pmc:
         add_traffic(roofline, N, W)
     for form in (roofline, roofline["one_step_launch"]):
