@@ -67,8 +67,14 @@ __host__ __device__ constexpr size_t relay_lds_fixed_bytes() {
     do {                                                                                                       \
         if (lane0 == 0 && g_trace && t == (n_steps >> 1)) g_trace[wave * 32 + (k)] = (unsigned long long)clock64(); \
     } while (0)
+// launch-level marks (not tied to a step): kernel entry / prologue done / first step posted / loop done / exit, per role (tools/trace_relay.py --launch)
+#define RELAY_MARK(k)                                                                                          \
+    do {                                                                                                       \
+        if (lane0 == 0 && g_trace) g_trace[wave * 32 + (k)] = (unsigned long long)clock64();                   \
+    } while (0)
 #else
 #define RELAY_STAMP(k) do { } while (0)
+#define RELAY_MARK(k) do { } while (0)
 #endif
 
 // the counters are read and written through explicit LDS (address space 3) volatile pointers: ds_read_b32 / ds_write_b32, not
@@ -237,6 +243,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     if (role == 0) {
         // ================================================ D: state owner =====================================================
         __builtin_amdgcn_s_setprio(3);
+        RELAY_MARK(20);                                    // D: kernel entry
         KCfg cd = c;                                        // this role's constants, pinned in scalar registers (see P)
         asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
                      "+s"(cd.timeout_enabled), "+s"(cd.switches));
@@ -256,6 +263,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         const bool present_first = active && (a.flags & CAVOID_F_PRESENT);
         bool restarted_any = false, moved_any = false;
         __syncthreads();                                   // table, counters, the loader's first records and actions
+        RELAY_MARK(21);                                    // D: state, table and the first actions are in
         int events = 0;
         bool T_moving;
         Agent T;
@@ -278,6 +286,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         stage_out(tents[0], T, lane0);
         relay_post(&seq->spec, 1);
         relay_post(&seq->stage, 1);
+        RELAY_MARK(22);                                    // D: step 0 posted
         int cslot = 0;                                      // (t + 1 - ring) mod NC, kept by counting
         // steps 0 .. n-2: each iteration posts the successor (step t+1) and then settles step t; the last step is settled below
         for (int t = 0; t + 1 < n_steps; ++t) {
@@ -377,6 +386,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             }
             relay_post(&seq->fin, t + 1);
         }
+        RELAY_MARK(23);                                    // D: last step settled
         relay_post(&seq->stage, n_steps + 1);               // (the loader may leave: no restart is waiting for a record any more)
         // ---- state write-back (once per launch) ------------------------------------------------------------------------------
         if (restarted_any) {
@@ -389,6 +399,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             s.speed[a_idx0] = S.speed;
             s.flags[a_idx0] = S.flags;
         }
+        RELAY_MARK(24);                                    // D: write-back issued
     } else if (role == 1) {
         // ================================================ P: pair pass, rewards, done ==========================================
         __builtin_amdgcn_s_setprio(3);
@@ -470,6 +481,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     } else if (role == 2 + NC) {
         // ================================================ L: actions and pool records ==========================================
         __builtin_amdgcn_s_setprio(1);
+        RELAY_MARK(25);                                    // L: kernel entry
         uint32_t ep = 0u;
         if (active) ep = s.episode[w];
         int loaded = 0;
@@ -491,6 +503,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             }
         };
         load_actions(n_steps < 8 ? n_steps : 8);            // enough for D to start; the rest follows while the loop runs
+        RELAY_MARK(26);                                    // L: first action batch in LDS
         __syncthreads();
         relay_post(&seq->act, loaded);
         // the next scenario-pool record of every lane: two dependent trips to memory (episode -> pool index -> record) that nobody
@@ -504,6 +517,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             nb.gx[lane0] = r0.gx; nb.gy[lane0] = r0.gy; nb.radius[lane0] = r0.radius; nb.pref[lane0] = r0.pref;
             nb.flags[lane0] = r0.flags;
             relay_post(&seq->nxt, 1);
+            RELAY_MARK(27);                                // L: first pool records posted
         }
         int served = 0, idle_polls = 0;
         while (true) {
@@ -591,8 +605,11 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             }
             relay_post(&seq->cons[cid], t + 1);
             RELAY_STAMP(19);                               // C: rows flushed
+            if (t == 0) RELAY_MARK(28);                    // C: step 0's rows flushed
+            if (t == n_steps - 1) RELAY_MARK(29);          // C: the last step's rows flushed
         }
         __builtin_amdgcn_s_waitcnt(0);                     // every store of this consumer has completed
+        if (cid == 0) RELAY_MARK(30);                      // C0: its stores have completed
         relay_post(&seq->cfin[cid], 1);
     }
 }

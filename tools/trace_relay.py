@@ -24,7 +24,7 @@ NAMES = {0: "D iteration begins", 1: "D successor posted", 2: "D verdict arrived
 def main():
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    K = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    K = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith('-') else 32
 
     class Cfg(EnvConfig):
         def __init__(self):
@@ -52,6 +52,18 @@ def main():
         for k in sorted(NAMES):
             d = t[:, k] - t[:, 0]
             print("   %-26s median %6d  p10 %6d  p90 %6d" % (NAMES[k], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    if "--launch" in sys.argv:                             # launch-level marks: where a K-step launch's fixed cost goes
+        marks = {20: "D kernel entry", 25: "L kernel entry", 26: "L first action batch in LDS", 21: "D prologue done (state, table, first actions)", 22: "D step 0 posted",
+                 27: "L first pool records posted", 28: "C step 0's rows flushed", 23: "D last step settled", 29: "C last step's rows flushed", 30: "C0 stores completed",
+                 24: "D write-back issued"}
+        t0 = np.minimum(t[:, 20], t[:, 25])                # (per tile: the shader clock is per XCD, tiles do not share a time base)
+        print("launch-level marks, cycles after the tile's own first kernel entry: median / p10 / p90 / max")
+        for k in marks:
+            d = t[:, k] - t0
+            print("   %-48s %7d %7d %7d %7d" % (marks[k], np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.max()))
+        span = np.maximum(np.maximum(t[:, 24], t[:, 30]), t[:, 29]) - t0
+        print("   span entry -> last mark per tile: median %d max %d cycles; D loop per step (mark 23 - mark 22) / (K - 1): %.0f cycles"
+              % (np.median(span), span.max(), np.median(t[:, 23] - t[:, 22]) / max(K - 1, 1)))
     env.close()
 
 
