@@ -167,3 +167,48 @@ def test_fused_actor_kernel_with_lookahead_equals_generation_inside_the_step(mod
     (o0, e0, s0, x0, r0, t0), (o1, e1, s1, x1, r1, t1) = out
     assert torch.equal(o0, o1) and torch.equal(e0, e1) and all(torch.equal(p, q) for p, q in zip(s0, s1))
     assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(t0, t1) and e0.max().item() >= 2
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_launch_sequences_keep_the_rings_covered(seed):
+    """the host's guaranteed-cover budget under fire: random sequences of one-step launches, K-step launches of random length, masked
+    resets and re-seedings on rings as short as the launches allow (R = 4 .. 32, K up to R - 1) -- a world that restarts at every
+    opportunity must always find its next scenario in its ring; bitwise against generation inside the step after every launch"""
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([2, 4, 5]))
+    R = int(rng.choice([4, 8, 16, 32]))
+    mode = int(rng.integers(0, 2))
+    W = int(rng.integers(50, 700))
+    over = dict(gen_mode=mode, gen_min_agents=int(rng.integers(1, N + 1)))
+    # short episodes: a tiny time budget and agents that start close make worlds restart every few steps
+    over.update(max_time_ratio=0.3 if rng.random() < 0.5 else 2.0)
+    a, b = _env(W, N, 100 + seed, 0, **over), _env(W, N, 100 + seed, R, **over)
+    assert torch.equal(a.reset(), b.reset())
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    slots_a, slots_b = a.new_step_slots(R), b.new_step_slots(R)
+    restarts_seen = 0
+    for it in range(60):
+        kind = rng.random()
+        if kind < 0.45:                                                      # a burst of one-step launches
+            for _ in range(int(rng.integers(1, 2 * R))):
+                acts = torch.randint(0, 11, (W, N), generator=g, device="cuda", dtype=torch.int32)
+                ra, rb = a.step_autoreset(acts), b.step_autoreset(acts)
+                assert all(torch.equal(x, y) for x, y in zip(ra, rb)), (it, "single")
+                restarts_seen += int(ra[3].sum().item())
+        elif kind < 0.85:                                                    # a K-step launch, K anywhere up to the ring's limit
+            K = int(rng.integers(2, R)) if R > 2 else 1
+            acts = torch.randint(0, 11, (K, W, N), generator=g, device="cuda", dtype=torch.int32)
+            a.step_autoreset_n(acts, K, slots=slots_a)
+            b.step_autoreset_n(acts, K, slots=slots_b)
+            for name in ("obs", "rewards", "done", "game_over"):
+                assert torch.equal(getattr(slots_a, name)[:K], getattr(slots_b, name)[:K]), (it, K, name)
+        elif kind < 0.95:                                                    # a masked reset
+            mask = (torch.rand(W, generator=g, device="cuda") < rng.random()).to(torch.uint8)
+            assert torch.equal(a.reset(mask), b.reset(mask)), (it, "reset")
+        else:                                                                # a new seed
+            s2 = int(rng.integers(0, 1 << 30))
+            a.seed(s2); b.seed(s2)
+            assert torch.equal(a.reset(), b.reset()), (it, "reseed")
+        assert _same_state(a, b), it
+    assert restarts_seen > 0
+    a.close(); b.close()
