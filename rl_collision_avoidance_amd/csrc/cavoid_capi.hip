@@ -194,11 +194,12 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
         e->ahead_R = cfg->gen_lookahead;
         e->pool_size = (int64_t)W * e->ahead_R;                                          // (> 0: the restart paths gather, as from a pool)
         const size_t recs = (size_t)e->pool_size * (size_t)cfg->max_agents * sizeof(PoolRec);
-        if (hipMalloc(&e->pool_slab, recs + W * sizeof(uint32_t)) != hipSuccess) rc = CAVOID_ENOMEM;
+        if (hipMalloc(&e->pool_slab, recs + 2 * W * sizeof(uint32_t)) != hipSuccess) rc = CAVOID_ENOMEM;
         else {
             e->pool = static_cast<PoolRec *>(e->pool_slab);
-            e->ahead_hi = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(e->pool_slab) + recs);
-            if (hipMemset(e->ahead_hi, 0xFF, W * sizeof(uint32_t)) != hipSuccess) rc = CAVOID_EHIP;
+            e->ahead_hi[0] = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(e->pool_slab) + recs);
+            e->ahead_hi[1] = e->ahead_hi[0] + W;
+            if (hipMemset(e->ahead_hi[0], 0xFF, 2 * W * sizeof(uint32_t)) != hipSuccess) rc = CAVOID_EHIP;
         }
     }
     if (rc != CAVOID_OK) { g_last_hip_error = (int)hipGetLastError(); cavoid_destroy(e); return rc; }
@@ -250,7 +251,6 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     k.timeout_enabled = cfg->timeout_enabled; k.num_actions = cfg->num_actions;
     k.pool_size = cfg->gen_lookahead > 0 ? (int32_t)(e->pool_size > 0x7fffffffLL ? 0x7fffffffLL : e->pool_size) : cfg->gen_pool_size;   // (look-ahead: only its sign is used)
     k.ahead = cfg->gen_lookahead;
-    k.ahead_hi = e->ahead_hi;
     k.evaluate_mode = cfg->evaluate_mode ? 1 : 0;
     k.stream_obs = (double)num_worlds * cfg->max_agents * (6 + 7 * cfg->max_other) * sizeof(float) > 16.0 * 1048576.0 ? 1 : 0;   // (measured: 10 x 262144 one step 213 -> 193 us, 4 x 65536 25.2 -> 24.5 us)
     if (const char *ov = std::getenv("CAVOID_STREAM_OBS")) k.stream_obs = std::atoi(ov) != 0;
@@ -360,8 +360,15 @@ int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
     if (capturing) e->ahead_always = true;
     if (!e->ahead_always && e->ahead_primed && e->ahead_budget >= n_steps + 1) return CAVOID_OK;
     const int64_t waves = (e->W + e->k.wpw - 1) / e->k.wpw;
-    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-#define CAVOID_AHEAD_CASE(NN) case NN: hipLaunchKernelGGL((ahead_fill_kernel<NN>), grid, block, 0, s, e->k, e->st.episode, e->ahead_hi, e->pool, e->ahead_R); break;
+    // The missing episodes of a world are dealt over grid.y wavefronts (4 in the steady state -- a world rarely consumed more since the last
+    // refill --, 32 for the first fill of R episodes per world): they all read the bookkeeping array `cur` and the y = 0 one writes the other,
+    // which becomes `cur`.  Once a hipGraph holds a refill (its kernel arguments are frozen) every refill works IN PLACE on one array with
+    // grid.y = 1, so that the graph's replays and the eager launches between them see the same bookkeeping.
+    const bool in_place = e->ahead_always;
+    const dim3 grid((unsigned)((waves + 3) / 4), in_place ? 1u : (e->ahead_primed ? 4u : 32u)), block(256);
+    const uint32_t *hi_in = e->ahead_hi[e->ahead_cur];
+    uint32_t *hi_out = e->ahead_hi[in_place ? e->ahead_cur : (e->ahead_cur ^ 1)];
+#define CAVOID_AHEAD_CASE(NN) case NN: hipLaunchKernelGGL((ahead_fill_kernel<NN>), grid, block, 0, s, e->k, e->st.episode, hi_in, hi_out, e->pool, e->ahead_R); break;
     switch (e->cfg.max_agents) {
 #ifdef CAVOID_DEV_ONLY_N
         CAVOID_AHEAD_CASE(4) CAVOID_AHEAD_CASE(10)
@@ -374,6 +381,7 @@ int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
     }
 #undef CAVOID_AHEAD_CASE
     HIP_TRY(hipGetLastError());
+    if (!in_place) e->ahead_cur ^= 1;
     if (!capturing) { e->ahead_primed = true; e->ahead_budget = e->ahead_R; }
     return CAVOID_OK;
 }
@@ -389,7 +397,7 @@ static int fill_pool(cavoid_env *e, hipStream_t s) {
     if (e->ahead_R > 0) {                                      // look-ahead rings: nothing of the old seed / episodes stays valid
         e->ahead_budget = 0;
         e->ahead_primed = false;
-        HIP_TRY(hipMemsetAsync(e->ahead_hi, 0xFF, (size_t)e->W * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(e->ahead_hi[0], 0xFF, 2 * (size_t)e->W * sizeof(uint32_t), s));
         return CAVOID_OK;
     }
     if (e->pool_size <= 0) return CAVOID_OK;

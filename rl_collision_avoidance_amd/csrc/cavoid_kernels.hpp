@@ -81,7 +81,6 @@ struct KCfg {
     uint32_t pool_epoch;         // the pool holds generator worlds 0..P-1 of this episode index
     int32_t pool_size;           // 0: restarts run the generator in-kernel; >0: gather from the pool
     int32_t ahead;               // R > 0: the "pool" is the look-ahead ring (slot ep % R of this world: exact fresh scenarios), not the hashed pool
-    uint32_t *ahead_hi;          // [W] highest episode in each world's ring (look-ahead only; kernels that refill their own rings keep it current)
     int32_t prefetch_pool;       // latency mode (small batches): every lane pre-loads its next pool entry
     int32_t tile_rows;           // rows of the LDS obs tile (one pass = tile_rows agents' rows)
     int32_t wpw;                 // worlds per wavefront, 1..floor(64/N): small batches spread over more, emptier wavefronts
@@ -991,10 +990,12 @@ __device__ __forceinline__ void new_episode(const KCfg &c, const PoolRec *pool, 
 // generator of (seed, GLOBAL world id, episode): GEN v1 per lane, GEN v2 wave-cooperatively, exactly what the in-kernel restart of
 // gen_pool_size = 0 computes (tests/test_gpu_lookahead.py holds the two bitwise equal).
 // one wavefront's share of the refill: `wave` = index of the 64-lane tile of (world, agent) slots, scratch = 4 x 64 doubles + 64 floats of
-// wave-private LDS (GEN v2 only).  A device function so that kernels can carry refill work beside their own (env_relay_kernel's extra blocks).
+// wave-private LDS (GEN v2 only).  The missing episodes of a world are dealt over `ny` wavefronts (this one takes the y-th, y + ny-th, ...), so
+// that a world which consumed several episodes since the last refill does not serialise their generation: hi_in is read by all of them, the
+// y = 0 wavefront writes the new bookkeeping to hi_out (the host swaps the two arrays after every refill).
 template <int N>
-__device__ __forceinline__ void ahead_fill_wave(const KCfg &c, const uint32_t *episode, uint32_t *filled_hi, PoolRec *ahead, const int need,
-                                                const int64_t wave, const int lane, double *sc_d, float *sc_r) {
+__device__ __forceinline__ void ahead_fill_wave(const KCfg &c, const uint32_t *episode, const uint32_t *hi_in, uint32_t *hi_out, PoolRec *ahead, const int need,
+                                                const int64_t wave, const int lane, const int y, const int ny, double *sc_d, float *sc_r) {
     const int wpw = c.wpw, lanes_used = wpw * N;
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = wave * wpw + lw;
@@ -1003,7 +1004,7 @@ __device__ __forceinline__ void ahead_fill_wave(const KCfg &c, const uint32_t *e
     uint32_t ep = 0u, fh = 0u;
     if (active) {
         ep = episode[w];
-        fh = filled_hi[w];
+        fh = hi_in[w];
         if (fh == 0xFFFFFFFFu || (int32_t)(fh - ep) < 0) fh = ep;      // nothing valid ahead of this world's current episode
     }
     const uint32_t target = ep + (uint32_t)need;
@@ -1013,7 +1014,7 @@ __device__ __forceinline__ void ahead_fill_wave(const KCfg &c, const uint32_t *e
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(trips, o, 64); trips = v > trips ? v : trips; }
     const uint32_t gw = (uint32_t)(c.world_offset + w);
-    for (int k = 0; k < trips; ++k) {                           // (wave-uniform)
+    for (int k = y; k < trips; k += ny) {                       // (wave-uniform)
         const uint32_t e = fh + 1u + (uint32_t)k;
         const bool fresh = active && k < missing;
         Agent a;
@@ -1028,15 +1029,16 @@ __device__ __forceinline__ void ahead_fill_wave(const KCfg &c, const uint32_t *e
             ahead[((int64_t)w * c.ahead + (int64_t)(e & (uint32_t)(c.ahead - 1))) * N + i] = r;
         }
     }
-    if (active && i == 0 && missing > 0) filled_hi[w] = target;
+    if (active && i == 0 && y == 0) hi_out[w] = missing > 0 ? target : fh;
 }
 
 template <int N>
-__global__ void __launch_bounds__(256) ahead_fill_kernel(const KCfg c, const uint32_t *episode, uint32_t *filled_hi, PoolRec *ahead, const int need) {
+__global__ void __launch_bounds__(256) ahead_fill_kernel(const KCfg c, const uint32_t *episode, const uint32_t *hi_in, uint32_t *hi_out, PoolRec *ahead, const int need) {
     __shared__ double sh_d[4][4 * 64];
     __shared__ float sh_r[4][64];
     const int wave_in_block = threadIdx.x >> 6;
-    ahead_fill_wave<N>(c, episode, filled_hi, ahead, need, (int64_t)blockIdx.x * 4 + wave_in_block, threadIdx.x & 63, sh_d[wave_in_block], sh_r[wave_in_block]);
+    ahead_fill_wave<N>(c, episode, hi_in, hi_out, ahead, need, (int64_t)blockIdx.x * 4 + wave_in_block, threadIdx.x & 63, (int)blockIdx.y, (int)gridDim.y,
+                       sh_d[wave_in_block], sh_r[wave_in_block]);
 }
 
 // ---- RVO scripted policy: ORCA, van den Berg et al., "Reciprocal n-body collision avoidance"

@@ -19,7 +19,8 @@ struct cavoid_env {
     uint32_t *pool_episode = nullptr;   // [P] scratch episode counters for the fill launch
     int64_t pool_size = 0;
     int ahead_R = 0;                    // scenario look-ahead (cfg.gen_lookahead): `pool` is then every world's ring of R records, filled by ahead_fill_kernel
-    uint32_t *ahead_hi = nullptr;       // [W] highest episode in each world's ring (0xFFFFFFFF: none)
+    uint32_t *ahead_hi[2] = {nullptr, nullptr};   // [W] highest episode in each world's ring (0xFFFFFFFF: none): a refill reads [ahead_cur], writes the other
+    int ahead_cur = 0;
     int ahead_budget = 0;               // restarts per world the ring is still guaranteed to cover without a refill
     bool ahead_primed = false;          // the rings have been filled once for the current seed / episodes
     bool ahead_always = false;          // a hipGraph holding stepping launches of this env exists: replays consume episodes the host does not see,
