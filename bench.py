@@ -7,7 +7,9 @@
 A "step" = one pass of the hot path (decode, dynamics, pairwise sensing, rewards, done flags, sorted
 observation, in-kernel restart of finished worlds) over one batch of synthetic worlds: BASELINE
 configs[1], 4 agents x 8192 worlds per GPU, unicycle dynamics, random actions pre-generated on the
-device.  The K timed steps go through `cavoid_step_autoreset_n`: launches of up to --slices steps, the
+device; a finished world restarts with a FRESH generator scenario (the reference's reset semantics) from its look-ahead
+ring, the refill kernel inside the timed region (`--scenarios pool | instep`: the other sources, all under
+extra.scenario_sources).  The K timed steps go through `cavoid_step_autoreset_n`: launches of up to --slices steps, the
 world state staying in registers between the steps of a launch; EVERY step reads its action slice and
 writes its observations, rewards, done flags and game_over INTO ITS OWN OUTPUT SLOT ([K, W, N, .] tensors:
 every step's outputs are there to be read afterwards -- what a rollout consumes, ProcessAgent.py:149-157).
@@ -325,6 +327,10 @@ def pmc_child(args) -> None:
             self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
             EnvConfig.__init__(self)
     over = {"gen_min_agents": args.min_agents} if args.min_agents else {}
+    if args.scenarios == "lookahead" and not args.min_agents:          # (the headline's scenario source; the configs[3] extra keeps the pool)
+        over.update(gen_pool_size=0, gen_lookahead=128 if args.slices + 2 <= 128 else 256)
+    elif args.scenarios == "instep" and not args.min_agents:
+        over.update(gen_pool_size=0)
     env = BatchedCollisionAvoidanceEnv(W, Cfg(), device="cuda:0", seed=7, **over)
     g = torch.Generator(device="cuda").manual_seed(1234)
     acts = torch.randint(0, env.num_actions, (args.slices, W, N), generator=g, device="cuda", dtype=torch.int32)
@@ -342,7 +348,7 @@ def pmc_child(args) -> None:
     env.close()
 
 
-def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 150.0, min_agents: int = 0):
+def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 150.0, min_agents: int = 0, scenarios: str = "pool"):
     """HBM bytes per launch of the step kernel from the PMC counters, collected live: one `rocprofv3 --pmc` pass per
     counter (FETCH_SIZE and WRITE_SIZE do not fit one pass; only --kernel-trace beside --pmc) around a child that
     repeats this bench's launch pattern.  Counters are KiB; gfx950 tallies 128-B read requests as 64 B, so FETCH_SIZE
@@ -361,7 +367,7 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
         d = tempfile.mkdtemp(prefix="cavoid_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.abspath(__file__), "--pmc-child", "--agents", str(N), "--worlds", str(W), "--slices", str(slices),
-               "--steps", str(steps), "--warmup", str(slices), "--min-agents", str(min_agents)]
+               "--steps", str(steps), "--warmup", str(slices), "--min-agents", str(min_agents), "--scenarios", scenarios]
         try:
             subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -420,8 +426,13 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the brief configs[4] extra of the default N = 1 run")
     ap.add_argument("--no-configs3", action="store_true", help="skip the brief configs[3] (10 agents x 8192 worlds) extra")
+    ap.add_argument("--scenarios", default="lookahead", choices=["lookahead", "pool", "instep"],
+                    help="where a restarting world's scenario comes from in the HEADLINE: lookahead (default) = a fresh generator scenario per episode -- "
+                         "the reference's reset semantics -- from per-world look-ahead rings refilled between launches (cavoid_cfg::gen_lookahead; bitwise the "
+                         "in-step generator); pool = a hashed pool of 65536 scenarios pre-generated outside the timed region (rounds 1-4's headline); "
+                         "instep = the generator inside the step kernel")
     ap.add_argument("--no-fresh-scenarios", action="store_true",
-                    help="skip the brief extra that times the same step with a fresh scenario generated in-kernel at every restart (no pool)")
+                    help="skip the brief extra that times the same step under the other scenario sources (and with the box generator GEN v2)")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live with rocprofv3 --pmc")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 code path)")
@@ -480,6 +491,20 @@ def main() -> None:
             dist.init_process_group("gloo")
 
     N, W = args.agents, args.worlds
+
+    def scen_over(mode, gen_mode=0):
+        """cavoid_cfg overrides of a scenario source (see --scenarios); the look-ahead ring must hold one launch (+1)"""
+        ring = 128
+        while ring < args.slices + 2:
+            ring *= 2
+        over = {"lookahead": {"gen_pool_size": 0, "gen_lookahead": ring}, "pool": {}, "instep": {"gen_pool_size": 0}}[mode]
+        return dict(over, gen_mode=gen_mode) if gen_mode else dict(over)
+    SCEN = scen_over(args.scenarios)
+    SCEN_TEXT = {"lookahead": "a finished world restarts with a FRESH generator scenario (the reference's reset semantics: a new random test case per reset) taken from its "
+                              "look-ahead ring -- exact (seed, global world, episode) streams, bitwise the in-step generator, the refill launches inside the timed "
+                              "region",
+                 "pool": "a finished world RESTARTS BY GATHERING one of 65536 scenarios pre-generated outside the timed region",
+                 "instep": "a finished world restarts with a FRESH scenario generated inside the step kernel"}[args.scenarios]
 
     def cfg_for(n_agents):
         class Cfg(EnvConfig):
@@ -550,7 +575,7 @@ def main() -> None:
         """PMC traffic of both forms, live (rocprofv3 --pmc passes around a child that repeats the launch pattern)"""
         for form, slices in ((fig, fig["steps_per_launch"]), (fig["one_step_launch"], 1)):
             try:
-                pmc = measure_traffic(n_agents, Wl, slices, max(slices * 4, 128), min_agents=min_agents)
+                pmc = measure_traffic(n_agents, Wl, slices, max(slices * 4, 128), min_agents=min_agents, scenarios=args.scenarios)
             except Exception:      # noqa: BLE001 -- measurement aid only
                 pmc = None
             if pmc is not None:
@@ -560,7 +585,7 @@ def main() -> None:
                 form["traffic_source"] = pmc
             form["bound"] = bound_of(form, Wl, n_agents)
 
-    env, acts = make(W)
+    env, acts = make(W, **SCEN)
     gather_mode = "none" if args.no_gather else args.gather
     exchange_possible = world_size > 1 or args.force_rccl      # (N = 1: only as a development run through a forced RCCL communicator)
     gather_in_metric = exchange_possible and gather_mode != "none"
@@ -595,7 +620,7 @@ def main() -> None:
             # same blocks through torch.distributed (ShardedEnv picks the transport from the process group's backend).
             from rl_collision_avoidance_amd.sharding import ShardedEnv
             env.close()
-            sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7, force_rccl=True if args.force_rccl else None)
+            sh = ShardedEnv(world_size * W, cfg_for(N), device=device, seed=7, force_rccl=True if args.force_rccl else None, **SCEN)
             sh.reset()
             env = sh.env
             run_steps(env, acts, preroll, None)
@@ -632,7 +657,7 @@ def main() -> None:
                 except Exception:      # noqa: BLE001
                     pass
                 sh = None
-            env, acts = make(W)
+            env, acts = make(W, **SCEN)
             slots = None if args.overwrite_outputs else env.new_step_slots(min(args.slices, max(args.steps, 1)))
             run_steps(env, acts, preroll, slots)
             run_steps(env, acts, args.warmup, slots)
@@ -678,7 +703,7 @@ def main() -> None:
     elapsed = times[mid]                                     # the MEDIAN repetition (an odd count: a repetition that really ran)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world_size * W * N * args.steps / elapsed
-    timing = {"timed_reps": len(times), "ms_per_step_median": ms_per_step, "ms_per_step_min": min(times) * 1e3 / args.steps,
+    timing = {"timed_reps": len(times), "ms_per_step_median": ms_per_step, "ms_per_step_mean": sum(times) / len(times) * 1e3 / args.steps, "ms_per_step_min": min(times) * 1e3 / args.steps,
               "ms_per_step_max": max(times) * 1e3 / args.steps, "ms_per_step_first_rep": times[0] * 1e3 / args.steps,
               "restarts_in_timed_region": restarts[mid], "restarts_per_rep_min_max": [min(restarts), max(restarts)],
               "preroll_steps": preroll,
@@ -846,11 +871,11 @@ def main() -> None:
         # reset, ProcessAgent.py:107): the same K-step timed region with NO scenario pool -- every restart generates its scenario inside the
         # step kernel, exact (seed, global world id, episode) streams -- for GEN v1 (rings) and GEN v2 (boxes, rejection sampling)
         fresh = {}
-        # ... and with the scenario LOOK-AHEAD (cavoid_cfg::gen_lookahead): the same fresh, exact scenarios (bitwise: tests/test_gpu_lookahead.py),
-        # generated by a small refill kernel in front of every K-step launch instead of inside the step -- the refill is inside these times
-        for label, over in (("gen_v1_ring", {"gen_pool_size": 0}), ("gen_v2_box", {"gen_pool_size": 0, "gen_mode": 1}),
-                            ("gen_v1_ring_lookahead", {"gen_pool_size": 0, "gen_lookahead": 128}),
-                            ("gen_v2_box_lookahead", {"gen_pool_size": 0, "gen_mode": 1, "gen_lookahead": 128})):
+        # the same K-step timed region under the scenario sources the headline does NOT use (GEN v1 rings), and under GEN v2 (boxes, rejection
+        # sampling) with the look-ahead and in the step kernel.  lookahead / instep are the same scenarios bit for bit (tests/test_gpu_lookahead.py).
+        cases = [("gen_v1_ring_" + m, scen_over(m)) for m in ("lookahead", "pool", "instep") if m != args.scenarios]
+        cases += [("gen_v2_box_" + m, scen_over(m, gen_mode=1)) for m in ("lookahead", "instep")]
+        for label, over in cases:
             try:
                 e0, a0 = make(W, N, **over)
                 s0 = None if args.overwrite_outputs else e0.new_step_slots(min(args.slices, max(args.steps, 1)))
@@ -868,17 +893,18 @@ def main() -> None:
                 f0 = kernel_figures(e0, a0, N, W, args.steps, s0)
                 fresh[label] = {"value": W * N * args.steps / ts[mid0], "unit": "agent-steps/s", "ms_per_step": ts[mid0] * 1e3 / args.steps,
                                 "restarts_in_timed_region": rs[mid0], "timed_reps": 5, "roofline": f0,
-                                "vs_pool_headline_kernel_us_per_step": [f0["kernel_us_per_step"], roofline["kernel_us_per_step"]]}
+                                "vs_headline_kernel_us_per_step": [f0["kernel_us_per_step"], roofline["kernel_us_per_step"]]}
                 del s0
                 e0.close()
                 del e0, a0
             except Exception as exc:      # noqa: BLE001
                 fresh[label] = {"error": repr(exc)}
-        fresh["note"] = ("gen_pool_size = 0: the scenario of every restarting world is a fresh generator scenario (the reference makes a new random test "
-                         "case per reset) -- generated in the step kernel (gen_v1_ring, gen_v2_box), or by the look-ahead refill in front of each launch "
-                         "(*_lookahead: same scenarios bit for bit, restart = a gather; `value` includes the refill kernel, `roofline` is the step kernel "
-                         "alone); same K, same per-step output slots as the headline, this rank's GPU only")
-        extra["no_scenario_pool"] = fresh
+        fresh["headline_source"] = args.scenarios
+        fresh["note"] = ("scenario source of a restarting world -- lookahead: a fresh generator scenario per episode (the reference makes a new random test case "
+                         "per reset) from per-world rings a small refill kernel tops up between launches (`value` includes the refill, `roofline` is the step "
+                         "kernel alone); instep: the same scenarios, bit for bit, generated inside the step kernel; pool: gathered from 65536 scenarios "
+                         "pre-generated outside the timed region.  Same K, same per-step output slots as the headline, this rank's GPU only")
+        extra["scenario_sources"] = fresh
 
     if args.full_loop or not args.no_full_loop:
         # configs[4] beside the headline (a brief version: actors only + the fused-trainer loop, ~15 s; the PyTorch comparison
@@ -916,16 +942,16 @@ def main() -> None:
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE %s: %d agents x %d worlds per GPU, unicycle dynamics, GEN v1 synthetic scenarios, "
-                               "uniform random actions pre-staged on the device, in-kernel auto-reset -- a finished world RESTARTS BY GATHERING "
-                               "one of 65536 scenarios pre-generated outside the timed region (the same step with a FRESH scenario at every restart -- "
-                               "generated in-kernel, or by the exact look-ahead refill -- GEN v1 and GEN v2: extra.no_scenario_pool); launches of up to %d steps "
+                               "uniform random actions pre-staged on the device, in-kernel auto-reset -- %s (the other scenario sources, "
+                               "GEN v1 and GEN v2: extra.scenario_sources); launches of up to %d steps "
                                "(world state in registers between the steps of a launch); %s%s"
-                               % (which, N, W, args.slices,
+                               % (which, N, W, SCEN_TEXT, args.slices,
                                   "every step overwrites one output slot" if args.overwrite_outputs else
                                   "every step's obs / reward / done / game_over written into its own output slot [K,W,N,.]",
                                   ("; + the gather of the packed records to %s inside the timed region (configs[2])"
                                    % ("every rank" if gather_root < 0 else "rank 0, the trainer rank")) if gather_in_metric else ""),
                    "worlds_per_gpu": W, "agents_per_world": N, "obs_width": env.obs_width, "steps_per_launch": min(args.slices, args.steps),
+                   "scenarios": args.scenarios,
                    "parallelism": ("worlds sharded over %d GPU(s), one gather of (obs|reward|done) per launch to %s (RCCL over xGMI)"
                                    % (world_size, "every rank" if gather_root < 0 else "rank 0"))
                                   if gather_in_metric else ("worlds sharded over %d GPU(s), no data-path collective" % world_size)},

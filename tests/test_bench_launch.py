@@ -69,10 +69,15 @@ def test_bench_two_rank_dry_run_on_one_device():
         assert f["agent_steps_per_s"] > 0 and f["bytes_per_link_per_step"] == (0 if mode == "none" else rec)
         assert (f["xgmi_frac"] is None) if mode == "none" else (abs(f["link_bound_us_per_step"] - rec / 153e3) < 1e-9 and f["xgmi_frac"] > 0)
     assert g["forms"]["all"]["agent_steps_per_s"] == line["value"]
-    # the reference's reset semantics beside the pooled headline: a fresh scenario generated in-kernel at every restart
-    for label in ("gen_v1_ring", "gen_v2_box", "gen_v1_ring_lookahead", "gen_v2_box_lookahead"):
-        f = line["extra"]["no_scenario_pool"][label]
+    # the headline restarts worlds with FRESH generator scenarios (the reference's reset semantics) from the look-ahead rings; the
+    # pooled and the in-step sources, and GEN v2, are measured beside it
+    assert line["config"]["scenarios"] == "lookahead" and "FRESH generator scenario" in line["config"]["workload"]
+    src = line["extra"]["scenario_sources"]
+    assert src["headline_source"] == "lookahead"
+    for label in ("gen_v1_ring_pool", "gen_v1_ring_instep", "gen_v2_box_lookahead", "gen_v2_box_instep"):
+        f = src[label]
         assert "error" not in f and f["value"] > 0 and f["restarts_in_timed_region"] > 0, f
+    assert line["timing"]["restarts_in_timed_region"] > 0 and line["timing"]["ms_per_step_mean"] > 0
 
 
 @pytest.mark.gpu
@@ -129,3 +134,13 @@ def test_the_json_line_is_the_last_line_of_stdout_even_with_rccl_banners():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert lines and lines[-1].startswith("{") and json.loads(lines[-1])["n_gpus"] == 1, lines[-3:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,says", [("pool", "pre-generated outside the timed region"), ("instep", "generated inside the step kernel")])
+def test_bench_other_scenario_sources_as_the_headline(mode, says):
+    """`--scenarios pool | instep`: the hashed pool (rounds 1-4's headline) and the in-step generator stay selectable; the line says which"""
+    line = _run(["--gpus", "1", "--scenarios", mode, "--steps", "40", "--warmup", "8", "--worlds", "2048", "--reps", "3", "--no-cpu-baseline",
+                 "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"], 900)
+    assert line["config"]["scenarios"] == mode and says in line["config"]["workload"]
+    assert line["value"] > 0 and line["timing"]["restarts_in_timed_region"] > 0
