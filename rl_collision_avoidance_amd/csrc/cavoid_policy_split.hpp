@@ -76,6 +76,7 @@ constexpr int kSpZeroCol = 256;                 // columns 256..263 of every row
 constexpr int kSpMaxOthers = 23;                // slots 0..M must fit columns 64..255
 // chunk counts (K = 32 each)
 constexpr int kSpChLstm = 3, kSpChL1 = 3, kSpChWide = 8;
+constexpr int kSpSlotChunk = 2;                 // the LSTM's / layer1's last chunk: the 8-wide input slot (chunks 0, 1: the hidden state)
 constexpr int64_t kSpFragPerChunk = 3 * 16 * 64;          // planes x column tiles x lanes
 constexpr int64_t kSpOffLstm = 0;
 constexpr int64_t kSpOffL1 = kSpOffLstm + kSpChLstm * kSpFragPerChunk;
@@ -191,6 +192,16 @@ __global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeig
             split3(split_weight(w, layer, c, g, e, col), a1, a2, a3);
             split3(split_weight(w, layer, c, g, e + 1, col), b1, b2, b3);
         }
+        if (f16 && layer <= 1 && c == kSpSlotChunk) {
+            // the input-slot chunk's MIXED plane (see split_gemm3): k-groups 0 and 1 hold the slot's first weight pieces, k-group 2 the
+            // second pieces, k-group 3 zeros -- against activation fragments (a1 | a2 | a1 | 0) ONE matrix instruction forms
+            // w1 a1 + w1 a2 + w2 a1 of the slot's <= 8 inputs.  (The float16 form has no third piece: plane 2 is free.)
+            uint32_t m1, m2, m3, n1, n2, n3;
+            split3_f16(split_weight(w, layer, c, 0, e, col), m1, m2, m3);
+            split3_f16(split_weight(w, layer, c, 0, e + 1, col), n1, n2, n3);
+            a3 = g < 2 ? m1 : (g == 2 ? m2 : 0u);
+            b3 = g < 2 ? n1 : (g == 2 ? n2 : 0u);
+        }
         pl[0][e >> 1] = a1 | (b1 << 16); pl[1][e >> 1] = a2 | (b2 << 16); pl[2][e >> 1] = a3 | (b3 << 16);
     }
     const int64_t plane_stride = layer == 4 ? 64 : 16 * 64;
@@ -242,6 +253,15 @@ __device__ __forceinline__ void split_load_a(uint4 (&a)[4], const unsigned char 
     for (int nt = 0; nt < 4; ++nt) a[nt] = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
 }
 
+// the MIXED activation fragments of the 8-wide input slot at LDS column `col`: k-group 0 = first pieces, 1 = second pieces, 2 = first
+// pieces again, 3 = zeros -- the partner of the packed weights' mixed plane (policy_pack_split_kernel)
+__device__ __forceinline__ void split_load_a_mix(uint4 (&a)[4], const unsigned char *planes, int lane, int col) {
+    const int g = lane >> 4;
+    const unsigned char *p = planes + (g == 1 ? kSpPlaneB : 0) + (lane & 15) * kSpStrideB + (g == 3 ? kSpZeroCol : col) * 2;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) a[nt] = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
+}
+
 // one partial product for all 16 (column tile, row tile) pairs: consecutive MFMAs never share an accumulator
 template <bool F16 = false>
 __device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4 (&a)[4], f32x4 (&acc)[4][4]) {
@@ -279,8 +299,27 @@ template <bool F16>
 __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const SplitSrc &src, int layer, int c0, int c1, int slot_chunk, int slot_col,
                                             int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], int next_layer, int next_c,
                                             f32x4 (&b4)[4], int next_bias) {
+    // Round 5, float16 form: the input-slot chunk (<= 8 inputs in a K = 32 instruction; always the LAST chunk, c1 - 1) is ONE product
+    // instead of three -- its three partial products laid side by side along K (mixed fragments: split_load_a_mix and the packed
+    // weights' plane 2): 16 matrix instructions per slot chunk instead of 48, the same three partial sums in the same float32
+    // accumulator.  A call that STARTS at the slot chunk (the first LSTM step) expects the mixed plane in w.w[0].
+    const bool slot_last = F16 && slot_chunk >= 0;
+    const int cm = slot_last ? c1 - 1 : c1;                // plain chunks: c0 .. cm - 1
     uint4 a_hi[4], a_lo[4];
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
+    if (c0 >= cm) {                                        // (uniform) only the slot chunk: acc = bias + mixed product
+        split_load_a_mix(a_lo, planes, lane, slot_col);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w.w[0][mt], a_lo[nt], b4[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+        split_load_bias(b4, src, next_bias, wave, lane);
+        split_load_w1(w.w[1], src, next_layer, 1, wave, lane, next_c);
+        split_load_w1(w.w[0], src, next_layer, 0, wave, lane, next_c);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
     split_load_a(a_hi, planes, 0, lane, col_of(c0), c0 == slot_chunk);
     int c = c0;
@@ -288,12 +327,14 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const S
 #pragma unroll 1
     for (;;) {
         {                                                  // chunk c with w1 in w.w[0]; w.w[2] is idle
-            const bool last = c + 1 >= c1;
+            const bool last = c + 1 >= cm;
+            const bool to_slot = last && slot_last;        // the mixed product follows this chunk
             const int n = last ? c : c + 1;
             const int wl = last ? next_layer : layer;
             const int wc = last ? next_c : n;
             __builtin_amdgcn_sched_barrier(0);
             if (!last) split_load_w1(w.w[2], src, layer, 0, wave, lane, n);
+            else if (to_slot) split_load_w1(w.w[2], src, layer, 2, wave, lane, cm);
             if (first) {                                   // (uniform) acc = bias + w1 * a_lo
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -305,34 +346,49 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const S
             }
             if (last) split_load_bias(b4, src, next_bias, wave, lane);   // (b4 was consumed by the first product: free since then)
             __builtin_amdgcn_sched_barrier(0);
-            split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
+            if (to_slot) split_load_a_mix(a_lo, planes, lane, slot_col);
+            else split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
             split_mfma_term<F16>(w.w[1], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[1], src, wl, 1, wave, lane, wc);
             split_mfma_term<F16>(w.w[0], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
-            split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
-            if (last) { split_load_w1(w.w[0], src, next_layer, 0, wave, lane, next_c); break; }
+            if (!to_slot) split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
+            if (last) {
+                split_load_w1(w.w[0], src, next_layer, 0, wave, lane, next_c);
+                if (to_slot) split_mfma_term<F16>(w.w[2], a_lo, acc);
+                break;
+            }
         }
         ++c;
         {                                                  // chunk c with w1 in w.w[2]; w.w[0] is idle
-            const bool last = c + 1 >= c1;
+            const bool last = c + 1 >= cm;
+            const bool to_slot = last && slot_last;
             const int n = last ? c : c + 1;
             const int wl = last ? next_layer : layer;
             const int wc = last ? next_c : n;
             __builtin_amdgcn_sched_barrier(0);
-            split_load_w1(w.w[0], src, wl, 0, wave, lane, wc);
+            if (to_slot) split_load_w1(w.w[0], src, layer, 2, wave, lane, cm);      // the slot chunk's mixed plane: 48 matrix instructions ahead
+            else split_load_w1(w.w[0], src, wl, 0, wave, lane, wc);
             split_mfma_term<F16>(w.w[2], a_lo, acc);
             if (last) split_load_bias(b4, src, next_bias, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
-            split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
+            if (to_slot) split_load_a_mix(a_lo, planes, lane, slot_col);            // ... and its mixed activations: 32 ahead
+            else split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
             split_mfma_term<F16>(w.w[1], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[1], src, wl, 1, wave, lane, wc);
             split_mfma_term<F16>(w.w[2], a_hi, acc);
             __builtin_amdgcn_sched_barrier(0);
-            split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
-            if (last) break;
+            if (!to_slot) split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
+            if (last) {
+                if (to_slot) {
+                    split_mfma_term<F16>(w.w[0], a_lo, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_load_w1(w.w[0], src, next_layer, 0, wave, lane, next_c);
+                }
+                break;
+            }
         }
         ++c;
     }
@@ -499,7 +555,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     constexpr int w_lstm = (int)kSpOffLstm;
     SplitW f0;
     f32x4 b4[4];                                           // the bias of the GEMM that comes next (P = 3: its first product's C operand)
-    split_load_w<P>(f0, src, w_lstm, wave, lane, 2);          // first LSTM step: h == 0, only the input chunk contributes
+    // first LSTM step: h == 0, only the input chunk contributes (float16 form: its mixed plane, one product)
+    if constexpr (F16) split_load_w1(f0.w[0], src, w_lstm, 2, wave, lane, kSpSlotChunk);
+    else split_load_w<P>(f0, src, w_lstm, wave, lane, kSpSlotChunk);
     split_load_bias(b4, src, kBiasLstm, wave, lane);
 
     // ---- input tile: gather + normalise + split into the slot columns ---------------------------------------------
