@@ -630,10 +630,12 @@ def main() -> None:
             else:
                 slots = None if args.overwrite_outputs else env.new_step_slots(min(args.slices, max(args.steps, 1)))
                 run_steps(env, acts, args.warmup, slots)
-            sync_all()
+            torch.cuda.synchronize(device)                    # (a device fault of the warm-up surfaces here, on this rank)
             failed = None
         except Exception as exc:      # noqa: BLE001 -- a broken exchange must not cost the shard-only number: say so and time that
             failed = repr(exc)
+        # (no barrier inside the try: a rank that failed goes straight to the status exchange below, so the FIRST collective after the
+        #  set-up is the same one on every rank whatever happened)
         # what every rank's communicator set-up (ncclCommInitRank behind cavoid_comm_create, or the gloo stand-in) came to
         comm_status = [None] * world_size
         if world_size > 1:

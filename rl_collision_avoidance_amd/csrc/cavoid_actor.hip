@@ -120,3 +120,11 @@ extern "C" int cavoid_step_push(cavoid_env *e, cavoid_rollout *r, const cavoid_r
     }
     return CAVOID_OK;
 }
+
+#ifdef CAVOID_TRACE
+// development build only: the phase stamps of actor_kernel<N, false, false> (this translation unit's copy of g_pol_trace; tools/trace_actor.py)
+extern "C" int cavoid_actor_debug_trace(unsigned long long *dev_ptr) {
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(cavoid::g_pol_trace), &dev_ptr, sizeof(dev_ptr)));
+    return CAVOID_OK;
+}
+#endif

@@ -79,6 +79,7 @@ __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState 
     };
     if (EARLY) first_trip();
     env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
+    POLICY_STAMP(0);                                       // (trace build) env.step of the tile done, its stores issued
     if (!EARLY) first_trip();
     const bool learning = in_range && learn_f > 0.5f;
     const int base = lane < wpw * N ? lw * N : 0;
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
         float *obs_n = io.obs[(t + 1) & 1];
         const int32_t step = step0 + t;
         const int blk = step % rc.ring_len;
+        POLICY_STAMP(13);                                    // (trace build, tools/trace_actor.py) the step begins
 
         // ---- predict_p_and_v + select_action for the tile's rows, read in place from the observation the env wrote -----------
         {
@@ -179,15 +181,23 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
             }
         }
         __syncthreads();                                     // the tile's actions / values are in memory; the planes are idle
+        POLICY_STAMP(14);                                    // policy pass + barrier done
 
         if (wave_in_block == 0) {
             // ---- env.step of the tile, then the Experience bookkeeping of its slots ---------------------------------------
             actor_env_push_tile<N, RVO, (N <= (RVO ? 9 : 13))>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, lds_tab, wbase, lane, tile, step, blk);
+            POLICY_STAMP(15);                                // env step + bookkeeping of the tile done (stores issued)
         } else {
             // ---- meanwhile: the step's state rows -> the time-major experience store -----------------------------------------
             rollout_copy_rows(rc, obs_t, rio_arg.x, a0, rows, blk, tid - 64, 192);
         }
         __syncthreads();                                     // obs(t+1), the world state and the slot state are in memory
+        POLICY_STAMP(6);                                     // the step ends
+#ifdef CAVOID_TRACE
+        if (tid0 == 0 && g_pol_trace)
+            g_pol_trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                      ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
     }
 }
 

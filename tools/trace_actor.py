@@ -1,0 +1,61 @@
+"""Per-tile phase timeline of the fused actor kernel's LAST step of a launch (development aid; needs the -DCAVOID_TRACE build:
+python -m rl_collision_avoidance_amd.build --trace; CAVOID_LIB=rl_collision_avoidance_amd/libcavoid_hip_trace.so).
+usage: python tools/trace_actor.py [worlds] [agents] [steps per launch]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from rl_collision_avoidance_amd import _lib
+from rl_collision_avoidance_amd.batched_env import BatchedCollisionAvoidanceEnv
+from rl_collision_avoidance_amd.config import EnvConfig
+from rl_collision_avoidance_amd.ga3c.network import NetworkVP_rnn
+from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+from rl_collision_avoidance_amd.ga3c.rollout import BatchedRollout
+
+
+def main():
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+
+    class Cfg(EnvConfig):
+        def __init__(self):
+            self.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+            EnvConfig.__init__(self)
+    cfg = Cfg()
+    env = BatchedCollisionAvoidanceEnv(W, cfg, seed=3)
+    torch.manual_seed(0)
+    pol = FusedPolicy(NetworkVP_rnn(cfg).cuda(), seed=5)
+    roll = BatchedRollout(env, pol, reflush_done=False, ring_len=4 * K + 64)
+    roll.reset()
+    for _ in range(3):
+        roll.run_fused(K)
+        roll.drain(provenance=False)
+    tiles = (W * N + 63) // 64
+    buf = torch.zeros((tiles, 16), dtype=torch.int64, device="cuda")
+    lib = _lib.lib()
+    lib.cavoid_actor_debug_trace.argtypes = [C.c_void_p]
+    assert lib.cavoid_actor_debug_trace(C.c_void_p(buf.data_ptr())) == 0
+    roll.run_fused(K)
+    torch.cuda.synchronize()
+    t = buf.cpu().numpy().astype(np.float64) / 100.0      # wall clock: 100 MHz -> us
+    # stamps of the last step: 13 begin | 5 inputs in LDS | 8..12 LSTM step 1 | 1 LSTM done | 2 layer1 | 3 layer2 + fc1 | 4 heads | 14 barrier | 0 env step | 15 bookkeeping | 6 end
+    order = [13, 5, 1, 2, 3, 4, 14, 0, 15, 6]
+    names = ["inputs", "lstm", "layer1", "layer2+fc1", "heads+select", "barrier", "env step (wavefront 0)", "Experience bookkeeping (wavefront 0)", "barrier"]
+    seg = np.stack([t[:, b] - t[:, a] for a, b in zip(order[:-1], order[1:])], axis=1)
+    print("tiles %d; last step of a %d-step launch, us, p10 / p50 / p90 over the tiles" % (tiles, K))
+    for n, col in zip(names, seg.T):
+        print("  %-40s %6.2f %6.2f %6.2f" % (n, *np.percentile(col, [10, 50, 90])))
+    per = t[:, 6] - t[:, 13]
+    print("  %-40s %6.2f %6.2f %6.2f" % ("the whole step", *np.percentile(per, [10, 50, 90])))
+    print("  policy pass (13 -> 14) p50 %.2f, env phase (14 -> 6) p50 %.2f" % (np.median(t[:, 14] - t[:, 13]), np.median(t[:, 6] - t[:, 14])))
+    lstm1 = np.diff(buf.cpu().numpy()[:, 8:13].astype(np.float64) / 100.0, axis=1)
+    print("  LSTM step 1 (gemm, barrier, cell update, barrier) p50:", np.round(np.median(lstm1, axis=0), 2).tolist())
+
+
+if __name__ == "__main__":
+    main()
