@@ -504,7 +504,7 @@ def main() -> None:
                               "look-ahead ring -- exact (seed, global world, episode) streams, bitwise the in-step generator, the refill launches inside the timed "
                               "region",
                  "pool": "a finished world RESTARTS BY GATHERING one of 65536 scenarios pre-generated outside the timed region",
-                 "instep": "a finished world restarts with a FRESH scenario generated inside the step kernel"}[args.scenarios]
+                 "instep": "a finished world restarts with a FRESH scenario generated inside the step kernel"}
 
     def cfg_for(n_agents):
         class Cfg(EnvConfig):
@@ -585,7 +585,29 @@ def main() -> None:
                 form["traffic_source"] = pmc
             form["bound"] = bound_of(form, Wl, n_agents)
 
-    env, acts = make(W, **SCEN)
+    scenario_fallback = None
+    try:
+        env, acts = make(W, **SCEN)
+        if args.scenarios == "lookahead":                     # one launch through the refill path before anything is timed
+            run_steps(env, acts, 1, None)
+            torch.cuda.synchronize(device)
+            env.reset()
+    except Exception as exc:      # noqa: BLE001 -- the look-ahead must never cost the contract line: fall back to the pool and say so
+        if args.scenarios == "pool":
+            raise
+        scenario_fallback = "--scenarios %s failed (%r): the headline restarts worlds from the pre-generated pool instead" % (args.scenarios, exc)
+        args.scenarios = "pool"
+        SCEN = scen_over("pool")
+        env, acts = make(W, **SCEN)
+    if world_size > 1:                                       # (every rank takes the same source)
+        flag = torch.tensor([0 if scenario_fallback is None else 1], dtype=torch.int32, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and scenario_fallback is None:
+            scenario_fallback = "another rank could not use --scenarios %s: pool" % args.scenarios
+            args.scenarios = "pool"
+            SCEN = scen_over("pool")
+            env.close()
+            env, acts = make(W, **SCEN)
     gather_mode = "none" if args.no_gather else args.gather
     exchange_possible = world_size > 1 or args.force_rccl      # (N = 1: only as a development run through a forced RCCL communicator)
     gather_in_metric = exchange_possible and gather_mode != "none"
@@ -593,6 +615,8 @@ def main() -> None:
     slots = None if (args.overwrite_outputs or gather_in_metric) else env.new_step_slots(min(args.slices, max(args.steps, 1)))
     sh = None
     extra = {}
+    if scenario_fallback:
+        extra["scenario_fallback"] = scenario_fallback
     # Synchronised PRE-ROLL (untimed, before the W warm-up steps the contract names): every world starts its first episode at step 0
     # and no episode can end on its time budget before ~40 steps, so a short --warmup would put a timed region in which NO world
     # restarts in front of the clock.  The pre-roll takes the batch past the first wave of restarts, so that the in-kernel
@@ -947,7 +971,7 @@ def main() -> None:
                                "uniform random actions pre-staged on the device, in-kernel auto-reset -- %s (the other scenario sources, "
                                "GEN v1 and GEN v2: extra.scenario_sources); launches of up to %d steps "
                                "(world state in registers between the steps of a launch); %s%s"
-                               % (which, N, W, SCEN_TEXT, args.slices,
+                               % (which, N, W, SCEN_TEXT[args.scenarios], args.slices,
                                   "every step overwrites one output slot" if args.overwrite_outputs else
                                   "every step's obs / reward / done / game_over written into its own output slot [K,W,N,.]",
                                   ("; + the gather of the packed records to %s inside the timed region (configs[2])"

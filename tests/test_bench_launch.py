@@ -144,3 +144,13 @@ def test_bench_other_scenario_sources_as_the_headline(mode, says):
                  "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"], 900)
     assert line["config"]["scenarios"] == mode and says in line["config"]["workload"]
     assert line["value"] > 0 and line["timing"]["restarts_in_timed_region"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_the_pool_when_the_lookahead_cannot_be_had():
+    """a look-ahead ring the library refuses (here: more than 4096 steps per launch asked for) must not cost the contract line: the
+    headline falls back to the pre-generated pool and says so"""
+    line = _run(["--gpus", "1", "--slices", "4100", "--steps", "20", "--warmup", "5", "--worlds", "512", "--reps", "3", "--no-cpu-baseline",
+                 "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"], 900)
+    assert line["config"]["scenarios"] == "pool" and "pre-generated" in line["config"]["workload"]
+    assert "failed" in line["extra"]["scenario_fallback"] and line["value"] > 0
