@@ -158,7 +158,29 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
                         if (4 * g + r == A) io.values[row] = logit[r];
                 }
             };
-            policy_split_tile<kSpDefaultProducts>(sa, planes, len_f, wave_max, rows, tid, load, emit);
+            if constexpr (!FROZEN) {
+                // Only the rows that still need an action go through the network (policy_split_tile, COMPACT): a learning agent that has not
+                // finished -- exactly the rows cavoid_rollout_active_rows lists for the step-by-step path (cavoid_rollout.hpp: obs column 0
+                // set, and the agent not done in the step that produced this observation unless its world has just restarted).  A finished
+                // agent waits for its world's last learning agent and a scripted agent acts by its own rule: the env ignores what either is
+                // given, the bookkeeping never reads it.  With the reference's re-flush quirk a done agent's value IS read: every row runs.
+                const uint8_t *done_prev = io.done + a0;
+                const uint8_t *over_prev = io.game_over + w0;
+                bool mine = lane < rows;
+                if (mine && rc.reflush_done == 0)
+                    mine = obs_t[(a0 + lane) * ow] > 0.5f && (over_prev[lane / N] != 0 || done_prev[lane] == 0);
+                // (a row that needs no action is handed action 0 / value 0, what the step-by-step path's row-list pass leaves there)
+                if (wave_in_block == 0 && lane < rows && !mine) { io.actions[a0 + lane] = 0; io.values[a0 + lane] = 0.0f; }
+                const unsigned long long live_mask = __ballot(mine);        // (every wavefront evaluates the same 64 rows: no trip through LDS)
+                const int n_rt = (__popcll(live_mask) + 15) >> 4;           // row tiles the live rows fill: one instantiation of the pass each
+                int *rmap = reinterpret_cast<int *>(len_f + 64);
+                if (n_rt == 4) policy_split_tile<kSpDefaultProducts, 4>(sa, planes, len_f, wave_max, rows, tid, load, emit, live_mask, rmap);
+                else if (n_rt == 3) policy_split_tile<kSpDefaultProducts, 3>(sa, planes, len_f, wave_max, rows, tid, load, emit, live_mask, rmap);
+                else if (n_rt >= 1) policy_split_tile<kSpDefaultProducts, 2>(sa, planes, len_f, wave_max, rows, tid, load, emit, live_mask, rmap);
+                // (n_rt == 0: nobody in the tile needs an action)
+            } else {
+                policy_split_tile<kSpDefaultProducts>(sa, planes, len_f, wave_max, rows, tid, load, emit);
+            }
             if constexpr (FROZEN) {
                 // the rows whose agent is a running frozen-network agent (the env state's flags: this step has not run yet)
                 bool mine = false;

@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "cavoid_policy.hpp"
 
 namespace cavoid {
@@ -225,6 +227,15 @@ __global__ void __launch_bounds__(256) policy_pack_split_kernel(const PolicyWeig
 
 #endif
 
+// Which of a tile's four 16-row tiles carry rows: all of them (the stand-alone kernel), or the first n (the fused actor kernel compacts the rows
+// that still need an action to the front of the tile -- policy_split_tile, COMPACT -- and the GEMMs, epilogues and cell updates of the others are skipped;
+// `n` is wave-uniform, every test a scalar branch)
+struct SpAllRows { static constexpr bool dyn = false; __device__ __forceinline__ constexpr bool has(int) const { return true; } };
+struct SpSomeRows { static constexpr bool dyn = true; int n; __device__ __forceinline__ bool has(int nt) const { return nt < n; } };
+// ... the first NRT of them, known at compile time: every test folds away (the fused actor kernel instantiates the pass for NRT = 2, 3, 4 and
+// picks one per tile and step by ONE scalar branch -- scalar tests around every group of matrix instructions cost more than the skipped
+// row tiles saved: profiles/r05_l_row_compaction.txt)
+template <int NRT> struct SpFirstRows { static constexpr bool dyn = true; __device__ __forceinline__ constexpr bool has(int nt) const { return nt < NRT; } };
 struct SplitYes { static constexpr bool value = true; };
 struct SplitNo { static constexpr bool value = false; };
 struct SplitW { uint4 w[3][4]; };                            // weight fragments of one chunk: plane x column tile
@@ -261,31 +272,59 @@ __device__ __forceinline__ void split_load_w(SplitW &f, const SplitSrc &src, int
 
 // activation fragments (ONE plane) of the k-range starting at LDS column `col` (32 wide); `slot`: the input chunk --
 // only k-group 0 holds data (one 8-value slot at column `col`), the other groups supply zeros
-__device__ __forceinline__ void split_load_a(uint4 (&a)[4], const unsigned char *planes, int plane, int lane, int col, bool slot) {
+template <class RT = SpAllRows>
+__device__ __forceinline__ void split_load_a(uint4 (&a)[4], const unsigned char *planes, int plane, int lane, int col, bool slot, RT rt = RT()) {
     const int g = lane >> 4;
     // (a chunk start is a multiple of 32 columns: sp_phys(col + 8 g) = col + the lane's constant part)
     const int off = slot ? (g == 0 ? sp_phys(col) : 2 * kSpZeroCol) : col + 16 * (g >> 1) + 256 * (g & 1);
     const unsigned char *p = planes + plane * kSpPlaneB + (lane & 15) * kSpStrideB + off;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) a[nt] = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
+    for (int nt = 0; nt < 4; ++nt) if (rt.has(nt)) a[nt] = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
 }
 
 // the MIXED activation fragments of the 8-wide input slot at LDS column `col`: k-group 0 = first pieces, 1 = second pieces, 2 = first
 // pieces again, 3 = anything finite (its weights are zeros) -- the partner of the packed weights' mixed plane (policy_pack_split_kernel)
-__device__ __forceinline__ void split_load_a_mix(uint4 (&a)[4], const unsigned char *planes, int lane, int col) {
+template <class RT = SpAllRows>
+__device__ __forceinline__ void split_load_a_mix(uint4 (&a)[4], const unsigned char *planes, int lane, int col, RT rt = RT()) {
     const int g = lane >> 4;                               // (k-group 3 re-reads k-group 2's values: its weights are zeros and activations are finite)
     const unsigned char *p = planes + (g == 1 ? kSpPlaneB : 0) + (lane & 15) * kSpStrideB + sp_phys(col);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) a[nt] = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
+    for (int nt = 0; nt < 4; ++nt) if (rt.has(nt)) a[nt] = *reinterpret_cast<const uint4 *>(p + nt * 16 * kSpStrideB);
 }
 
 // one partial product for all 16 (column tile, row tile) pairs: consecutive MFMAs never share an accumulator
-template <bool F16 = false>
-__device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4 (&a)[4], f32x4 (&acc)[4][4]) {
+template <bool F16 = false, class RT = SpAllRows>
+__device__ __forceinline__ void split_mfma_term(const uint4 (&w)[4], const uint4 (&a)[4], f32x4 (&acc)[4][4], RT rt = RT()) {
+    if constexpr (RT::dyn) {                               // row tile outermost: one scalar test per row tile, four independent MFMAs behind it
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int nt = 0; nt < 4; ++nt)
+            if (rt.has(nt)) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w[mt], a[nt], acc[mt][nt]);
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mfma_bf16<F16>(w[mt], a[nt], acc[mt][nt]);
+            }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w[mt], a[nt], acc[mt][nt]);
+    }
+}
+// the first product of a GEMM: C operand = the layer's bias
+template <bool F16, class RT>
+__device__ __forceinline__ void split_mfma_first(const uint4 (&w)[4], const uint4 (&a)[4], f32x4 (&acc)[4][4], const f32x4 (&b4)[4], RT rt) {
+    if constexpr (RT::dyn) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            if (rt.has(nt)) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mfma_bf16<F16>(w[mt], a[nt], b4[mt]);
+            }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w[mt], a[nt], b4[mt]);
+    }
 }
 
 // acc += W(chunks c0..c1-1 of `layer`) x act.  Chunk c reads LDS columns 32c.., except `slot_chunk`, which reads the
@@ -312,10 +351,10 @@ __device__ __forceinline__ void split_load_bias(f32x4 (&b4)[4], const SplitSrc &
 // The accumulators are not initialised: the very first product takes the layer's bias (this lane's four columns per column
 // tile, 16 registers: b4) as its C operand -- 64 register moves per GEMM less than broadcasting the bias into acc first.  b4 is
 // loaded one GEMM ahead, like the first weight fragments: the last chunk requests `next_bias` into it.
-template <bool F16>
+template <bool F16, class RT = SpAllRows>
 __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const SplitSrc &src, int layer, int c0, int c1, int slot_chunk, int slot_col,
                                             int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], int next_layer, int next_c,
-                                            f32x4 (&b4)[4], int next_bias) {
+                                            f32x4 (&b4)[4], int next_bias, RT rt = RT()) {
     // Round 5, float16 form: the input-slot chunk (<= 8 inputs in a K = 32 instruction; always the LAST chunk, c1 - 1) is ONE product
     // instead of three -- its three partial products laid side by side along K (mixed fragments: split_load_a_mix and the packed
     // weights' plane 2): 16 matrix instructions per slot chunk instead of 48, the same three partial sums in the same float32
@@ -325,11 +364,8 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const S
     uint4 a_hi[4], a_lo[4];
     auto col_of = [&](int c) { return c == slot_chunk ? slot_col : 32 * c; };
     if (c0 >= cm) {                                        // (uniform) only the slot chunk: acc = bias + mixed product
-        split_load_a_mix(a_lo, planes, lane, slot_col);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w.w[0][mt], a_lo[nt], b4[mt]);
+        split_load_a_mix(a_lo, planes, lane, slot_col, rt);
+        split_mfma_first<F16>(w.w[0], a_lo, acc, b4, rt);
         __builtin_amdgcn_sched_barrier(0);
         split_load_bias(b4, src, next_bias, wave, lane);
         split_load_w1(w.w[1], src, next_layer, 1, wave, lane, next_c);
@@ -337,8 +373,8 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const S
         __builtin_amdgcn_sched_barrier(0);
         return;
     }
-    split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk);
-    split_load_a(a_hi, planes, 0, lane, col_of(c0), c0 == slot_chunk);
+    split_load_a(a_lo, planes, 1, lane, col_of(c0), c0 == slot_chunk, rt);
+    split_load_a(a_hi, planes, 0, lane, col_of(c0), c0 == slot_chunk, rt);
     int c = c0;
     bool first = true;
 #pragma unroll 1
@@ -353,27 +389,24 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const S
             if (!last) split_load_w1(w.w[2], src, layer, 0, wave, lane, n);
             else if (to_slot) split_load_w1(w.w[2], src, layer, 2, wave, lane, cm);
             if (first) {                                   // (uniform) acc = bias + w1 * a_lo
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_bf16<F16>(w.w[0][mt], a_lo[nt], b4[mt]);
+                split_mfma_first<F16>(w.w[0], a_lo, acc, b4, rt);
                 first = false;
             } else {
-                split_mfma_term<F16>(w.w[0], a_lo, acc);
+                split_mfma_term<F16>(w.w[0], a_lo, acc, rt);
             }
             if (last) split_load_bias(b4, src, next_bias, wave, lane);   // (b4 was consumed by the first product: free since then)
             __builtin_amdgcn_sched_barrier(0);
-            if (to_slot) split_load_a_mix(a_lo, planes, lane, slot_col);
-            else split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
-            split_mfma_term<F16>(w.w[1], a_hi, acc);
+            if (to_slot) split_load_a_mix(a_lo, planes, lane, slot_col, rt);
+            else split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk, rt);
+            split_mfma_term<F16>(w.w[1], a_hi, acc, rt);
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[1], src, wl, 1, wave, lane, wc);
-            split_mfma_term<F16>(w.w[0], a_hi, acc);
+            split_mfma_term<F16>(w.w[0], a_hi, acc, rt);
             __builtin_amdgcn_sched_barrier(0);
-            if (!to_slot) split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
+            if (!to_slot) split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk, rt);
             if (last) {
                 split_load_w1(w.w[0], src, next_layer, 0, wave, lane, next_c);
-                if (to_slot) split_mfma_term<F16>(w.w[2], a_lo, acc);
+                if (to_slot) split_mfma_term<F16>(w.w[2], a_lo, acc, rt);
                 break;
             }
         }
@@ -387,20 +420,20 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const S
             __builtin_amdgcn_sched_barrier(0);
             if (to_slot) split_load_w1(w.w[0], src, layer, 2, wave, lane, cm);      // the slot chunk's mixed plane: 48 matrix instructions ahead
             else split_load_w1(w.w[0], src, wl, 0, wave, lane, wc);
-            split_mfma_term<F16>(w.w[2], a_lo, acc);
+            split_mfma_term<F16>(w.w[2], a_lo, acc, rt);
             if (last) split_load_bias(b4, src, next_bias, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
-            if (to_slot) split_load_a_mix(a_lo, planes, lane, slot_col);            // ... and its mixed activations: 32 ahead
-            else split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk);
-            split_mfma_term<F16>(w.w[1], a_hi, acc);
+            if (to_slot) split_load_a_mix(a_lo, planes, lane, slot_col, rt);            // ... and its mixed activations: 32 ahead
+            else split_load_a(a_lo, planes, 1, lane, col_of(n), n == slot_chunk, rt);
+            split_mfma_term<F16>(w.w[1], a_hi, acc, rt);
             __builtin_amdgcn_sched_barrier(0);
             split_load_w1(w.w[1], src, wl, 1, wave, lane, wc);
-            split_mfma_term<F16>(w.w[2], a_hi, acc);
+            split_mfma_term<F16>(w.w[2], a_hi, acc, rt);
             __builtin_amdgcn_sched_barrier(0);
-            if (!to_slot) split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk);
+            if (!to_slot) split_load_a(a_hi, planes, 0, lane, col_of(n), n == slot_chunk, rt);
             if (last) {
                 if (to_slot) {
-                    split_mfma_term<F16>(w.w[0], a_lo, acc);
+                    split_mfma_term<F16>(w.w[0], a_lo, acc, rt);
                     __builtin_amdgcn_sched_barrier(0);
                     split_load_w1(w.w[0], src, next_layer, 0, wave, lane, next_c);
                 }
@@ -412,14 +445,15 @@ __device__ __forceinline__ void split_gemm3(const unsigned char *planes, const S
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int P>
+template <int P, class RT = SpAllRows>
 __device__ __forceinline__ void split_gemm(const unsigned char *planes, const SplitSrc &src, int layer, int c0, int c1, int slot_chunk, int slot_col,
                                            int wave, int lane, SplitW &w, f32x4 (&acc)[4][4], int next_layer, int next_c,
-                                           int bias, f32x4 (&b4)[4], int next_bias) {
+                                           int bias, f32x4 (&b4)[4], int next_bias, RT rt = RT()) {
     if constexpr (P == 3 || P == kSpF16) {
-        split_gemm3<P == kSpF16>(planes, src, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, b4, next_bias);
+        split_gemm3<P == kSpF16>(planes, src, layer, c0, c1, slot_chunk, slot_col, wave, lane, w, acc, next_layer, next_c, b4, next_bias, rt);
         return;
     }
+    static_assert(!RT::dyn || P == 3 || P == kSpF16, "row compaction is carried by the three-product forms");
     {                                                      // acc[mt][nt] = bias of the lane's four columns 16*(4*wave+mt) + 4*(lane/16) + r
         f32x4 bb[4];
         split_load_bias(bb, src, bias, wave, lane);
@@ -470,12 +504,13 @@ __device__ __forceinline__ void split_store4(unsigned char *planes, int row, int
     *reinterpret_cast<uint2 *>(p + kSpPlaneB) = uint2{l0, l1};
 }
 
-template <bool F16 = false>
-__device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave, int lane, const f32x4 (&acc)[4][4]) {
+template <bool F16 = false, class RT = SpAllRows>
+__device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave, int lane, const f32x4 (&acc)[4][4], RT rt = RT()) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int nt = 0; nt < 4; ++nt) {
+        if (!rt.has(nt)) continue;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int mt = 0; mt < 4; ++mt) {
             f32x4 z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                  // relu as ONE integer max on the bit pattern (negative floats are negative
@@ -486,6 +521,7 @@ __device__ __forceinline__ void split_store_relu(unsigned char *planes, int wave
             }
             split_store4<F16>(planes, 16 * nt + (lane & 15), 16 * (4 * wave + mt) + 4 * (lane >> 4), z);
         }
+    }
 }
 
 struct SplitArgs {
@@ -562,17 +598,35 @@ __device__ __forceinline__ void split_lstm_cell2(const f32x2 xi, const f32x2 xj,
 //   emit(trow, g, pj, logit) is called by every lane of the heads' layout: tile row trow = 16 wave + lane%16, columns 4g..4g+3 --
 //                  pj = softmax probabilities incl. MIN_POLICY, logit[r] = raw head output (column A = the value).
 // planes / len_f / wave_max: the workgroup's LDS (policy_split_lds_bytes()).  Contains workgroup barriers: every thread calls it.
-template <int P, class Load, class Emit>
+// COMPACT (the fused actor kernel): `live(r)` says which tile rows still need an action (a learning agent that has not finished: what
+// cavoid_rollout_active_rows lists for the step-by-step path; a finished agent waits for its world's last learning agent, the env ignores
+// whatever it is given).  The live rows are packed to the front of the tile -- input row r goes to tile row popcount(live rows below r); rmap[64]
+// (LDS) holds the way back for emit() -- and only the first ceil(n_live / 16) row tiles are computed: GEMMs, cell updates, epilogues and heads of
+// the others are skipped by scalar branches.  Rows are independent in every layer, so a live row's outputs are bit for bit what the full pass
+// gives it; emit() is called for live rows only, with their ORIGINAL tile row (the action draw is keyed on it).
+// NRT > 0 = COMPACT with the first NRT row tiles computed: `live_mask` (bit r: tile row r still needs an action; the same value in every
+// wavefront; at least one bit, at most 16 NRT) comes from the caller, which picks the instantiation.
+template <int P, int NRT = 0, class Load, class Emit>
 __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned char *planes, float *len_f, int *wave_max, int rows_here,
-                                                  int tid, Load load, Emit emit) {
+                                                  int tid, Load load, Emit emit, unsigned long long live_mask = ~0ull, int *rmap = nullptr) {
     const PolicyArgs &p = sa.p;
     constexpr bool F16 = SplitFmt<P>::f16;
+    constexpr bool COMPACT = NRT > 0;
+    using RT = typename std::conditional<COMPACT, SpFirstRows<(NRT > 0 ? NRT : 4)>, SpAllRows>::type;
     // (wave in a scalar register: every weight / bias address is then a uniform base + this lane's constant 32-bit offset, and the
     //  fragment loads need no vector address arithmetic)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4;
     const int M = p.max_other, A = p.num_actions;
     const SplitSrc src = split_src(sa.sfrags, sa.sbias);
     constexpr int w_lstm = (int)kSpOffLstm;
+    int n_live = 64, pos = tid & 63;
+    bool mine = (tid & 63) < rows_here;
+    const RT rt{};
+    if constexpr (COMPACT) {
+        mine = (live_mask >> (tid & 63)) & 1ull;
+        n_live = __popcll(live_mask);
+        pos = __popcll(live_mask & ((1ull << (tid & 63)) - 1ull));
+    }
     SplitW f0;
     f32x4 b4[4];                                           // the bias of the GEMM that comes next (P = 3: its first product's C operand)
     // first LSTM step: h == 0, only the input chunk contributes (float16 form: its mixed plane, one product)
@@ -584,13 +638,19 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     {
         int local_max = 0, local_min = 0;
         if (tid < 64) {
-            const float v = tid < rows_here ? load(tid, 0) : 0.0f;
-            len_f[tid] = v;
+            const float v = (COMPACT ? mine : tid < rows_here) ? load(tid, 0) : 0.0f;
+            if constexpr (COMPACT) {                        // tile row `pos` takes input row `tid`; the tile rows behind the live ones are empty
+                if (mine) { len_f[pos] = v; rmap[pos] = tid; }
+                if (tid >= n_live) len_f[tid] = 0.0f;
+            } else {
+                len_f[tid] = v;
+            }
             int len = (int)v;
             len = len < 0 ? 0 : (len > M ? M : len);
             local_max = len;
             local_min = v >= (float)len ? len : len - 1;   // (a fractional count: the row's last step is live only up to floor)
             local_min = local_min < 0 ? 0 : local_min;
+            if (COMPACT && !mine) local_min = M;           // (the empty tile rows do not decide whether every row is live at step t)
         }
         // h = 0 (columns 0..63 of both planes)
         for (int e = tid; e < 2 * 64 * 8; e += 256) {
@@ -605,7 +665,10 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
             const int n_in = s == 0 ? kPolHost : kPolOther, sc0 = s == 0 ? 1 : 1 + kPolHost + kPolOther * (s - 1);
             // all eight loads (and the sixteen of avg / std) are issued before the first use: unused elements re-read element 0
             // of the slot and rows past the end re-read row 0 -- valid addresses, selected away below -- so nothing is conditional
-            const bool row_ok = r < rows_here;
+            // COMPACT: r == this thread's lane; a live row writes tile row `pos`, a lane at or behind n_live zeroes tile row `lane`, the
+            // lanes in between (not live, below n_live) own no tile row
+            const bool row_ok = COMPACT ? mine : r < rows_here;
+            if (COMPACT && !mine && r < n_live) continue;
             const int rr = row_ok ? r : 0;
             float v[8], av[8], sd[8];
 #pragma unroll
@@ -625,7 +688,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
             uint32_t hi[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) split2<F16>(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
-            unsigned char *d = planes + r * kSpStrideB + sp_phys(kSpSlotCol + 8 * s);
+            unsigned char *d = planes + ((COMPACT && mine) ? pos : r) * kSpStrideB + sp_phys(kSpSlotCol + 8 * s);
             *reinterpret_cast<uint4 *>(d) = uint4{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<uint4 *>(d + kSpPlaneB) = uint4{lo[0], lo[1], lo[2], lo[3]};
         }
@@ -660,7 +723,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         if (t == 1) POLICY_STAMP(8);
         split_gemm<P>(planes, src, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
                       t + 1 < steps ? w_lstm : (int)kSpOffL1, 0, kBiasLstm, b4,
-                      t + 1 < steps ? kBiasLstm : kBiasL1);                 // (requests the next step's / layer1's first fragments and bias)
+                      t + 1 < steps ? kBiasLstm : kBiasL1, rt);             // (requests the next step's / layer1's first fragments and bias)
         if (t == 1) POLICY_STAMP(9);
         __syncthreads();                                   // every wavefront has read h
         if (t == 1) POLICY_STAMP(10);
@@ -668,6 +731,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         // length keep (c, h)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
+            if (!rt.has(nt)) continue;
             const bool live = ALL_LIVE || len_r[nt] > (float)t;
             f32x4 h_new;
 #pragma unroll
@@ -702,36 +766,36 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
             split_load_w<P>(f0, src, (int)kSpOffL1, wave, lane, 0);
             split_load_bias(b4, src, kBiasL1, wave, lane);
         }
-        split_gemm<P>(planes, src, (int)kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, (int)kSpOffL2, 0, kBiasL1, b4, kBiasL2);
+        split_gemm<P>(planes, src, (int)kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, (int)kSpOffL2, 0, kBiasL1, b4, kBiasL2, rt);
         __syncthreads();
-        split_store_relu<F16>(planes, wave, lane, acc);
+        split_store_relu<F16>(planes, wave, lane, acc, rt);
         __syncthreads();
     }
     POLICY_STAMP(2);
     // ---- layer2, fullyconnected1 ----------------------------------------------------------------------------------
     {
         f32x4 acc[4][4];
-        split_gemm<P>(planes, src, (int)kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, (int)kSpOffFc1, 0, kBiasL2, b4, kBiasFc1);
+        split_gemm<P>(planes, src, (int)kSpOffL2, 0, kSpChWide, -1, 0, wave, lane, f0, acc, (int)kSpOffFc1, 0, kBiasL2, b4, kBiasFc1, rt);
         __syncthreads();
-        split_store_relu<F16>(planes, wave, lane, acc);
+        split_store_relu<F16>(planes, wave, lane, acc, rt);
         __syncthreads();
     }
     uint4 hw[kSpChWide][3];                                // the heads' weight fragments: half in flight across the epilogue
     auto head_frag = [&](int c, int pl) { return split_buf16(src.w, lane * 16, ((int)kSpOffHead + (c * 3 + pl) * 64) * 16); };
     {
         f32x4 acc[4][4];
-        split_gemm<P>(planes, src, (int)kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, (int)kSpOffFc1, kSpChWide - 1, kBiasFc1, b4, kBiasFc1);
+        split_gemm<P>(planes, src, (int)kSpOffFc1, 0, kSpChWide, -1, 0, wave, lane, f0, acc, (int)kSpOffFc1, kSpChWide - 1, kBiasFc1, b4, kBiasFc1, rt);
 #pragma unroll
         for (int c = 0; c < kSpChWide / 2; ++c)
 #pragma unroll
             for (int pl = 0; pl < SplitFmt<P>::planes; ++pl) hw[c][pl] = head_frag(c, pl);
         __syncthreads();
-        split_store_relu<F16>(planes, wave, lane, acc);
+        split_store_relu<F16>(planes, wave, lane, acc, rt);
         __syncthreads();
     }
     POLICY_STAMP(3);
     // ---- heads: wavefront w does rows 16w..16w+15 x 16 columns (A logits, the value, padding) ---------------------
-    {
+    if (rt.has(wave)) {                                    // (COMPACT: a wavefront whose row tile is empty has no heads to make)
 #pragma unroll
         for (int c = kSpChWide / 2; c < kSpChWide; ++c)
 #pragma unroll
@@ -765,7 +829,11 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         float pj[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pj[r] = (4 * g + r < A) ? (e[r] / sum + p.min_policy) * scale : 0.0f;
-        emit(trow, g, pj, logit);
+        if constexpr (COMPACT) {                            // the tile row's input row; only live rows are emitted
+            if (trow < n_live) emit(rmap[trow], g, pj, logit);
+        } else {
+            emit(trow, g, pj, logit);
+        }
     }
     POLICY_STAMP(4);
 }

@@ -210,7 +210,8 @@ class BatchedRollout(object):
         """Why ``step()`` / the hipGraph form must be used instead of the fused actor kernel (None: it applies)."""
         cfg = self.env.cfg
         # (skip_finished -- the step-by-step path's row list of the agents that still need an action -- does not matter here: the
-        #  kernel runs every row of a tile anyway, and what finished agents are given as action / value is never used)
+        #  kernel packs the rows that still need an action to the front of their tile itself and skips the empty row tiles -- unless the
+        #  re-flush quirk or frozen-network agents make every row count -- and hands the others action 0 / value 0 like the row-list pass)
         if not getattr(self.policy, "accepts_strided_obs", False):
             return "the policy is not a FusedPolicy"
         if cfg.rvo_enabled and cfg.max_agents > 12:

@@ -35,6 +35,11 @@ def _make(W, N, seed, reflush, greedy=False, skip_finished=None, **over):
     if over.get("gen_frozen_fraction", 0.0) > 0.0:          # the network behind the frozen-network agents: its own weights
         torch.manual_seed(4321)
         frozen = FusedPolicy(NetworkVP_rnn(cfg).to("cuda:0"), seed=0)
+    # The fused kernel runs the network only for the rows that still need an action (a learning agent that has not finished; with the
+    # re-flush quirk or frozen-network agents: every row), exactly the rows the step-by-step path lists with skip_finished -- what a
+    # finished agent's ring entry holds as action is whatever it was last given, in both forms, so the forms are compared like for like.
+    if skip_finished is None:
+        skip_finished = (not reflush) and not (over.get("gen_frozen_fraction", 0.0) > 0.0)
     # short chunks: many flushes; room for every duplicate row of the re-flush quirk (a full buffer drops rows in arrival order,
     # which legitimately differs between the two forms)
     roll = BatchedRollout(env, pol, reflush_done=reflush, greedy=greedy, time_max=5, dup_capacity=600000 if reflush else None,

@@ -127,7 +127,13 @@ def test_fused_actor_against_the_oracles(N, W, reflush, greedy, launches, over):
         vals_all[t] = v_k.cpu().numpy().reshape(W, N)
         with torch.no_grad():
             _, p_ref, v_ref = net.forward(xt)
-        running = torch.from_numpy((is_learning[t][..., 0] > 0.5).reshape(-1)).cuda()
+        # the rows the loop runs the network for: a learning agent that has not finished (done in the step that produced this observation,
+        # unless its world has just restarted) -- a finished agent is handed action 0 / value 0, which nothing reads.  With the re-flush
+        # quirk or frozen-network agents in the batch every row runs.
+        need = is_learning[t][..., 0] > 0.5
+        if t >= 1 and not reflush and roll.frozen_policy is None:
+            need = need & ((ora[t - 1][3].reshape(W, 1) != 0) | (ora[t - 1][2].reshape(W, N) == 0))
+        running = torch.from_numpy(need.reshape(-1)).cuda()
         worst_v = max(worst_v, float((v_k - v_ref).abs()[running].max()))
         if greedy:
             top2 = p_ref.topk(2, dim=1).values

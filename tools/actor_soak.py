@@ -28,8 +28,10 @@ def make(W, N, seed, reflush, greedy, time_max, net_seed, **kw):
     net = NetworkVP_rnn(cfg).to("cuda:0")
     with torch.no_grad():                                   # less uniform policies than the initialisation's: sharper heads
         net.p_kernel.mul_(6.0)
+    # (the fused kernel runs the network for the rows that still need an action only -- every row with the re-flush quirk -- and so does
+    #  the step-by-step path with skip_finished: like for like, down to what a finished agent's ring entry holds)
     roll = BatchedRollout(env, FusedPolicy(net, seed=net_seed + 1), reflush_done=reflush, greedy=greedy, time_max=time_max,
-                          dup_capacity=4 * W * N * 64 if reflush else None)
+                          dup_capacity=4 * W * N * 64 if reflush else None, skip_finished=not reflush)
     roll.reset()
     return env, roll
 
