@@ -54,13 +54,13 @@ __host__ __device__ inline size_t actor_env_lds_bytes(int n_agents, int tile_flo
 template <int N, bool RVO, bool EARLY>
 __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState &s, const PoolRec *pool, const RolloutCfg &rc, const RolloutState &rs,
                                                     const RolloutIO &rio_arg, const ActorIO &io, const float *obs_t, float *obs_n, double *lds_tab,
-                                                    float *wbase, int lane, int64_t tile, int32_t step, int blk) {
+                                                    float *wbase, int lane, int64_t tile, int32_t step, int blk, int *live_next = nullptr) {
     const int wpw = c.wpw, ow = c.width;
     const int64_t w0 = tile * wpw;
     KIO k{};
     k.actions = io.actions; k.obs = obs_n; k.rew = io.rewards; k.done = io.done; k.game_over = io.game_over;
     k.obs_stride = ow; k.n_steps = 1;
-    StepOut so{0.0f, true, false};
+    StepOut so{0.0f, true, false, false};
     const int lw = lane / N, i = lane - lw * N;
     const int64_t w = w0 + lw, a = w * N + i;
     const bool in_range = lane < wpw * N && w < c.num_worlds;
@@ -80,6 +80,11 @@ __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState 
     if (EARLY) first_trip();
     env_tile<N, MODE_STEP_AUTORESET, RVO>(c, s, pool, k, lds_tab, wbase, lane, tile, &so);
     POLICY_STAMP(0);                                       // (trace build) env.step of the tile done, its stores issued
+    if (live_next) {        // the rows that need an action at the NEXT step (cavoid_rollout_active_rows' predicate on what this step produced), for the
+        //                     fused kernel's next policy pass: in LDS, so that the pass need not go to memory for the flags
+        const unsigned long long m = __ballot(in_range && so.learning_next && (so.game_over || !so.done));
+        if (lane == 0) { live_next[0] = (int)(uint32_t)m; live_next[1] = (int)(uint32_t)(m >> 32); }
+    }
     if (!EARLY) first_trip();
     const bool learning = in_range && learn_f > 0.5f;
     const int base = lane < wpw * N ? lw * N : 0;
@@ -167,8 +172,14 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
                 const uint8_t *done_prev = io.done + a0;
                 const uint8_t *over_prev = io.game_over + w0;
                 bool mine = lane < rows;
-                if (mine && rc.reflush_done == 0)
-                    mine = obs_t[(a0 + lane) * ow] > 0.5f && (over_prev[lane / N] != 0 || done_prev[lane] == 0);
+                if (rc.reflush_done == 0) {
+                    if (t == 0) {                            // (uniform) the first step of a launch reads the flags the previous launch left in memory,
+                        if (mine) mine = obs_t[(a0 + lane) * ow] > 0.5f && (over_prev[lane / N] != 0 || done_prev[lane] == 0);
+                    } else {                                 // the later ones the mask the tile's own env step left in LDS
+                        const unsigned long long m = (unsigned long long)(uint32_t)wave_max[12] | ((unsigned long long)(uint32_t)wave_max[13] << 32);
+                        mine = (m >> lane) & 1ull;
+                    }
+                }
                 // (a row that needs no action is handed action 0 / value 0, what the step-by-step path's row-list pass leaves there)
                 if (wave_in_block == 0 && lane < rows && !mine) { io.actions[a0 + lane] = 0; io.values[a0 + lane] = 0.0f; }
                 const unsigned long long live_mask = __ballot(mine);        // (every wavefront evaluates the same 64 rows: no trip through LDS)
@@ -207,7 +218,8 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
 
         if (wave_in_block == 0) {
             // ---- env.step of the tile, then the Experience bookkeeping of its slots ---------------------------------------
-            actor_env_push_tile<N, RVO, (N <= (RVO ? 9 : 13))>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, lds_tab, wbase, lane, tile, step, blk);
+            actor_env_push_tile<N, RVO, (N <= (RVO ? 9 : 13))>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, lds_tab, wbase, lane, tile, step, blk,
+                                                               FROZEN ? nullptr : wave_max + 12);
             POLICY_STAMP(15);                                // env step + bookkeeping of the tile done (stores issued)
         } else {
             // ---- meanwhile: the step's state rows -> the time-major experience store -----------------------------------------

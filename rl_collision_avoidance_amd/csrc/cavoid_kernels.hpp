@@ -1213,7 +1213,7 @@ enum : int { MODE_STEP = 0, MODE_STEP_AUTORESET = 1, MODE_OBSERVE = 2, MODE_RESE
 // registers (N = 10: +40 VGPRs and scratch) for code it never runs.
 // what the last step of a tile left in the lane's registers, for a caller that goes on in the same kernel (the fused actor:
 // cavoid_actor.hpp hands it to the experience bookkeeping)
-struct StepOut { float reward; bool done, game_over; };
+struct StepOut { float reward; bool done, game_over; bool learning_next; };   // learning_next: column 0 of the NEXT observation (after a restart: the new agent's)
 
 // The body of env_kernel for ONE tile (one wavefront): lds_tab = the workgroup's action-table copy, wbase = the wavefront's
 // private LDS (staging arrays, obs tile, ORCA scratch), wave = the tile's index.  A device function so that the fused actor
@@ -1532,6 +1532,7 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
     }
 
     CAVOID_STAMP(5);                                        // rewards / restart done
+    if (out) out->learning_next = active && (a.flags & CAVOID_F_PRESENT) != 0u && (a.flags & CAVOID_F_LEARNING) != 0u;
     // one step per launch: the state is final here -- its stores complete under the observation phase instead of behind it, where the
     // kernel's end waited for them (same box: 4 x 8192 5.99 -> 5.69 us, 10 x 8192 12.8 -> 12.4; saturated launches pay 3 % for it:
     // 4 x 262144 44.9 -> 46.4 us.  Chosen at run time by batch size, the two copies of the stores cost more than either gains.)
