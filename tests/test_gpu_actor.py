@@ -286,3 +286,20 @@ def test_step_push_equals_step_then_push(N, W, reflush, over):
     np.testing.assert_allclose(epa[:, 1], epb[:, 1], rtol=1e-6, atol=1e-6)
     for e, r in rolls:
         r.close(); e.close()
+
+
+def test_rows_that_need_no_action_get_none():
+    """The fused kernel runs the network only for the rows that still need an action (cavoid_actor.hpp, policy_split_tile<P, NRT>): right after a
+    reset that is every learning agent -- scripted and absent agents' rows are handed action 0 / value 0 -- and a live row's value is bit for bit
+    the stand-alone pass's on the same observation, whatever tile row the compaction moved it to."""
+    env, net, pol, roll = _make(700, 4, 5, False, gen_min_agents=2, gen_nonlearning_fraction=0.5, gen_static_fraction=0.5)
+    obs0 = roll.obs.clone()
+    need = (obs0[..., 0] > 0.5)
+    assert 0.2 < need.float().mean().item() < 0.8                       # a real mix: most tiles run 2 or 3 of their 4 row tiles
+    roll.run_fused(1)
+    torch.cuda.synchronize()
+    acts, vals = roll._act_out.view(700, 4), roll._val_out.view(700, 4)      # (the kernel's hand-over buffers: the last step's actions / values)
+    assert (acts[~need] == 0).all() and (vals[~need] == 0).all()
+    _, v_ref = pol(obs0[..., 1:].reshape(700 * 4, -1))                   # the stand-alone kernel on every row
+    assert torch.equal(vals[need], v_ref.view(700, 4)[need])
+    assert (acts[need] >= 0).all() and (acts[need] < env.num_actions).all() and acts[need].float().std().item() > 0
