@@ -306,6 +306,12 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
  *   obs_cur [W,N,1+D]: the observation to act on first; obs_next: a second buffer of the same shape -- step t reads one and
  *   writes the other, so after the call the current observation is in obs_cur when n_steps is even, in obs_next when odd.
  *   rewards / done / game_over / actions int32 [W,N] / values float [W,N]: per-step outputs, holding the LAST step's afterwards.
+ *   The network runs only for the rows that still need an action -- what cavoid_rollout_active_rows lists: a learning agent (obs
+ *   column 0) that was not done in the step that produced the observation, or whose world has just restarted; a finished agent
+ *   waits for its world's last learning agent, a scripted agent acts by its own rule, the env ignores what either is given -- and
+ *   the other rows are handed action 0 / value 0, like cavoid_policy_forward_rows' pass over that list (nothing reads them; the
+ *   experience store's action entry of such a row is 0).  With reflush_done (the reference's re-flush quirk reads a done agent's
+ *   value) and in cavoid_actor_run_mix every row runs.
  *   buffers: the experience store of cavoid_rollout_push.  The policy's launch counter and the rollout's step counter advance
  *   by n_steps on the device (the call can sit in a hipGraph).
  * Worlds with ORCA agents (rvo_enabled) and GEN v2 scenarios generated inside the step run over the env step's ORCA instantiation,
