@@ -41,6 +41,17 @@ EXTRA_FLAGS = {"cavoid_multistep.hip": ["-mllvm", "-disable-machine-licm"], "cav
 STAMP_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so.stamp")
 DEPS = SOURCES + [os.path.join(CSRC, h) for hs in HEADERS.values() for h in hs] + [os.path.join(ROOT, "include", "cavoid.h")]
 OBJ_DIR = os.path.join(PKG_DIR, "build")
+# Development variants (phase-trace build, fault-injection builds) are test / tooling artefacts, never the product: they are linked
+# into tests/_variants/, NOT beside libcavoid_hip.so, so that the package directory holds exactly one library and a process that maps
+# the product maps nothing else (selected with CAVOID_LIB=<path> by the tests and tools that want one, always in a child process).
+VARIANT_DIR = os.path.join(ROOT, "tests", "_variants")
+
+
+def variant_path(name: str) -> str:
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    return os.path.join(VARIANT_DIR, "libcavoid_hip_%s.so" % name)
+
+
 # -ffp-contract=off: the reference env is unfused NumPy float64; keep mul/add separate so that the
 # only numerical difference from the CPU oracle is the transcendental library.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -120,7 +131,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 def build_trace(verbose: bool = False) -> str:
     """Development variant with in-kernel phase time stamps (tools/trace_step.py); never loaded by
     the product (select it with CAVOID_LIB=<path>)."""
-    out = os.path.join(PKG_DIR, "libcavoid_hip_trace.so")
+    out = variant_path("trace")
     return _link(_compile_objects(["-DCAVOID_TRACE"], ".trace", False, verbose), out, verbose)
 
 
@@ -135,7 +146,7 @@ def build_fault(verbose: bool = False) -> str:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     objs = [obj if o.endswith("cavoid_relay.o") else o for o in objs]
-    return _link(objs, os.path.join(PKG_DIR, "libcavoid_hip_fault.so"), verbose)
+    return _link(objs, variant_path("fault"), verbose)
 
 
 def build_ulp_fault(kind: int, verbose: bool = False) -> str:
@@ -159,7 +170,7 @@ def build_ulp_fault(kind: int, verbose: bool = False) -> str:
                 print(" ".join(j), flush=True)
         with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
             list(pool.map(subprocess.check_call, jobs))
-    return _link([swap.get(o, o) for o in objs], os.path.join(PKG_DIR, "libcavoid_hip_ulp%d.so" % kind), verbose)
+    return _link([swap.get(o, o) for o in objs], variant_path("ulp%d" % kind), verbose)
 
 
 if __name__ == "__main__":

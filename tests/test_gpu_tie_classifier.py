@@ -75,7 +75,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _stress_with_fault(kind, case):
     from rl_collision_avoidance_amd import build
-    lib = os.path.join(build.PKG_DIR, "libcavoid_hip_ulp%d.so" % kind)
+    lib = build.variant_path("ulp%d" % kind)
     if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(build.CSRC, "cavoid_kernels.hpp")):
         if build.shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
             pytest.skip("no prebuilt fault variant and no hipcc on this box")

@@ -39,7 +39,7 @@ timeout 900 python tools/pmc.py actor_kernel $out/${tag}_actor_pmc.json "SQ_BUSY
 (hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/mfma_valu_overlap.hip -o /tmp/mvo 2>/dev/null && /tmp/mvo > $out/${tag}_mfma_valu_overlap.txt) 2>> $out/errors.txt
 (hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/cu_scaling.hip -o /tmp/cus 2>/dev/null && /tmp/cus > $out/${tag}_cu_scaling.txt) 2>> $out/errors.txt
 (hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/wave_placement.hip -o /tmp/wp 2>/dev/null && /tmp/wp > $out/${tag}_wave_placement.txt) 2>> $out/errors.txt
-for n in 16384 32768; do CAVOID_LIB=rl_collision_avoidance_amd/libcavoid_hip_trace.so python tools/trace_policy.py $n 2>&1 | grep -v "amdgpu.ids\|pair " ; done > $out/${tag}_policy_phase_trace.txt
+for n in 16384 32768; do CAVOID_LIB=tests/_variants/libcavoid_hip_trace.so python tools/trace_policy.py $n 2>&1 | grep -v "amdgpu.ids\|pair " ; done > $out/${tag}_policy_phase_trace.txt
 timeout 1500 python bench.py --sweep --full-loop > $out/${tag}_bench.json 2>> $out/errors.txt
 timeout 900 python bench.py --agents 10 --sweep --no-full-loop > $out/${tag}_bench_n10.json 2>> $out/errors.txt
 timeout 300 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_k20.json 2>> $out/errors.txt   # the driver's command line

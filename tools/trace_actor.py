@@ -1,5 +1,5 @@
 """Per-tile phase timeline of the fused actor kernel's LAST step of a launch (development aid; needs the -DCAVOID_TRACE build:
-python -m rl_collision_avoidance_amd.build --trace; CAVOID_LIB=rl_collision_avoidance_amd/libcavoid_hip_trace.so).
+python -m rl_collision_avoidance_amd.build --trace; CAVOID_LIB=tests/_variants/libcavoid_hip_trace.so).
 usage: python tools/trace_actor.py [worlds] [agents] [steps per launch]"""
 import ctypes as C
 import os

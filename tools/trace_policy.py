@@ -1,5 +1,5 @@
 """Per-workgroup timeline of the fused policy kernel (development aid; needs the -DCAVOID_TRACE build:
-python -m rl_collision_avoidance_amd.build --trace; CAVOID_LIB=rl_collision_avoidance_amd/libcavoid_hip_trace.so)."""
+python -m rl_collision_avoidance_amd.build --trace; CAVOID_LIB=tests/_variants/libcavoid_hip_trace.so)."""
 import ctypes as C
 import os
 import sys

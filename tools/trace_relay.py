@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("CAVOID_LIB", os.path.join(ROOT, "rl_collision_avoidance_amd", "libcavoid_hip_trace.so"))
+os.environ.setdefault("CAVOID_LIB", os.path.join(ROOT, "tests", "_variants", "libcavoid_hip_trace.so"))
 
 import numpy as np
 import torch

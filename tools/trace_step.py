@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where does one env-step wavefront spend its time?  Runs the -DCAVOID_TRACE build
-(CAVOID_LIB=rl_collision_avoidance_amd/libcavoid_hip_trace.so) and prints, per phase, the
+(CAVOID_LIB=tests/_variants/libcavoid_hip_trace.so) and prints, per phase, the
 shader-clock deltas (median / p90 / max over wavefronts) plus the launch span."""
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("CAVOID_LIB", os.path.join(ROOT, "rl_collision_avoidance_amd", "libcavoid_hip_trace.so"))
+os.environ.setdefault("CAVOID_LIB", os.path.join(ROOT, "tests", "_variants", "libcavoid_hip_trace.so"))
 
 import numpy as np
 import torch
