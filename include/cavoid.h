@@ -209,6 +209,18 @@ int cavoid_step_autoreset(cavoid_env *env, const int32_t *actions, float *obs, f
 int cavoid_step_autoreset_n(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
                             float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream);
 
+/* The env-level CONTINUOUS action space (run-ws/config.yaml:3-5, ACTION_SPACE_TYPE = 0: "continuous" at the gym level; SURVEY App. A:
+ * the discretisation lives in the policy) in the auto-reset and K-step launch forms: float actions [n_steps][W,N,2] -- (speed,
+ * heading change) for the unicycle dynamics, a velocity (vx, vy) for CAVOID_DYN_HOLONOMIC (which ONLY these entry points and
+ * cavoid_step_continuous can step: it has no table actions) -- slice t at actions + t*action_stride FLOATS (>= 2*W*N, or 0 with
+ * n_steps == 1); everything else as cavoid_step_autoreset / _n / _packed: in-kernel restarts from the pool, the look-ahead rings or the
+ * in-step generator, every step's outputs in its own slot, scripted agents acting by their own rule.  (A continuous K-step launch
+ * runs the single-wavefront step loop: the role-split and pipelined forms decode table actions.) */
+int cavoid_step_continuous_autoreset(cavoid_env *env, const float *actions /* [W,N,2] */, float *obs, float *rewards, uint8_t *done,
+                                     uint8_t *game_over, void *stream);
+int cavoid_step_continuous_autoreset_n(cavoid_env *env, const float *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
+                                       float *obs, float *rewards, uint8_t *done, uint8_t *game_over, void *stream);
+
 /* ---- packed outputs: one record per agent, [W, N, cavoid_packed_width()] floats = (obs row | reward | done) ----
  * The kernel assembles the record in its LDS tile and writes it with the same coalesced stores as the plain
  * observation: no separate reward / done arrays, no pack pass before the multi-GPU gather.  reset / observe write
@@ -220,6 +232,8 @@ int cavoid_step_packed(cavoid_env *env, const int32_t *actions, float *packed, u
 /* packed [n_steps, S, N, width + 2] and game_over [n_steps, S] with S = out_step_stride worlds, or one slot when it is 0 */
 int cavoid_step_autoreset_packed(cavoid_env *env, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
                                  float *packed, uint8_t *game_over, void *stream);
+int cavoid_step_continuous_autoreset_packed(cavoid_env *env, const float *actions, int64_t action_stride, int32_t n_steps,
+                                            int64_t out_step_stride, float *packed, uint8_t *game_over, void *stream);
 
 /* ---- multi-GPU hand-over: ONE all-gather of every rank's packed shard (RCCL over xGMI) ------------------------------
  * One process per GPU, contiguous world ranges (rank r owns worlds [r*W, (r+1)*W)).  The communicator is created from

@@ -68,8 +68,11 @@ def lib():
         _lib.oracle_step_autoreset.argtypes = [C.POINTER(OracleCfg), C.POINTER(OracleGen), C.c_uint64, C.c_int64,
                                                C.c_void_p, C.c_int64, C.POINTER(_State), C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.oracle_step_autoreset_any.argtypes = [C.POINTER(OracleCfg), C.POINTER(OracleGen), C.c_uint64, C.c_int64,
+                                                   C.c_void_p, C.c_int64, C.POINTER(_State), C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for f in (_lib.oracle_default_cfg, _lib.oracle_step, _lib.oracle_observe, _lib.oracle_generate,
-                  _lib.oracle_step_autoreset):
+                  _lib.oracle_step_autoreset, _lib.oracle_step_autoreset_any):
             f.restype = None
     return _lib
 
@@ -174,7 +177,7 @@ def generate(cfg: OracleCfg, gen: OracleGen, seed: int, st: State, episode: np.n
 
 
 def step_autoreset(cfg: OracleCfg, gen: OracleGen, seed: int, st: State, episode: np.ndarray, actions,
-                   world_offset: int = 0):
+                   world_offset: int = 0, cont=None):
     N = cfg.max_agents
     W = st.flags.size // N
     width = 6 + 7 * cfg.max_other
@@ -183,8 +186,12 @@ def step_autoreset(cfg: OracleCfg, gen: OracleGen, seed: int, st: State, episode
     rew = np.empty((W, N), np.float64)
     done = np.empty((W, N), np.uint8)
     go = np.empty(W, np.uint8)
-    actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(W, N)
+    if actions is not None:
+        actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(W, N)
+    if cont is not None:                                     # float [W,N,2] continuous / holonomic actions (oracle_step's second form)
+        cont = np.ascontiguousarray(cont, dtype=np.float32).reshape(W, N, 2)
+    assert (actions is None) != (cont is None)
     cs = st._c()
-    lib().oracle_step_autoreset(C.byref(cfg), C.byref(gen), seed, world_offset, _ptr(episode), W, C.byref(cs),
-                                _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(go))
+    lib().oracle_step_autoreset_any(C.byref(cfg), C.byref(gen), seed, world_offset, _ptr(episode), W, C.byref(cs),
+                                    _ptr(actions), _ptr(cont), _ptr(obs), _ptr(rew), _ptr(done), _ptr(go))
     return obs, rew, done, go

@@ -513,14 +513,17 @@ void oracle_generate(const oracle_cfg *c, const oracle_gen *g, uint64_t seed, in
         if (!mask || mask[w]) generate_world(c, g, seed, (uint32_t)(world_offset + w), episode[w], st, w);
 }
 
-void oracle_step_autoreset(const oracle_cfg *c, const oracle_gen *g, uint64_t seed, int64_t world_offset,
-                           uint32_t *episode, int64_t W, oracle_state *st, const int32_t *actions,
+/* the auto-reset step with either action form: int32 [W,N] table indices (cont == NULL) or float [W,N,2] continuous actions
+ * (speed, heading change) resp. holonomic velocities (cont != NULL) -- the VecEnv convention of oracle_step_autoreset around oracle_step's
+ * two action forms */
+void oracle_step_autoreset_any(const oracle_cfg *c, const oracle_gen *g, uint64_t seed, int64_t world_offset,
+                               uint32_t *episode, int64_t W, oracle_state *st, const int32_t *actions, const float *cont,
                            double *obs, double *rew, uint8_t *done, uint8_t *game_over) {
     const int N = c->max_agents, width = 6 + 7 * c->max_other;
     for (int64_t w = 0; w < W; ++w) {
         agent_t ag[ORACLE_MAX_AGENTS];
         int n = load_world(c, st, w, ag);
-        step_world(c, ag, n, actions + w * N, 0, obs + w * N * width, rew + w * N, done + w * N, game_over + w);
+        step_world(c, ag, n, actions ? actions + w * N : 0, cont ? cont + w * N * 2 : 0, obs + w * N * width, rew + w * N, done + w * N, game_over + w);
         store_world(c, st, w, ag, n);
         if (game_over[w]) {
             episode[w] += 1;
@@ -529,4 +532,10 @@ void oracle_step_autoreset(const oracle_cfg *c, const oracle_gen *g, uint64_t se
             observe_world(c, ag, n, obs + w * N * width);
         }
     }
+}
+
+void oracle_step_autoreset(const oracle_cfg *c, const oracle_gen *g, uint64_t seed, int64_t world_offset,
+                           uint32_t *episode, int64_t W, oracle_state *st, const int32_t *actions,
+                           double *obs, double *rew, uint8_t *done, uint8_t *game_over) {
+    oracle_step_autoreset_any(c, g, seed, world_offset, episode, W, st, actions, 0, obs, rew, done, game_over);
 }

@@ -73,6 +73,11 @@ void oracle_step_autoreset(const oracle_cfg *cfg, const oracle_gen *gen, uint64_
                            uint32_t *episode, int64_t W, oracle_state *st, const int32_t *actions,
                            double *obs, double *rew, uint8_t *done, uint8_t *game_over);
 
+/* ... the same with either action form (cont != NULL: float [W,N,2] continuous / holonomic actions, like oracle_step) */
+void oracle_step_autoreset_any(const oracle_cfg *cfg, const oracle_gen *gen, uint64_t seed, int64_t world_offset,
+                               uint32_t *episode, int64_t W, oracle_state *st, const int32_t *actions, const float *cont,
+                               double *obs, double *rew, uint8_t *done, uint8_t *game_over);
+
 void oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

@@ -105,6 +105,9 @@ SYMBOLS = [
     ("cavoid_step_continuous", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("cavoid_step_autoreset", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("cavoid_step_autoreset_n", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P, _P, _P]),
+    ("cavoid_step_continuous_autoreset", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("cavoid_step_continuous_autoreset_n", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P, _P, _P]),
+    ("cavoid_step_continuous_autoreset_packed", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P]),
     ("cavoid_step_autoreset_n_timed", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_float)]),
     ("cavoid_policy_rows", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("cavoid_packed_width", C.c_int32, [_P]),

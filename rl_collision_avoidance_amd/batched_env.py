@@ -358,6 +358,37 @@ class BatchedCollisionAvoidanceEnv(object):
             _lib.check(rc, "cavoid_step_autoreset_n")
         return self.obs, self.rewards, self.done, self.game_over
 
+    def step_continuous_autoreset(self, actions: torch.Tensor, n_steps: Optional[int] = None, slots: Optional[StepSlots] = None):
+        """The auto-reset step with CONTINUOUS actions -- float32 ``[W,N,2]`` (one step) or pre-staged ``[T,W,N,2]`` (``n_steps`` <= T steps
+        in ONE launch, the world state in registers between them): (speed, heading change) for the unicycle dynamics, a velocity for the
+        holonomic ones.  ``slots``: plain ``StepSlots`` (every step's obs / rewards / done / game_over in its own slot) or
+        ``StepSlots(packed=True)`` (the (obs | reward | done) records); without, the env's own output buffers hold the last step's."""
+        W, N = self.num_worlds, self.max_agents
+        if actions.dim() == 3:
+            a, n, stride = self._want(actions, (W, N, 2), torch.float32, "actions"), 1, 0
+        else:
+            T = actions.shape[0]
+            n = T if n_steps is None else int(n_steps)
+            if n > T:
+                raise ValueError("n_steps > number of action slices")
+            a, stride = self._want(actions, (T, W, N, 2), torch.float32, "actions"), 2 * W * N
+        if slots is not None and slots.steps < n:
+            raise ValueError("need StepSlots of at least n_steps slots")
+        if slots is not None and slots.is_packed:
+            _lib.check(self._lib.cavoid_step_continuous_autoreset_packed(self._h, self._ptr(a), stride, n, W, self._ptr(slots.packed),
+                                                                         self._ptr(slots.game_over), self._stream()),
+                       "cavoid_step_continuous_autoreset_packed")
+            return slots.packed, slots.game_over
+        out = (slots.obs, slots.rewards, slots.done, slots.game_over) if slots is not None else (self.obs, self.rewards, self.done, self.game_over)
+        if slots is None and actions.dim() == 3:
+            _lib.check(self._lib.cavoid_step_continuous_autoreset(self._h, self._ptr(a), self._ptr(out[0]), self._ptr(out[1]), self._ptr(out[2]),
+                                                                  self._ptr(out[3]), self._stream()), "cavoid_step_continuous_autoreset")
+            return out
+        _lib.check(self._lib.cavoid_step_continuous_autoreset_n(self._h, self._ptr(a), stride, n, W if slots is not None else 0,
+                                                                self._ptr(out[0]), self._ptr(out[1]), self._ptr(out[2]), self._ptr(out[3]),
+                                                                self._stream()), "cavoid_step_continuous_autoreset_n")
+        return out
+
     def policy_rows(self, policy_id: int, only_running: bool = True):
         """(row_index int32 [W*N], row_count int32 [1]) on the device: the (world, agent) slots run by scripted policy
         ``policy_id`` (``_lib.POLICY_*``) -- for POLICY_FROZEN_NET the rows a frozen network must supply actions for."""

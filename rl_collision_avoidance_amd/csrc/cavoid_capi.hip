@@ -530,13 +530,19 @@ extern "C" int cavoid_step_continuous(cavoid_env *e, const float *actions, float
 
 // the auto-reset step, n_steps >= 1 steps in ONE launch.  Latency mode (small batch with a scenario pool) takes the
 // register-prefetch instantiation for multi-step launches (and for single steps when CAVOID_PREFETCH_POOL=1).
+// Continuous actions (`cont` != null: float [n_steps][W,N,2], (speed, heading change) for the unicycle dynamics, a velocity for the
+// holonomic ones -- cavoid_step_continuous's action form) take the same launch forms: one step per launch, or the in-launch step loop with
+// every step's outputs in its own slot and restarts from the pool / the look-ahead rings / the in-step generator.  (The role-split relay
+// and the two-wavefront pipeline decode table actions only: a continuous K-step launch runs the single-wavefront loop kernels.)
 static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64_t action_stride, int32_t n_steps, int64_t out_step_stride,
-                            hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC) return CAVOID_EINVAL;
+                            hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const float *cont = nullptr) {
+    if (e->cfg.dynamics == CAVOID_DYN_HOLONOMIC && !cont) return CAVOID_EINVAL;     // holonomic needs velocity actions
     if (n_steps < 1 || action_stride < 0) return CAVOID_EINVAL;
+    if (cont && n_steps > 1 && action_stride != 0 && action_stride < 2 * e->A) return CAVOID_EINVAL;   // (float slices must not overlap)
     if (out_step_stride != 0 && out_step_stride < e->W) return CAVOID_EINVAL;   // slots of consecutive steps must not overlap
     io.out_step_stride = n_steps > 1 ? out_step_stride : 0;
     io.actions = actions;
+    io.cont = cont;
     io.action_stride = action_stride;
     io.n_steps = n_steps;
     if (int rc = cavoid_ahead_prepare(e, n_steps, s)) return rc;
@@ -566,6 +572,28 @@ extern "C" int cavoid_step_autoreset_packed(cavoid_env *e, const int32_t *action
     if (n_steps == 0) return CAVOID_OK;
     return launch_autoreset(e, packed_io(e, packed, game_over), actions, action_stride, n_steps, out_step_stride,
                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cavoid_step_continuous_autoreset(cavoid_env *e, const float *actions, float *obs, float *rew, uint8_t *done, uint8_t *game_over,
+                                               void *stream) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK) return CAVOID_EINVAL;
+    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), nullptr, 0, 1, 0, static_cast<hipStream_t>(stream), nullptr, nullptr, actions);
+}
+
+extern "C" int cavoid_step_continuous_autoreset_n(cavoid_env *e, const float *actions, int64_t action_stride, int32_t n_steps,
+                                                 int64_t out_step_stride, float *obs, float *rew, uint8_t *done, uint8_t *game_over, void *stream) {
+    if (step_args(e, actions, rew, done, game_over) != CAVOID_OK || n_steps < 0) return CAVOID_EINVAL;
+    if (n_steps == 0) return CAVOID_OK;
+    return launch_autoreset(e, plain_io(e, obs, rew, done, game_over), nullptr, action_stride, n_steps, out_step_stride,
+                            static_cast<hipStream_t>(stream), nullptr, nullptr, actions);
+}
+
+extern "C" int cavoid_step_continuous_autoreset_packed(cavoid_env *e, const float *actions, int64_t action_stride, int32_t n_steps,
+                                                      int64_t out_step_stride, float *packed, uint8_t *game_over, void *stream) {
+    if (!e || !actions || !packed || !game_over || n_steps < 0) return CAVOID_EINVAL;
+    if (n_steps == 0) return CAVOID_OK;
+    return launch_autoreset(e, packed_io(e, packed, game_over), nullptr, action_stride, n_steps, out_step_stride,
+                            static_cast<hipStream_t>(stream), nullptr, nullptr, actions);
 }
 
 extern "C" int cavoid_step_autoreset_n_timed(cavoid_env *e, const int32_t *actions, int64_t action_stride, int32_t n_steps,

@@ -123,13 +123,13 @@ static_assert(sizeof(PoolRec) == 64, "pool record must be one 64-byte line");
 struct KIO {
     PoolRec *pool_out;       // MODE_RESET only: write the generated agents here (pool fill) instead of the world buffer
     const int32_t *actions;  // [n_steps][W,N] (slice t at actions + t*action_stride) or null
-    const float *cont;       // [W,N,2] or null
+    const float *cont;       // continuous actions [n_steps][W,N,2] (slice t at cont + t*action_stride FLOATS) or null
     const uint8_t *mask;     // reset mask [W] or null
     float *obs;              // [W,N,obs_stride] or null
     float *rew;              // [W,N]; null in packed mode
     uint8_t *done;           // [W,N]; null in packed mode
     uint8_t *game_over;      // [W]
-    int64_t action_stride;   // int32 elements between the action slices of consecutive steps
+    int64_t action_stride;   // elements (int32 of `actions`, floats of `cont`) between the action slices of consecutive steps
     int64_t out_step_stride; // multi-step launches: step t writes its outputs into slot t -- obs + t*S*N*obs_stride, rew / done + t*S*N,
                              // game_over + t*S with S = out_step_stride WORLDS (>= num_worlds); 0: every step overwrites slot 0
     int32_t n_steps;         // steps taken by ONE launch (MODE_STEP_AUTORESET; 1 elsewhere)
@@ -1268,8 +1268,8 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
     a.flags = 0u;
     uint32_t episode = 0u;
     bool fresh = false;                                    // this lane's world starts a new episode
-    int act_next = 0;                                      // the NEXT step's action index, loaded one step ahead
-    float c0 = 0.f, c1 = 0.f;
+    int act_next = 0;                                      // the NEXT step's action, loaded one step ahead: the table index -- or, with continuous
+    float c1_next = 0.f;                                   // actions (io.cont), the BITS of its first component, the second one in c1_next
     if (active) {
         if (MODE == MODE_RESET) {
             fresh = io.mask == nullptr || io.mask[w] != 0;
@@ -1282,7 +1282,7 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
             if (!kStepping || RVO) a.speed = s.speed[a_idx];   // (RVO agents read the others' last velocities)
         }
         if (kStepping) {
-            if (io.cont) { c0 = io.cont[2 * a_idx]; c1 = io.cont[2 * a_idx + 1]; }
+            if (io.cont) { act_next = __float_as_int(io.cont[2 * a_idx]); c1_next = io.cont[2 * a_idx + 1]; }
             else act_next = io.actions[a_idx];
         }
     }
@@ -1363,7 +1363,13 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
     int act = act_next;
-    if (kLoop && t + 1 < n_steps && active) act_next = io.actions[(int64_t)(t + 1) * io.action_stride + a_idx];
+    const float c1 = c1_next;
+    if (kLoop && t + 1 < n_steps && active) {
+        if (CAVOID_RARE(io.cont != nullptr)) {
+            const float *cn = io.cont + (int64_t)(t + 1) * io.action_stride + 2 * a_idx;
+            act_next = __float_as_int(cn[0]); c1_next = cn[1];
+        } else act_next = io.actions[(int64_t)(t + 1) * io.action_stride + a_idx];
+    }
     const int64_t slot_w = kLoop ? (int64_t)t * io.out_step_stride : 0;   // first world row of this step's output slot
 
     if (kStepping) {
@@ -1371,7 +1377,7 @@ __device__ __forceinline__ void env_tile(const KCfg &c, const KState &s, const P
         wave_lds_sync();
         const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK;   // (4 = frozen network: its action index comes in like a learner's)
         double a0 = 0.0, a1 = 0.0;
-        if (io.cont) { a0 = (double)c0; a1 = (double)c1; }
+        if (io.cont) { a0 = (double)__int_as_float(act); a1 = (double)c1; }
         else {
             act = act < 0 ? 0 : (act >= c.num_actions ? c.num_actions - 1 : act);
             a0 = (double)a.pref * lds_tab[2 * act];

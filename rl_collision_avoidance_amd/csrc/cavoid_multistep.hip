@@ -10,11 +10,12 @@ using namespace cavoid;
 int cavoid_launch_multistep(cavoid_env *e, const KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (e->k.rvo_enabled || (e->k.gen_mode == 1 && e->k.pool_size <= 0))       // ORCA agents / in-step box generator: cavoid_rvo.hip
         return cavoid_launch_rvo(e, prefetch ? MODE_STEP_AUTORESET_PF : MODE_STEP_AUTORESET_N, io, s, ev_start, ev_stop);
-    if (prefetch && e->pipeline >= 2) {                     // small batch: the step cut into roles on several wavefronts (env_relay_kernel)
+    // (continuous actions: the role-split and pipelined forms decode table actions only -- the single-wavefront loops carry them)
+    if (prefetch && e->pipeline >= 2 && !io.cont) {                     // small batch: the step cut into roles on several wavefronts (env_relay_kernel)
         const int rc = cavoid_launch_relay(e, io, s, ev_start, ev_stop);
         if (rc != CAVOID_EUNSUPPORTED) return rc;
     }
-    if (prefetch && e->pipeline) {                          // two wavefronts per tile, pipelined (env_pipe_kernel)
+    if (prefetch && e->pipeline && !io.cont) {                          // two wavefronts per tile, pipelined (env_pipe_kernel)
         const int rc = launch_pipe<false>(e, io, s, ev_start, ev_stop);
         if (rc != CAVOID_EUNSUPPORTED) return rc;
     }

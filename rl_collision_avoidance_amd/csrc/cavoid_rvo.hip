@@ -7,7 +7,7 @@
 using namespace cavoid;
 
 int cavoid_launch_rvo(cavoid_env *e, int mode, const KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (mode == MODE_STEP_AUTORESET_PF && e->pipeline) {
+    if (mode == MODE_STEP_AUTORESET_PF && e->pipeline && !io.cont) {       // (the pipelined form decodes table actions only)
         const int rc = launch_pipe<true>(e, io, s, ev_start, ev_stop);
         if (rc != CAVOID_EUNSUPPORTED) return rc;
     }

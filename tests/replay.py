@@ -106,6 +106,24 @@ def replay_rollout(rec, rows, episodes, reflush, gamma, t_max):
     return expect_rows
 
 
+def subset_worlds(rec, rows, episodes, worlds):
+    """replay_rollout's inputs restricted to `worlds` (sorted world indices), renumbered 0..len-1: for batches too large to replay world
+    by world in Python"""
+    worlds = np.asarray(worlds)
+    index = -np.ones(rec[0][0].shape[0], np.int64)
+    index[worlds] = np.arange(len(worlds))
+    rec = [tuple(v[worlds] for v in r) for r in rec]
+    x, r, a, src = rows
+    keep = index[src[:, 0]] >= 0
+    src = src[keep].copy()
+    src[:, 0] = index[src[:, 0]]
+    if episodes is not None:
+        ek = index[episodes[:, 0].astype(np.int64)] >= 0
+        episodes = episodes[ek].copy()
+        episodes[:, 0] = index[episodes[:, 0].astype(np.int64)]
+    return rec, (x[keep], r[keep], a[keep], src), episodes
+
+
 # ---- ties of a scripted policy vs real divergences -------------------------------------------------------------------------
 def _explain(ocfg, ogen, seed, w, N, pre_s, pre_e, a, s, e, h, spread, eps, trials):
     """Diagnostics of a divergence the classifier calls real (CAVOID_STRESS_EXPLAIN=1): per agent, how far HIP's post-step state is from

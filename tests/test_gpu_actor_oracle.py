@@ -67,6 +67,35 @@ def _make(W, N, seed, reflush, greedy, ring_len, **over):
     (3, 130, False, True, (5, 16, 16, 16, 16, 16, 11), dict(gen_pool_size=0, gen_min_agents=2)),
 ])
 def test_fused_actor_against_the_oracles(N, W, reflush, greedy, launches, over):
+    _check_fused_actor(N, W, reflush, greedy, launches, over)
+
+
+# Round 6: the same checks where the hardware hazard of DESIGN.md 3.7 (d) lived -- 512 tiles, i.e. TWO workgroups per CU, one tile's env
+# step running beside the partner tile's matrix phase on the same SIMDs.  The nondeterministic v_par rows of round 4 appeared ONLY in this
+# regime and were found by a soak, not by `pytest -m gpu`; here the float64 env oracle checks every observation row the policy acted on at
+# every step of BASELINE configs[4]'s own shape (4 x 8192) and of 10 x 4096 (6 worlds per tile -> 683 tiles).  The env and policy halves run
+# over all worlds; the rollout half (a pure-Python replay, world by world) over every 16th world.
+@pytest.mark.parametrize("N,W,launches,over", [
+    (4, 8192, (1, 16, 16, 7), dict()),
+    (10, 4096, (2, 16, 16, 6), dict(gen_min_agents=2, gen_nonlearning_fraction=0.2)),
+])
+def test_fused_actor_against_the_oracles_two_workgroups_per_cu(N, W, launches, over):
+    _check_fused_actor(N, W, False, False, launches, over, rollout_worlds=np.arange(0, W, 16))
+
+
+def test_a_slice_of_the_actor_soak():
+    """20 seconds of tools/actor_soak.py (random shapes incl. 512 tiles, scenario sources, ORCA agents, the re-flush quirk; the fused actor
+    kernel against step-by-step stepping, bitwise) inside the suite: the run that found round 4's wrong rows was this soak"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "actor_soak.py"), "20"], cwd=root, timeout=600,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and "bitwise" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
+def _check_fused_actor(N, W, reflush, greedy, launches, over, rollout_worlds=None):
     seed = 33
     T = sum(launches)
     env, net, pol, roll = _make(W, N, seed, reflush, greedy, T + 8, **over)
@@ -166,7 +195,10 @@ def test_fused_actor_against_the_oracles(N, W, reflush, greedy, launches, over):
     episodes = roll.drain_episodes().cpu().numpy()
     assert batch.dropped == 0 and roll.lost_blocks == 0 and len(batch) > W * 5
     rows = [v.cpu().numpy() for v in (batch.x, batch.r, batch.a_index, batch.src)]
+    n_eps = len(episodes)
+    if rollout_worlds is not None:
+        rec, rows, episodes = rp.subset_worlds(rec, rows, episodes, rollout_worlds)
     matched = rp.replay_rollout(rec, rows, episodes, reflush, GAMMA, T_MAX)
-    assert matched > W * 5
-    assert len(episodes) == int(sum(o[3].sum() for o in ora))   # one log record per finished episode
+    assert matched > (W if rollout_worlds is None else len(rollout_worlds)) * 5
+    assert n_eps == int(sum(o[3].sum() for o in ora))           # one log record per finished episode
     roll.close(); env.close()

@@ -193,6 +193,119 @@ def test_continuous_actions_parity(dyn):
     env.close()
 
 
+def _cont_actions(rng, dyn, st, K, W, N):
+    """K slices of continuous actions [K,W,N,2]: holonomic = a velocity towards the goal (as seen from `st`) + noise, unicycle =
+    (speed, heading change) with the heading change biased towards the goal so that agents also arrive"""
+    g = np.stack([st.f32[0] - st.f64[0], st.f32[1] - st.f64[1]], -1).reshape(W, N, 2)
+    if dyn == "holonomic":
+        v = g / np.maximum(np.linalg.norm(g, axis=-1, keepdims=True), 1e-6) * st.f32[3].reshape(W, N, 1)
+        return (v[None] + rng.normal(0, 0.3, size=(K, W, N, 2))).astype(np.float32)
+    to_goal = np.arctan2(g[..., 1], g[..., 0]) - st.f64[2].reshape(W, N)
+    to_goal = (to_goal + np.pi) % (2 * np.pi) - np.pi
+    dh = np.clip(to_goal, -0.5, 0.5)[None] * (rng.random((K, W, N)) < 0.7) + rng.uniform(-0.4, 0.4, (K, W, N))
+    sp = st.f32[3].reshape(1, W, N) * rng.uniform(0.3, 1.0, (K, W, N))
+    return np.stack([sp, dh], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("source", ["pool", "lookahead", "instep"])
+@pytest.mark.parametrize("dyn", ["unicycle", "unicycle_max_turn_rate", "holonomic"])
+def test_continuous_actions_in_the_autoreset_and_k_step_launch_forms(dyn, source):
+    """Round 6 (north_star "unicycle/holonomic dynamics"): continuous / velocity actions in EVERY launch form -- one
+    auto-reset step per launch, K steps per launch with every step's outputs in its own slot (plain and packed records) -- with restarts
+    from the pool, the look-ahead rings and the in-step generator; every step against the float64 oracle's step."""
+    W, N, seed = 777, 4, 23
+    code = {"unicycle": 0, "unicycle_max_turn_rate": 1, "holonomic": 2}[dyn]
+    over = {"pool": dict(gen_pool_size=300), "lookahead": dict(gen_pool_size=0, gen_lookahead=64), "instep": dict(gen_pool_size=0)}[source]
+    ocfg, ogen = _oracle(N, None, 2, 0.3, pool=over["gen_pool_size"], dynamics=code)
+    env = _env(W, N, seed=seed, dynamics=dyn, gen_min_agents=2, gen_nonlearning_fraction=0.3, **over)
+    env.reset()
+    st, ep = co.State.empty(W, N), np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    rng = np.random.default_rng(seed)
+
+    def check(tag, obs, rew, done, go, ora):
+        oobs, orew, odone, ogo = ora
+        assert np.array_equal(done, odone) and np.array_equal(go, ogo), tag
+        np.testing.assert_allclose(rew, orew, rtol=0, atol=OBS_TOL, err_msg=str(tag))
+        d = np.abs(obs - oobs)
+        d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2.0 * np.pi))
+        assert d.max() <= OBS_TOL, (tag, d.max())
+
+    def check_state(tag):
+        f64, f32, fl = _pull(env)
+        assert np.array_equal(fl, st.flags) and np.array_equal(f32, st.f32), tag
+        np.testing.assert_allclose(f64, st.f64, rtol=0, atol=STATE_TOL, err_msg=str(tag))
+        assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep), tag
+    # ---- one auto-reset step per launch ----------------------------------------------------------------------------------
+    for t in range(50):
+        a = _cont_actions(rng, dyn, st, 1, W, N)[0]
+        out = env.step_continuous_autoreset(torch.from_numpy(a).cuda())
+        ora = co.step_autoreset(ocfg, ogen, seed, st, ep, None, cont=a)
+        check((dyn, source, "single", t), *[v.cpu().numpy() for v in out], ora)
+        check_state((dyn, source, "single", t))
+    # ---- K steps per launch, per-step slots (plain, then packed records) --------------------------------------------------
+    K = 16
+    slots, pslots = env.new_step_slots(K), env.new_step_slots(K, packed=True)
+    wdt = env.obs_width
+    for launch in range(7):
+        a = _cont_actions(rng, dyn, st, K, W, N)
+        packed = launch >= 5
+        n = K if launch != 3 else 11                        # (a launch shorter than its slots and its action slices)
+        if packed:
+            pk, go = env.step_continuous_autoreset(torch.from_numpy(a).cuda(), slots=pslots)
+            obs, rew, done = pk[..., :wdt], pk[..., wdt], pk[..., wdt + 1].to(torch.uint8)
+        else:
+            obs, rew, done, go = env.step_continuous_autoreset(torch.from_numpy(a).cuda(), n_steps=n, slots=slots)
+        for t in range(n):
+            ora = co.step_autoreset(ocfg, ogen, seed, st, ep, None, cont=a[t])
+            check((dyn, source, launch, t), obs[t].cpu().numpy(), rew[t].cpu().numpy(), done[t].cpu().numpy(), go[t].cpu().numpy(), ora)
+        check_state((dyn, source, launch))
+    assert ep.max() >= 1 and (ep >= 1).mean() > 0.3        # the restarts were exercised
+    # table actions are refused for the holonomic dynamics in every form (they have no velocity meaning), loudly
+    if dyn == "holonomic":
+        ai = torch.zeros((W, N), dtype=torch.int32, device="cuda")
+        with pytest.raises(RuntimeError):
+            env.step_autoreset(ai)
+    env.close()
+
+
+def test_continuous_k_step_launch_at_the_benchmark_shape_and_argument_checks():
+    """4 x 8192 (BASELINE configs[1]'s batch), 24 continuous-action steps in ONE launch with per-step slots, every slot against the oracle;
+    == the same steps one launch each, bit for bit; overlapping float slices are refused"""
+    import ctypes as C
+    from rl_collision_avoidance_amd import _lib
+    W, N, K, seed = 8192, 4, 24, 31
+    ocfg, ogen = _oracle(N)
+    env, twin = _env(W, N, seed=seed), _env(W, N, seed=seed)
+    env.reset(); twin.reset()
+    st, ep = co.State.empty(W, N), np.zeros(W, np.uint32)
+    co.generate(ocfg, ogen, seed, st, ep)
+    rng = np.random.default_rng(seed)
+    for rnd in range(3):                                    # (three launches: past the first restarts)
+        a = _cont_actions(rng, "unicycle", st, K, W, N)
+        slots = env.new_step_slots(K)
+        obs, rew, done, go = env.step_continuous_autoreset(torch.from_numpy(a).cuda(), slots=slots)
+        for t in range(K):
+            oobs, orew, odone, ogo = co.step_autoreset(ocfg, ogen, seed, st, ep, None, cont=a[t])
+            d = np.abs(obs[t].cpu().numpy() - oobs)
+            d[..., 3] = np.minimum(d[..., 3], np.abs(d[..., 3] - 2.0 * np.pi))
+            assert d.max() <= OBS_TOL and np.abs(rew[t].cpu().numpy() - orew).max() <= OBS_TOL, (rnd, t)
+            assert np.array_equal(done[t].cpu().numpy(), odone) and np.array_equal(go[t].cpu().numpy(), ogo), (rnd, t)
+            o1 = twin.step_continuous_autoreset(torch.from_numpy(a[t]).cuda())
+            assert torch.equal(o1[0], obs[t]) and torch.equal(o1[1], rew[t]) and torch.equal(o1[2], done[t]) and torch.equal(o1[3], go[t]), (rnd, t)
+        assert np.array_equal(_pull(env)[2], st.flags) and np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep)
+    assert ep.max() >= 1
+    lib = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    at = torch.from_numpy(a).cuda()
+    rc = lib.cavoid_step_continuous_autoreset_n(env._h, p(at), 2 * W * N - 1, 4, W, p(slots.obs), p(slots.rewards), p(slots.done), p(slots.game_over), None)
+    assert rc == -1                                         # float slices of consecutive steps must not overlap
+    rc = lib.cavoid_step_continuous_autoreset_n(env._h, None, 2 * W * N, 4, W, p(slots.obs), p(slots.rewards), p(slots.done), p(slots.game_over), None)
+    assert rc == -1
+    torch.cuda.synchronize()
+    env.close(); twin.close()
+
+
 def test_u_switches_follow_the_oracle():
     """close-penalty sign (U5), float64 action array, timeout off (U1), time budget from the goal centre (U11):
     flipped on both sides."""

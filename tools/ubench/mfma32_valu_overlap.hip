@@ -9,7 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 enum { IDLE = 0, M16 = 1, M32 = 2, FMA = 3, EXP = 4, MIX = 5, F64 = 6, LDSR = 7, CVT = 8,
-       M32_F1 = 9, M32_F2 = 10, M32_F3 = 11, M32_F4 = 12, M32_F5 = 13, M32_F6 = 14, M16_F1 = 15, M16_F2 = 16, M32_D2 = 17, M32_D4 = 18 };
+       M32_F1 = 9, M32_F2 = 10, M32_F3 = 11, M32_F4 = 12, M32_F5 = 13, M32_F6 = 14, M16_F1 = 15, M16_F2 = 16, M32_D2 = 17, M32_D4 = 18,
+       PKFMA = 19, MED3 = 20, FMIX = 21, RCP = 22, MOV = 23, PERM = 24, CVTRTZ = 25 };
 
 template <int KIND>
 __device__ __forceinline__ float stream(int iters, float a, float b, const unsigned char *lds) {
@@ -27,8 +28,8 @@ __device__ __forceinline__ float stream(int iters, float a, float b, const unsig
                     acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, acc[k], 0, 0, 0);
                     if (KIND != M16) {
                         __builtin_amdgcn_sched_barrier(0);
-                        r[k & 3] = __builtin_fmaf(r[k & 3], b, a);
-                        if (KIND == M16_F2) r[(k + 2) & 3] = __builtin_fmaf(r[(k + 2) & 3], b, a);
+                        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[k & 3]) : "v"(b), "v"(a));
+                        if (KIND == M16_F2) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[(k + 2) & 3]) : "v"(b), "v"(a));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -53,7 +54,7 @@ __device__ __forceinline__ float stream(int iters, float a, float b, const unsig
                     if (NF || ND) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) r[f] = __builtin_fmaf(r[f], b, a);
+                        for (int f = 0; f < NF; ++f) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[f]) : "v"(b), "v"(a));
 #pragma unroll
                         for (int f = 0; f < ND; ++f) d[f] = __builtin_fma(d[f], (double)b, (double)a);
                         __builtin_amdgcn_sched_barrier(0);
@@ -63,7 +64,7 @@ __device__ __forceinline__ float stream(int iters, float a, float b, const unsig
         float s = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + (float)(d[0] + d[1] + d[2] + d[3]);
         for (int k = 0; k < 4; ++k) s += acc[k][0];
         return s;                                                            // 32 MFMAs (32 clocks each) per iteration
-    } else if (KIND == FMA || KIND == EXP || KIND == MIX || KIND == CVT) {
+    } else if (KIND == FMA || KIND == EXP || KIND == MIX || KIND == CVT || KIND >= PKFMA) {
         float r[8];
         for (int k = 0; k < 8; ++k) r[k] = a + k;
         for (int it = 0; it < iters; ++it) {
@@ -71,9 +72,16 @@ __device__ __forceinline__ float stream(int iters, float a, float b, const unsig
             for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    if (KIND == FMA) r[k] = __builtin_fmaf(r[k], b, a);
+                    if (KIND == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(b), "v"(a));     // (plain C is packed into v_pk_fma_f32 by the compiler)
+                    else if (KIND == PKFMA) r[k] = __builtin_fmaf(r[k], b, a);
+                    else if (KIND == MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(b), "v"(a));
+                    else if (KIND == FMIX) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(r[k]) : "v"(b), "v"(a));
+                    else if (KIND == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[k]));
+                    else if (KIND == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(r[k]) : "v"(b));
+                    else if (KIND == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(b), "v"(a));
                     else if (KIND == EXP) r[k] = __builtin_amdgcn_exp2f(r[k]);
-                    else if (KIND == CVT) { unsigned h; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(r[k]), "v"(r[(k + 1) & 7])); r[k] = __uint_as_float(h | 0x3c003c00u); }
+                    else if (KIND == CVT) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(r[k]) : "v"(b));
+                    else if (KIND == CVTRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r[k]) : "v"(b));
                     else r[k] = (u & 3) == 0 ? __builtin_amdgcn_exp2f(r[k]) : __builtin_fmaf(r[k], b, a);
                 }
         }
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(512) pair(float *out, long long *cyc, int iter
 static const char *name(int k) {
     static const char *n[] = {"idle", "mfma16x16x32", "mfma32x32x16", "fma32", "exp32", "mix(1 exp:3 fma)", "fma64", "lds b128", "cvt_pk_f16",
                               "m32 + 1 fma", "m32 + 2 fma", "m32 + 3 fma", "m32 + 4 fma", "m32 + 5 fma", "m32 + 6 fma", "m16 + 1 fma", "m16 + 2 fma",
-                              "m32 + 2 fma64", "m32 + 4 fma64"};
+                              "m32 + 2 fma64", "m32 + 4 fma64", "pk_fma32 (2 vals)", "med3", "fma_mix", "rcp32", "mov", "perm", "cvt_pkrtz_f16"};
     return n[k];
 }
 static double per(int k) { return k == LDSR ? 16 : ((k == M32 || (k >= M32_F1 && k <= M32_F6) || k == M32_D2 || k == M32_D4) ? 32 : 64); }
@@ -141,13 +149,22 @@ int main() {
     float *out; long long *cyc; hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
     const int it = 2000;
     run<M16, IDLE>(out, cyc, it); run<M32, IDLE>(out, cyc, it);
-    run<IDLE, FMA>(out, cyc, it); run<IDLE, EXP>(out, cyc, it); run<IDLE, MIX>(out, cyc, it); run<IDLE, F64>(out, cyc, it); run<IDLE, LDSR>(out, cyc, it); run<IDLE, CVT>(out, cyc, it);
+    run<IDLE, FMA>(out, cyc, it); run<IDLE, PKFMA>(out, cyc, it); run<IDLE, EXP>(out, cyc, it); run<IDLE, RCP>(out, cyc, it); run<IDLE, MIX>(out, cyc, it); run<IDLE, F64>(out, cyc, it);
+    run<IDLE, LDSR>(out, cyc, it); run<IDLE, CVT>(out, cyc, it); run<IDLE, CVTRTZ>(out, cyc, it); run<IDLE, MED3>(out, cyc, it); run<IDLE, FMIX>(out, cyc, it); run<IDLE, MOV>(out, cyc, it); run<IDLE, PERM>(out, cyc, it);
+    run<FMA, FMA>(out, cyc, it); run<EXP, EXP>(out, cyc, it); run<CVT, CVT>(out, cyc, it);
     std::printf("-- the SIMD's other wavefront beside a matrix stream\n");
     run<M16, FMA>(out, cyc, it); run<M32, FMA>(out, cyc, it);
     run<M16, EXP>(out, cyc, it); run<M32, EXP>(out, cyc, it);
     run<M16, MIX>(out, cyc, it); run<M32, MIX>(out, cyc, it);
     run<M16, F64>(out, cyc, it); run<M32, F64>(out, cyc, it);
     run<M16, CVT>(out, cyc, it); run<M32, CVT>(out, cyc, it);
+    run<M16, PKFMA>(out, cyc, it); run<M32, PKFMA>(out, cyc, it);
+    run<M16, CVTRTZ>(out, cyc, it); run<M32, CVTRTZ>(out, cyc, it);
+    run<M16, MED3>(out, cyc, it); run<M32, MED3>(out, cyc, it);
+    run<M16, FMIX>(out, cyc, it); run<M32, FMIX>(out, cyc, it);
+    run<M16, RCP>(out, cyc, it); run<M32, RCP>(out, cyc, it);
+    run<M16, MOV>(out, cyc, it); run<M32, MOV>(out, cyc, it);
+    run<M16, PERM>(out, cyc, it); run<M32, PERM>(out, cyc, it);
     run<M16, LDSR>(out, cyc, it); run<M32, LDSR>(out, cyc, it);
     run<M16, M16>(out, cyc, it); run<M32, M32>(out, cyc, it);
     std::printf("-- independent vector instructions of the SAME wavefront between its matrix instructions\n");
