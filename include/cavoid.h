@@ -319,7 +319,9 @@ int cavoid_rollout_push(cavoid_rollout *r, const float *prev_obs, const int32_t 
  * boundary, no host, nothing between workgroups.  Results are bit-identical to calling those three entry points K times.
  *   obs_cur [W,N,1+D]: the observation to act on first; obs_next: a second buffer of the same shape -- step t reads one and
  *   writes the other, so after the call the current observation is in obs_cur when n_steps is even, in obs_next when odd.
- *   rewards / done / game_over / actions int32 [W,N] / values float [W,N]: per-step outputs, holding the LAST step's afterwards.
+ *   rewards / done / game_over / actions int32 [W,N] / values float [W,N]: per-step OUTPUTS, holding the LAST step's afterwards; they are
+ *   never read (which rows need an action at a launch's first step is derived from the world state's own flags, so a cavoid_reset -- masked
+ *   or not --, a cavoid_set_state or fresh buffers between two launches are all fine).
  *   The network runs only for the rows that still need an action -- what cavoid_rollout_active_rows lists: a learning agent (obs
  *   column 0) that was not done in the step that produced the observation, or whose world has just restarted; a finished agent
  *   waits for its world's last learning agent, a scripted agent acts by its own rule, the env ignores what either is given -- and

@@ -169,12 +169,15 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
                 // set, and the agent not done in the step that produced this observation unless its world has just restarted).  A finished
                 // agent waits for its world's last learning agent and a scripted agent acts by its own rule: the env ignores what either is
                 // given, the bookkeeping never reads it.  With the reference's re-flush quirk a done agent's value IS read: every row runs.
-                const uint8_t *done_prev = io.done + a0;
-                const uint8_t *over_prev = io.game_over + w0;
                 bool mine = lane < rows;
                 if (rc.reflush_done == 0) {
-                    if (t == 0) {                            // (uniform) the first step of a launch reads the flags the previous launch left in memory,
-                        if (mine) mine = obs_t[(a0 + lane) * ow] > 0.5f && (over_prev[lane / N] != 0 || done_prev[lane] == 0);
+                    if (t == 0) {
+                        // (uniform) the first step of a launch: the same predicate from the WORLD STATE -- a learning agent whose state carries no
+                        // terminal flag.  After a step that is what (game_over || !done) of that step says (a restarted world's agents are
+                        // fresh; elsewhere done == a terminal flag), and unlike the caller's done / game_over buffers the state cannot be stale:
+                        // a (masked) cavoid_reset, cavoid_set_state or freshly allocated output buffers between two launches change nothing
+                        // here -- done / game_over stay pure OUTPUTS of this entry point, as include/cavoid.h documents them
+                        if (mine) mine = obs_t[(a0 + lane) * ow] > 0.5f && (s.flags[a0 + lane] & CAVOID_F_DONE_MASK) == 0u;
                     } else {                                 // the later ones the mask the tile's own env step left in LDS
                         const unsigned long long m = (unsigned long long)(uint32_t)wave_max[12] | ((unsigned long long)(uint32_t)wave_max[13] << 32);
                         mine = (m >> lane) & 1ull;

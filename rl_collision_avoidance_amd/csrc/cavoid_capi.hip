@@ -350,7 +350,7 @@ static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_sta
 // (Measured and dropped, profiles/r05_e_lookahead.txt: the refill on a side stream beside the previous launch -- the cross-stream event wait costs
 // what the refill launch costs; the refill inside env_relay_kernel, by its loader role in idle time -- +5 % on the kernel -- or by extra
 // workgroups of the same launch -- they displace tile workgroups, which must all be resident.)
-int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
+int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s, hipEvent_t *timed_start) {
     if (!e || e->ahead_R <= 0) return CAVOID_OK;
     if (n_steps + 1 > e->ahead_R) return CAVOID_EUNSUPPORTED;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -368,7 +368,12 @@ int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s) {
     const dim3 grid((unsigned)((waves + 3) / 4), in_place ? 1u : (e->ahead_primed ? 4u : 32u)), block(256);
     const uint32_t *hi_in = e->ahead_hi[e->ahead_cur];
     uint32_t *hi_out = e->ahead_hi[in_place ? e->ahead_cur : (e->ahead_cur ^ 1)];
-#define CAVOID_AHEAD_CASE(NN) case NN: hipLaunchKernelGGL((ahead_fill_kernel<NN>), grid, block, 0, s, e->k, e->st.episode, hi_in, hi_out, e->pool, e->ahead_R); break;
+    hipEvent_t ev_fill = (timed_start && !capturing) ? *timed_start : nullptr;
+    if (ev_fill) *timed_start = nullptr;                     // (the refill kernel opens the timed interval)
+#define CAVOID_AHEAD_CASE(NN) case NN: \
+        if (ev_fill) hipExtLaunchKernelGGL((ahead_fill_kernel<NN>), grid, block, 0, s, ev_fill, nullptr, 0, e->k, e->st.episode, hi_in, hi_out, e->pool, e->ahead_R); \
+        else hipLaunchKernelGGL((ahead_fill_kernel<NN>), grid, block, 0, s, e->k, e->st.episode, hi_in, hi_out, e->pool, e->ahead_R); \
+        break;
     switch (e->cfg.max_agents) {
 #ifdef CAVOID_DEV_ONLY_N
         CAVOID_AHEAD_CASE(4) CAVOID_AHEAD_CASE(10)
@@ -545,7 +550,7 @@ static int launch_autoreset(cavoid_env *e, KIO io, const int32_t *actions, int64
     io.cont = cont;
     io.action_stride = action_stride;
     io.n_steps = n_steps;
-    if (int rc = cavoid_ahead_prepare(e, n_steps, s)) return rc;
+    if (int rc = cavoid_ahead_prepare(e, n_steps, s, &ev_start)) return rc;      // (a timed launch includes its look-ahead refill, when it needs one)
     const int rc = (n_steps > 1 || e->prefetch_single)           // the in-launch step loop lives in cavoid_multistep.hip
                        ? cavoid_launch_multistep(e, io, e->latency_mode != 0, s, ev_start, ev_stop)
                        : launch<MODE_STEP_AUTORESET>(e, io, s, ev_start, ev_stop);

@@ -119,7 +119,10 @@ static inline int launch_pipe(cavoid_env *e, const KIO &io, hipStream_t s, hipEv
 
 // scenario look-ahead: make sure every world's ring covers the restarts `n_steps` more steps can bring (a no-op without look-ahead);
 // CAVOID_EUNSUPPORTED when n_steps + 1 > R (cavoid_capi.hip)
-int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s);
+// timed_start (may be null): a start event the caller wants recorded where the launch's work begins -- when a refill is launched it is recorded
+// in front of THAT kernel and *timed_start is set to null (the stepping kernel behind it then records only its stop event), so that a timed
+// launch includes its refill (cavoid_step_autoreset_n_timed)
+int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s, hipEvent_t *timed_start = nullptr);
 void cavoid_ahead_consumed(cavoid_env *e, int32_t n_steps);     // call after the stepping launch that cavoid_ahead_prepare(n_steps) preceded
 // env_relay_kernel (cavoid_relay.hip): CAVOID_EUNSUPPORTED when the batch is too large for it or its LDS does not fit
 int cavoid_launch_relay(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);

@@ -69,12 +69,19 @@ def test_bench_two_rank_dry_run_on_one_device():
         assert f["agent_steps_per_s"] > 0 and f["bytes_per_link_per_step"] == (0 if mode == "none" else rec)
         assert (f["xgmi_frac"] is None) if mode == "none" else (abs(f["link_bound_us_per_step"] - rec / 153e3) < 1e-9 and f["xgmi_frac"] > 0)
     assert g["forms"]["all"]["agent_steps_per_s"] == line["value"]
+    # ... and the TOP LEVEL says which of them `value` is, what the wire allows and which curve the scaling target is judged on (round 6):
+    # an every-step hand-over of all observations is xGMI-bound below ONE GPU's shard-only rate, which must not read as a scaling failure
+    assert line["value_is"] == "all" and line["value_gather_all"] == line["value"]
+    assert line["value_shard_only"] == g["forms"]["none"]["agent_steps_per_s"] and line["value_gather_root"] == g["forms"]["root"]["agent_steps_per_s"]
+    assert abs(line["wire_bound_agent_steps_per_s"] - 2 * 2048 * 4 / (rec / 153e9)) < 1e-6 * line["wire_bound_agent_steps_per_s"]
+    assert line["scaling_judged_on"].startswith("value_shard_only") and "value_shard_only" in line["config"]["parallelism"]
+    assert line["extra"]["evidence"]["ran"] == []           # (N > 1: no rocprofv3 child passes, no all-cores baselines)
     # the headline restarts worlds with FRESH generator scenarios (the reference's reset semantics) from the look-ahead rings; the
     # pooled and the in-step sources, and GEN v2, are measured beside it
     assert line["config"]["scenarios"] == "lookahead" and "FRESH generator scenario" in line["config"]["workload"]
     src = line["extra"]["scenario_sources"]
     assert src["headline_source"] == "lookahead"
-    for label in ("gen_v1_ring_pool", "gen_v1_ring_instep", "gen_v2_box_lookahead", "gen_v2_box_instep"):
+    for label in ("gen_v1_ring_pool", "gen_v1_ring_instep", "gen_v2_box_lookahead", "gen_v2_box_instep", "training_mix_orca_agents_pool"):
         f = src[label]
         assert "error" not in f and f["value"] > 0 and f["restarts_in_timed_region"] > 0, f
     assert line["timing"]["restarts_in_timed_region"] > 0 and line["timing"]["ms_per_step_mean"] > 0
@@ -108,6 +115,8 @@ def test_bench_two_rank_dry_run_other_gather_forms(mode):
     assert "error" not in g, g
     assert g["value_is"] == mode and g["steps_per_launch"] == 8 and g["forms"][mode]["agent_steps_per_s"] == line["value"]
     assert ("rank 0" in line["config"]["parallelism"]) if mode == "root" else ("no data-path collective" in line["config"]["parallelism"])
+    assert line["value_is"] == ("root" if mode == "root" else "shard_only")
+    assert line["value_shard_only"] == g["forms"]["none"]["agent_steps_per_s"] and line["wire_bound_agent_steps_per_s"] > 0
 
 
 @pytest.mark.gpu
@@ -154,3 +163,29 @@ def test_bench_falls_back_to_the_pool_when_the_lookahead_cannot_be_had():
                  "--no-full-loop", "--no-configs3", "--no-pmc", "--no-fresh-scenarios"], 900)
     assert line["config"]["scenarios"] == "pool" and "pre-generated" in line["config"]["workload"]
     assert "failed" in line["extra"]["scenario_fallback"] and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_the_default_one_gpu_line_carries_its_evidence_and_the_mfma_rooflines():
+    """Round 6: the N = 1 line holds `roofline.traffic` (PMC), `cpu_baseline` and -- for BASELINE configs[4] -- MFMA rooflines of the policy
+    kernel and of the fused actor kernel that FOLLOW the kernels: issued flop = the matrix instructions the hardware counted
+    (SQ_INSTS_MFMA) x 16 384, and the static count bench.py derives from the kernel's loop structure agrees with that count exactly for
+    the stand-alone kernel (every row tile computed) and to within the live-row statistics for the actor kernel."""
+    line = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--reps", "3", "--cpu-seconds", "1", "--no-configs3", "--no-fresh-scenarios"], 900)
+    r = line["roofline"]
+    assert r["traffic"] and 0.5 < r["traffic_over_moved"] < 2.0 and r["one_step_launch"]["traffic"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+    ev = line["extra"]["evidence"]
+    assert "pmc_traffic" in ev["ran"] and "pmc_mfma" in ev["ran"] and ev["spent_s"] <= 75.0, ev
+    fl = line["extra"]["full_ga3c_loop"]
+    assert fl["configs4_is"].startswith("actors_only_actor_kernel") and "beyond_configs4_with_trainer" in fl
+    pk = fl["policy_kernel"]
+    assert pk["mfma_count_source"].startswith("rocprofv3") and pk["mfma_instructions_per_launch"] == pk["mfma_instructions_per_launch_static"] == 2048 * 1144
+    assert abs(pk["issued_TFLOPs"] - pk["mfma_instructions_per_launch"] * 16384 / pk["kernel_us"] * 1e-6) < 1e-6 * pk["issued_TFLOPs"]
+    assert abs(pk["frac"] - pk["issued_TFLOPs"] / 2500.0) < 1e-9 and 0.15 < pk["frac"] < 0.6
+    ar = fl["actors_only_actor_kernel"]["roofline"]
+    assert ar["kernel"].startswith("cavoid::actor_kernel<4") and ar["bound"] == "mfma" and 20.0 < ar["kernel_us_per_env_step"] < 60.0
+    assert 0.4 < ar["live_row_fraction"] < 0.9 and abs(sum(ar["tiles_by_row_tiles_computed"].values()) - 1.0) < 1e-9
+    assert abs(ar["mfma_instructions_per_env_step"] / ar["mfma_instructions_per_env_step_static"] - 1.0) < 0.08, ar
+    assert abs(ar["frac"] - ar["mfma_instructions_per_env_step"] * 16384 / ar["kernel_us_per_env_step"] * 1e-6 / 2500.0) < 1e-9
+    assert 0.2 < ar["frac"] < 0.6 and ar["useful_f32_grade_TFLOPs"] > 100.0

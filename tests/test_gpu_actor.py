@@ -303,3 +303,39 @@ def test_rows_that_need_no_action_get_none():
     _, v_ref = pol(obs0[..., 1:].reshape(700 * 4, -1))                   # the stand-alone kernel on every row
     assert torch.equal(vals[need], v_ref.view(700, 4)[need])
     assert (acts[need] >= 0).all() and (acts[need] < env.num_actions).all() and acts[need].float().std().item() > 0
+
+
+def test_a_masked_reset_between_two_fused_launches_needs_no_flag_fixup():
+    """done / game_over are OUTPUTS of cavoid_actor_run (include/cavoid.h): which rows need an action at a launch's first step is derived
+    from the world state, not from what the previous launch left in those buffers.  A masked cavoid_reset between two launches leaves them
+    stale for the reset worlds (done = 1 of an agent whose world now starts a new episode, game_over = 0): launch 2 must give those agents real
+    actions all the same -- identical to a twin whose buffers were patched by hand to what round 5's kernel wanted to see."""
+    W, N, seed = 1024, 4, 9
+    env_a, _, _, a = _make(W, N, seed, False)
+    env_b, _, _, b = _make(W, N, seed, False)
+    for r in (a, b):
+        r.run_fused(12)                                      # (even: the current observation is back in env.obs)
+    _same(a.obs, b.obs, "after launch 1")
+    # worlds that are NOT over but hold a finished learning agent: stale done = 1 after the reset
+    stale = (env_a.done.bool() & (a.obs[..., 0] > 0.5)).any(dim=1) & (env_a.game_over == 0)
+    assert int(stale.sum()) >= 10
+    mask = stale.to(torch.uint8)
+    for env in (env_a, env_b):
+        env.reset(mask)                                      # writes the observation of all worlds into env.obs == the rollout's current buffer
+    env_b.done[stale] = 0                                    # the twin: buffers as a step that restarted those worlds would have left them
+    env_b.game_over[stale] = 1
+    assert not torch.equal(env_a.done, env_b.done)
+    for r in (a, b):
+        r.run_fused(6)
+    _same(a.obs, b.obs, "obs after launch 2")
+    for x, y in zip(env_a.get_state(), env_b.get_state()):
+        _same(x, y, "state after launch 2")
+    for name in ("x", "val", "ret", "act_ring", "emit_t"):
+        _same(getattr(a, name), getattr(b, name), name)
+    # and the reset worlds' learning agents did act: their first step's ring entry is not the 'no action needed' filler everywhere
+    t0 = 12 % a.ring_len
+    acted = a.act_ring[t0].view(W, N)[stale]
+    assert int((acted != 0).sum()) > 0
+    for r in (a, b):
+        r.close()
+    env_a.close(); env_b.close()
