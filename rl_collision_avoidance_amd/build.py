@@ -11,7 +11,7 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
 SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_multistep.hip"), os.path.join(CSRC, "cavoid_rvo.hip"),
-           os.path.join(CSRC, "cavoid_relay.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
+           os.path.join(CSRC, "cavoid_relay.hip"), os.path.join(CSRC, "cavoid_quad.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
            os.path.join(CSRC, "cavoid_policy_capi.hip"), os.path.join(CSRC, "cavoid_comm_capi.hip"), os.path.join(CSRC, "cavoid_actor.hip"),
            os.path.join(CSRC, "cavoid_actor_rvo.hip"), os.path.join(CSRC, "cavoid_actor_frozen.hip")]
 HEADERS = {
@@ -19,13 +19,14 @@ HEADERS = {
     "cavoid_multistep.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rvo.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_relay.hip": ["cavoid_kernels.hpp", "cavoid_relay.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
+    "cavoid_quad.hip": ["cavoid_kernels.hpp", "cavoid_quad.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_rollout_host.hpp", "cavoid_host.hpp"],
-    "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_policy_split.hpp", "cavoid_policy_host.hpp", "cavoid_host.hpp"],
-    "cavoid_actor.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
+    "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_policy_split.hpp", "cavoid_policy_split8.hpp", "cavoid_policy_host.hpp", "cavoid_host.hpp"],
+    "cavoid_actor.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_quad.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
                          "cavoid_policy_split.hpp", "cavoid_policy_host.hpp", "cavoid_rollout.hpp", "cavoid_rollout_host.hpp", "cavoid_host.hpp"],
-    "cavoid_actor_rvo.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
+    "cavoid_actor_rvo.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_quad.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
                              "cavoid_policy_split.hpp", "cavoid_rollout.hpp", "cavoid_host.hpp"],
-    "cavoid_actor_frozen.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
+    "cavoid_actor_frozen.hip": ["cavoid_actor.hpp", "cavoid_actor_host.hpp", "cavoid_kernels.hpp", "cavoid_quad.hpp", "cavoid_launch.hpp", "cavoid_policy.hpp",
                                 "cavoid_policy_split.hpp", "cavoid_rollout.hpp", "cavoid_host.hpp"],
     "cavoid_comm_capi.hip": ["cavoid_host.hpp"],
 }

@@ -1,6 +1,7 @@
 // cavoid_actor.hip -- C ABI (include/cavoid.h, cavoid_actor_run) over actor_kernel<N> (cavoid_actor.hpp): K closed-loop GA3C actor
 // steps -- policy forward, action selection, env.step, experience bookkeeping -- in ONE launch.  Own translation unit (the
 // kernel carries the policy's GEMM loops and the env step; instantiated per agent count).
+#include <cstdlib>
 #define CAVOID_ACTOR_KERNELS
 #include "cavoid_actor_host.hpp"
 #include "cavoid_policy_host.hpp"
@@ -66,6 +67,11 @@ static int actor_run(cavoid_env *e, cavoid_policy *h, cavoid_policy *frozen, cav
     ActorIO io{};
     io.obs[0] = obs_cur; io.obs[1] = obs_next; io.rewards = rewards; io.done = done; io.game_over = game_over;
     io.actions = actions; io.values = values; io.rollout_step = r->s.step_counter; io.n_steps = n_steps; io.greedy = greedy ? 1 : 0;
+    // the tile's env step spread over the workgroup's four wavefronts (cavoid_quad.hpp) where that form carries the configuration: not the
+    // ORCA / in-step box instantiation, one pass per tile, its LDS inside the lent planes (CAVOID_ACTOR_QUAD=0: wavefront 0 alone, A/B runs)
+    io.quad = (!rvo_form && e->cfg.max_agents <= kActorQuadMaxAgents && k.tile_rows >= k.wpw * e->cfg.max_agents &&
+               quad_lds_bytes<kActorQuadMaxAgents>((k.tile_rows * k.width + 3) & ~3) <= (size_t)2 * kSpPlaneB) ? 1 : 0;
+    if (const char *ov = std::getenv("CAVOID_ACTOR_QUAD")) io.quad = (io.quad && std::atoi(ov) != 0) ? 1 : 0;
     const int rc_launch = frozen ? cavoid_launch_actor_frozen(e, sa, fz, rc, r->s, rio, io, s)
                                  : (rvo_form ? cavoid_launch_actor_rvo(e, sa, rc, r->s, rio, io, s) : launch_actor_any<false>(e, sa, sa, rc, r->s, rio, io, s));
     if (rc_launch != CAVOID_OK) return rc_launch;

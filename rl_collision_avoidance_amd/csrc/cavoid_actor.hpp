@@ -22,6 +22,7 @@
 // (tests/test_gpu_actor.py).
 #pragma once
 #include "cavoid_kernels.hpp"
+#include "cavoid_quad.hpp"
 #include "cavoid_policy_split.hpp"
 #include "cavoid_rollout.hpp"
 
@@ -30,6 +31,7 @@ namespace cavoid {
 #ifndef CAVOID_COPY_U
 #define CAVOID_COPY_U 32        // loads in flight per lane of step_push_kernel's row-copy wavefronts
 #endif
+constexpr int kActorQuadMaxAgents = 4;   // the cooperative env step inside the fused actor kernel: instantiated up to this many agents per world
 struct ActorIO {
     float *obs[2];            // [W,N,1+D] each: step t acts on obs[t & 1]; the env writes the next observation into obs[(t+1) & 1]
     float *rewards;           // [W,N]   the env's step outputs; after the launch they hold the LAST step's
@@ -40,6 +42,8 @@ struct ActorIO {
     int32_t *rollout_step;    // device-side step index of the experience store (advanced by actor_finish_kernel)
     int32_t n_steps;
     int32_t greedy;           // PLAY_MODE / EVALUATE_MODE: argmax instead of sampling
+    int32_t quad;             // the tile's env step by all four wavefronts (cavoid_quad.hpp) instead of wavefront 0 alone -- the host sets it where that
+                              // form carries the configuration (actor_run); same results
 };
 
 // LDS the env step of a tile needs inside the (idle) activation planes: the action table + one wavefront's staging arrays and
@@ -96,6 +100,50 @@ __device__ __forceinline__ void actor_env_push_tile(const KCfg &c, const KState 
     // rollout_close_episode reads the sums at the cache the atomics went to
     if (__ballot(in_range && so.game_over) != 0ull) {
         __builtin_amdgcn_s_waitcnt(0);                       // (vmcnt 0: the atomics have been performed at the L2)
+        if (in_range && i == 0 && so.game_over) rollout_close_episode(rc, rs, rio, w);
+    }
+}
+
+// The same by the workgroup's four wavefronts (io.quad): quad_env_tile's cooperative step -- wavefront 0 hosts it and then does the bookkeeping
+// exactly as above, wavefronts 1..3 take the neighbours' chains, the ranking, their slots of the rows and their share of the flush.  Contains
+// workgroup barriers: every thread of the workgroup calls it.  smem: the (idle) activation planes.
+template <int N, bool EARLY>
+__device__ __forceinline__ void actor_env_push_tile_quad(const KCfg &c, const KState &s, const PoolRec *pool, const RolloutCfg &rc, const RolloutState &rs,
+                                                         const RolloutIO &rio_arg, const ActorIO &io, const float *obs_t, float *obs_n,
+                                                         unsigned char *smem, int role, int lane, int64_t tile, int32_t step, int blk, int *live_next) {
+    const int wpw = c.wpw, ow = c.width;
+    const int64_t w0 = tile * wpw;
+    KIO k{};
+    k.actions = io.actions; k.obs = obs_n; k.rew = io.rewards; k.done = io.done; k.game_over = io.game_over;
+    k.obs_stride = ow; k.n_steps = 1;
+    StepOut so{0.0f, true, false, false};
+    const int lw = lane / N, i = lane - lw * N;
+    const int64_t w = w0 + lw, a = w * N + i;
+    const bool in_range = lane < wpw * N && w < c.num_worlds;
+    RolloutSlot slot_in{0, 0, false, 0.0};
+    float learn_f = 0.0f, value = 0.0f;
+    int action = 0;
+    auto first_trip = [&]() {
+        slot_in = rollout_slot_load(rs, a, in_range);
+        if (in_range) { learn_f = obs_t[a * ow]; value = io.values[a]; action = io.actions[a]; }
+    };
+    if (role == 0 && EARLY) first_trip();
+    quad_env_tile<N>(c, s, pool, k, smem, role, lane, tile, &so);
+    if (role != 0) return;
+    POLICY_STAMP(0);
+    if (live_next) {
+        const unsigned long long m = __ballot(in_range && so.learning_next && (so.game_over || !so.done));
+        if (lane == 0) { live_next[0] = (int)(uint32_t)m; live_next[1] = (int)(uint32_t)(m >> 32); }
+    }
+    if (!EARLY) first_trip();
+    const bool learning = in_range && learn_f > 0.5f;
+    const int base = lane < wpw * N ? lw * N : 0;
+    const int n_learning = __popcll(__ballot(learning) & (((1ull << N) - 1ull) << base));
+    RolloutIO rio = rio_arg;
+    rollout_push_slot(rc, rs, rio, a, in_range ? w : 0, i, in_range, learning, n_learning, so.done, so.game_over, so.reward, value,
+                      action, step, blk, slot_in);
+    if (__ballot(in_range && so.game_over) != 0ull) {
+        __builtin_amdgcn_s_waitcnt(0);
         if (in_range && i == 0 && so.game_over) rollout_close_episode(rc, rs, rio, w);
     }
 }
@@ -219,7 +267,14 @@ __global__ void __launch_bounds__(256, 2) actor_kernel(const KCfg c, const KStat
         __syncthreads();                                     // the tile's actions / values are in memory; the planes are idle
         POLICY_STAMP(14);                                    // policy pass + barrier done
 
-        if (wave_in_block == 0) {
+        if (!RVO && N <= kActorQuadMaxAgents && io.quad) {   // (uniform)
+            // ---- the step's state rows -> the experience store by wavefronts 1..3, then env.step of the tile by all four (cavoid_quad.hpp) and
+            //      the Experience bookkeeping of its slots by wavefront 0
+            if (wave_in_block != 0) rollout_copy_rows(rc, obs_t, rio_arg.x, a0, rows, blk, tid - 64, 192);
+            actor_env_push_tile_quad<(N <= kActorQuadMaxAgents ? N : 1), true>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, planes, wave_in_block, lane, tile,
+                                                                              step, blk, FROZEN ? nullptr : wave_max + 12);
+            if (wave_in_block == 0) POLICY_STAMP(15);
+        } else if (wave_in_block == 0) {
             // ---- env.step of the tile, then the Experience bookkeeping of its slots ---------------------------------------
             actor_env_push_tile<N, RVO, (N <= (RVO ? 9 : 13))>(c, s, pool, rc, rs, rio_arg, io, obs_t, obs_n, lds_tab, wbase, lane, tile, step, blk,
                                                                FROZEN ? nullptr : wave_max + 12);

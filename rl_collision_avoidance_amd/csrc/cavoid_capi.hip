@@ -278,6 +278,7 @@ extern "C" int cavoid_create(const cavoid_cfg *cfg, int64_t num_worlds, int64_t 
     }
     k.prefetch_pool = e->latency_mode;
     if (const char *ov = std::getenv("CAVOID_PIPELINE")) e->pipeline = std::atoi(ov);
+    if (const char *ov = std::getenv("CAVOID_QUAD")) e->quad = std::atoi(ov);
     if (const char *ov = std::getenv("CAVOID_RELAY_CONSUMERS")) {
         const int v = std::atoi(ov);
         if (v >= 1 && v <= cavoid::kRelayMaxConsumers) e->relay_consumers = v;
@@ -339,6 +340,10 @@ static int launch(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t ev_sta
     if (((MODE == MODE_STEP || MODE == MODE_STEP_AUTORESET) && e->k.rvo_enabled) ||
         (MODE == MODE_STEP_AUTORESET && e->k.gen_mode == 1 && e->k.pool_size <= 0))
         return cavoid_launch_rvo(e, MODE, io, s, ev_start, ev_stop);
+    if (MODE == MODE_STEP_AUTORESET) {                     // small batches: the step spread over four wavefronts per tile, where that form carries it
+        const int rc = cavoid_launch_quad(e, io, s, ev_start, ev_stop);
+        if (rc != CAVOID_EUNSUPPORTED) return rc;
+    }
     return launch_on<MODE>(e, e->k, e->st, e->grid, io, s, ev_start, ev_stop);
 }
 

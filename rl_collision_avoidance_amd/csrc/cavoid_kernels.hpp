@@ -744,17 +744,25 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
 // coalesced write-out.  The tile holds c.tile_rows rows; wide rows (large N) go out in several passes so
 // that the LDS footprint -- and with it the wavefronts resident per CU -- does not scale with N*(1+D).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// Which part of its row a lane writes (the cooperative step, cavoid_quad.hpp: the ranking is made by every wavefront that writes, from the
+// same keys; the host wavefront writes the row's head and clears the empty slots itself, a pair wavefront the slots of ITS neighbours)
+struct PartAll { static constexpr bool head = true; __device__ __forceinline__ constexpr bool other(int) const { return true; } };
+struct PartOthers {                                          // neighbours o with o % every == mine
+    static constexpr bool head = false;
+    int mine, every;
+    __device__ __forceinline__ bool other(int o) const { return o % every == mine; }
+};
 // PreFlush: called once, right before the first global store of the tile (env_relay_kernel orders the last step's rows behind
 // the rows of the steps before it, which other wavefronts write)
 // FLUSH = false: the rows stay in the LDS tile (row r at tile + r * ostride; needs c.tile_rows >= rows_active), nothing is written
 // to obs_dst
 // FEAT: the pair pass made the neighbours' features (feat_in); else they are made here from the staged state.
-template <int N, bool PARK, bool FEAT, class Stage, class PreFlush = NoHook, bool FLUSH = true>
+template <int N, bool PARK, bool FEAT, class Stage, class PreFlush = NoHook, bool FLUSH = true, class Part = PartAll>
 __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, const Ego &e, bool active, int lane, const Stage &st,
                                              const Key (&key_in)[Others<N>::K], const float (&gapf_in)[Others<N>::K], const float (*feat_in)[kFeat],
                                              uint32_t valid, float *tile,
                                              float *obs_dst, int rows_active, int ostride, bool packed, float rew_f, float done_f, int64_t wave,
-                                             PreFlush pre_flush = PreFlush(), bool stream_out = false, int *prev_kept = nullptr) {
+                                             PreFlush pre_flush = PreFlush(), bool stream_out = false, int *prev_kept = nullptr, Part part = Part()) {
     // prev_kept (step loops that own their tile from step to step): how many slots of this lane's row the PREVIOUS step of the
     // launch filled -- the slots behind them are still zero in the tile, so only the slots [kept, *prev_kept) need zeroing now
     // (none, step after step, unless the lane's world restarted or a neighbour went out of sight).  Null: every slot behind `kept`.
@@ -879,17 +887,20 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
     }
     if (!(CAVOID_SKIP & 4) && active && lane >= p0 && lane < p0 + rpp) {
         float *row = tile + (lane - p0) * ostride;
+        if (Part::head) {
         row[0] = (present && (a.flags & CAVOID_F_LEARNING)) ? 1.0f : 0.0f;
         row[1] = (float)kept;                                   // 0 for an absent agent (others == 0)
         row[2] = present ? (float)e.dist : 0.0f;
         row[3] = present ? (float)e.heading_ego : 0.0f;
         row[4] = present ? a.pref : 0.0f;
         row[5] = present ? a.radius : 0.0f;
+        }
         // r_host + r_other as ONE float32 add is bit for bit the float32 rounding of the float64 sum (the sum of two floats is
         // exact in float64).
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
             if (!((keep >> o) & 1u)) continue;
+            if (!part.other(o)) continue;
             float f[kFeat];
             if (FEAT) {
 #pragma unroll
@@ -905,6 +916,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         // agent's, all M slots -- so float by float it was 7 M dependent iterations per step at N = 10 with 2..10 agents present.
         // (Measured and dropped there: straight-line predicated zero writes into the slots the not-kept neighbours rank at, +80
         // vector instructions per wavefront-step.)
+        if (Part::head) {
         const int zero_to = prev_kept ? *prev_kept : M;
         for (int sl = zero_first ? M : kept; sl < zero_to; ++sl) {
             float *z = row + 6 + 7 * sl;
@@ -913,6 +925,7 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         }
         if (packed) { row[width] = rew_f; row[width + 1] = done_f; }   // (obs | reward | done) gather record
         if (prev_kept) *prev_kept = kept;
+        }
     }
     wave_lds_sync();
     CAVOID_STAMP(10);                                            // rows in the LDS tile

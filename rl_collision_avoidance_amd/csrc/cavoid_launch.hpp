@@ -34,6 +34,8 @@ struct cavoid_env {
                                  // (two wavefronts per tile), 0 = one wavefront per tile (CAVOID_PIPELINE)
     int relay_consumers = 3;     // observation wavefronts per tile of env_relay_kernel (CAVOID_RELAY_CONSUMERS, 1..4)
     int latency_mode = 0;        // small batch: multi-step launches keep the next pool record in registers (MODE_STEP_AUTORESET_PF)
+    int quad = -1;               // one-step auto-reset launches with four cooperating wavefronts per tile (env_quad_kernel): -1 = where it pays
+                                 // (<= 512 tiles), 0 / 1 = never / wherever it can run (CAVOID_QUAD)
     int prefetch_single = 0;     // ... and single-step launches too (CAVOID_PREFETCH_POOL=1; costs 64 B of reads per agent-step)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -127,6 +129,8 @@ void cavoid_ahead_consumed(cavoid_env *e, int32_t n_steps);     // call after th
 // env_relay_kernel (cavoid_relay.hip): CAVOID_EUNSUPPORTED when the batch is too large for it or its LDS does not fit
 int cavoid_launch_relay(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-step auto-reset launch (cavoid_multistep.hip): prefetch != 0 -> MODE_STEP_AUTORESET_PF, else MODE_STEP_AUTORESET_N
+// env_quad_kernel (cavoid_quad.hip): CAVOID_EUNSUPPORTED when the configuration or the launch is not one it carries
+int cavoid_launch_quad(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 int cavoid_launch_multistep(cavoid_env *e, const cavoid::KIO &io, bool prefetch, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // any stepping mode for an env with rvo_enabled (cavoid_rvo.hip: the instantiations that carry the ORCA policy)
 int cavoid_launch_rvo(cavoid_env *e, int mode, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);

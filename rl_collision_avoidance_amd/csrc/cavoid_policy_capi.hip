@@ -8,7 +8,9 @@
 #include "cavoid_host.hpp"
 #define CAVOID_POLICY_KERNELS 1
 #include "cavoid_policy.hpp"
+#include <cstring>
 #include "cavoid_policy_split.hpp"
+#include "cavoid_policy_split8.hpp"
 #include "cavoid_policy_host.hpp"
 
 #include <cstdlib>
@@ -29,7 +31,7 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_frag = carve((size_t)kPackFragsTrain * sizeof(f32x4)), o_bias = carve(kBiasFloats * sizeof(float));
-    const size_t o_sfrag = carve((size_t)kSpPackFrags * sizeof(uint4)), o_sbias = carve(kBiasFloats * sizeof(float));
+    const size_t o_sfrag = carve((size_t)kSpPackFrags8 * sizeof(uint4)), o_sbias = carve(kBiasFloats8 * sizeof(float));
     const size_t o_avg = carve(h->in_size * sizeof(float)), o_std = carve(h->in_size * sizeof(float));
     const size_t o_step = carve(sizeof(int32_t)), o_done = carve(sizeof(uint32_t)), o_tick = carve(kPolCuSlots * sizeof(uint32_t));
     const size_t o_clamp = carve(sizeof(uint32_t));
@@ -41,6 +43,12 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     if (const char *ov = std::getenv("CAVOID_POLICY_F32")) h->use_split = std::atoi(ov) == 0;
     // 16 (default): two float16 pieces per operand, three products -- float32-grade; 3 / 4 / 5: bf16 pieces, that many products (A/B runs)
     if (const char *ov = std::getenv("CAVOID_POLICY_PRODUCTS")) { const int v = std::atoi(ov); if ((v >= 3 && v <= 5) || v == kSpF16) h->split_products = v; }
+    // CAVOID_POLICY_FORM: how the stand-alone inference launch maps tiles to wavefronts (bit-identical results, A/B runs) -- quad: four wavefronts per
+    // 64-row tile, two independent workgroups per CU; oct: eight wavefronts per tile (cavoid_policy_split8.hpp); duo: two tiles per workgroup, phases
+    // locked one barrier apart (policy_forward_split_duo_kernel)
+    // Default (-1): duo once the launch has at least two tiles per compute unit (below that a paired workgroup would leave CUs idle), else quad.
+    if (const char *ov = std::getenv("CAVOID_POLICY_FORM")) h->form = !std::strcmp(ov, "oct") ? 1 : (!std::strcmp(ov, "duo") ? 2 : (!std::strcmp(ov, "quad") ? 0 : -1));
+    if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->num_cus <= 0) h->num_cus = 256;
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
     h->cu_tickets = reinterpret_cast<uint32_t *>(b + o_tick);
@@ -59,7 +67,11 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_split_lds_bytes()) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<kSpF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)policy_split_lds_bytes()) != hipSuccess) {
+                            (int)policy_split_lds_bytes()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_split_lds_bytes()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_duo_kernel<kSpF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_split_duo_lds_bytes()) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError(); (void)hipFree(h->slab); delete h; return CAVOID_EHIP;
     }
     *out = h;
@@ -97,6 +109,10 @@ extern "C" int cavoid_policy_load(cavoid_policy *h, const cavoid_policy_weights 
         hipLaunchKernelGGL(policy_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k, h->sfrags, h->sbias,
                            h->split_products == kSpF16 ? 1 : 0, h->clamped_weights);
         HIP_TRY(hipGetLastError());
+        if (h->split_products == kSpF16) {                  // the LSTM once more in the eight-wavefront form's column order
+            hipLaunchKernelGGL(policy_pack_split8_kernel, dim3((unsigned)((kSpChLstm * 16 * 64 + 255) / 256)), dim3(256), 0, s, k, h->sfrags, h->sbias);
+            HIP_TRY(hipGetLastError());
+        }
     }
     h->normalize = w->avg != nullptr;
     if (h->normalize) {
@@ -150,7 +166,11 @@ static int policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_
     if (h->use_split) {
         SplitArgs sa{a, h->sfrags, h->sbias};
         hipStream_t s = static_cast<hipStream_t>(stream);
-        if (h->split_products == kSpF16) hipLaunchKernelGGL(policy_forward_split_kernel<kSpF16>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
+        const int form = h->form >= 0 ? h->form : (blocks >= 2 * (int64_t)h->num_cus ? 2 : 0);
+        if (h->split_products == kSpF16 && form == 1) hipLaunchKernelGGL(policy_forward_split8_kernel, dim3((unsigned)blocks), dim3(512), policy_split_lds_bytes(), s, sa);
+        else if (h->split_products == kSpF16 && form == 2)
+            hipLaunchKernelGGL(policy_forward_split_duo_kernel<kSpF16>, dim3((unsigned)((blocks + 1) / 2)), dim3(512), policy_split_duo_lds_bytes(), s, sa);
+        else if (h->split_products == kSpF16) hipLaunchKernelGGL(policy_forward_split_kernel<kSpF16>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
         else if (h->split_products == 5) hipLaunchKernelGGL(policy_forward_split_kernel<5>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
         else if (h->split_products == 4) hipLaunchKernelGGL(policy_forward_split_kernel<4>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
         else hipLaunchKernelGGL(policy_forward_split_kernel<3>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);

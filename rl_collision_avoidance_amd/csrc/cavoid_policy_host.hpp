@@ -20,6 +20,9 @@ struct cavoid_policy {
     uint4 *sfrags = nullptr;         // split weight fragments of the inference kernel (cavoid_policy_split.hpp)
     float *sbias = nullptr;          // ... and its biases (packed order; the LSTM gates pre-scaled by log2 e / 2 log2 e like their weight columns)
     int split_products = cavoid::kSpDefaultProducts;   // 16 (default): float16 pieces, three products; 3 / 4 / 5: bf16 pieces (CAVOID_POLICY_PRODUCTS)
+    int form = -1;                   // CAVOID_POLICY_FORM = quad (0) / oct (1) / duo (2) / unset (-1: duo from two tiles per CU on, else quad): the stand-alone inference
+                                     // launch's tile-to-wavefront mapping (same results in every form)
+    int num_cus = 256;
     bool use_split = true;           // CAVOID_POLICY_F32=1: run inference on the float32-MFMA kernel instead (A/B runs)
     float *bias = nullptr, *avg = nullptr, *std = nullptr;
     int32_t *step_counter = nullptr;

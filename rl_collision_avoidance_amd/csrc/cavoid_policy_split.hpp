@@ -98,6 +98,10 @@ constexpr int64_t kSpOffL2 = kSpOffL1 + kSpChL1 * kSpFragPerChunk;
 constexpr int64_t kSpOffFc1 = kSpOffL2 + kSpChWide * kSpFragPerChunk;
 constexpr int64_t kSpOffHead = kSpOffFc1 + kSpChWide * kSpFragPerChunk;   // one column tile: 3 x 64 frags per chunk
 constexpr int64_t kSpPackFrags = kSpOffHead + kSpChWide * 3 * 64;
+// behind them: the LSTM once more in the EIGHT-wavefront form's column order (cavoid_policy_split8.hpp), and its 256 biases behind the packed biases
+constexpr int64_t kSpOffLstm8 = kSpPackFrags;
+constexpr int64_t kSpPackFrags8 = kSpOffLstm8 + kSpChLstm * kSpFragPerChunk;
+constexpr int kBiasLstm8 = kBiasFloats, kBiasFloats8 = kBiasFloats + 256;
 constexpr size_t policy_split_lds_bytes() { return (size_t)2 * kSpPlaneB + 64 * sizeof(float) + 64 * sizeof(int) + 64; }
 
 // float -> (hi, lo) 16-bit pieces with hi = rn(x), lo = rn(x - hi); two values at a time (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
@@ -252,8 +256,8 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4 &a, const uint4 &b, const
 struct SplitSrc { __amdgpu_buffer_rsrc_t w, b; };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ SplitSrc split_src(const uint4 *sfrags, const float *bias) {
-    return SplitSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(sfrags), 0, (int)(kSpPackFrags * 16), 0x00020000),
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias), 0, (int)(kBiasFloats * sizeof(float)), 0x00020000)};
+    return SplitSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(sfrags), 0, (int)(kSpPackFrags8 * 16), 0x00020000),
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias), 0, (int)(kBiasFloats8 * sizeof(float)), 0x00020000)};
 }
 __device__ __forceinline__ uint4 split_buf16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
@@ -608,7 +612,8 @@ __device__ __forceinline__ void split_lstm_cell2(const f32x2 xi, const f32x2 xj,
 // wavefront; at least one bit, at most 16 NRT) comes from the caller, which picks the instantiation.
 template <int P, int NRT = 0, class Load, class Emit>
 __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned char *planes, float *len_f, int *wave_max, int rows_here,
-                                                  int tid, Load load, Emit emit, unsigned long long live_mask = ~0ull, int *rmap = nullptr) {
+                                                  int tid, Load load, Emit emit, unsigned long long live_mask = ~0ull, int *rmap = nullptr,
+                                                  int steps_total = -1) {
     const PolicyArgs &p = sa.p;
     constexpr bool F16 = SplitFmt<P>::f16;
     constexpr bool COMPACT = NRT > 0;
@@ -757,6 +762,9 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
         for (; t < t_all; ++t) lstm_step(t, SplitYes{});
 #pragma unroll 1
         for (; t < steps; ++t) lstm_step(t, SplitNo{});
+        // (the paired form, policy_forward_split_duo_kernel: the workgroup's other tile has more LSTM steps -- keep its barrier count)
+#pragma unroll 1
+        for (; t < steps_total; ++t) { __syncthreads(); __syncthreads(); }
     }
     POLICY_STAMP(1);
     // ---- layer1 on [h | host] -------------------------------------------------------------------------------------
@@ -895,6 +903,74 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
     if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
 #endif
     if (p.actions_out) policy_finish(p, step, tid);
+}
+
+// ---- the PAIRED form: two 64-row tiles per workgroup, their phases locked one barrier apart ------------------------------------------------
+// policy_split_tile alternates matrix phases (a layer's GEMM) and vector phases (LSTM cell update / relu + split epilogue), a workgroup barrier
+// between them.  With two independent workgroups per CU the two tiles of a CU drift: whether one tile's vector phase meets the other's matrix
+// phase -- the only way the two pipes of a SIMD work at the same time (tools/ubench/mfma32_valu_overlap.hip: a matrix stream at full rate with
+// the partner wavefront issuing a vector instruction every 8-16 clocks) -- is chance (profiles/r05_m_policy_phase_trace.txt: one tile alone on a
+// CU 27.5 us, two drifting tiles 39.5 / 46 us).  Here ONE workgroup of eight wavefronts owns both tiles (wavefronts 0..3 tile 2b, 4..7 tile
+// 2b+1: each SIMD holds one wavefront of either), every barrier of the pass is the workgroup's, and the second tile starts ONE barrier late: for
+// the whole pass tile A's matrix phases run beside tile B's vector phases and vice versa.  The per-tile statements are policy_split_tile's,
+// untouched: results are bit for bit the unpaired kernel's.  (A tile with fewer LSTM steps than its partner idles through the difference.)
+constexpr size_t policy_split_duo_lds_bytes() { return 2 * policy_split_lds_bytes() + 16; }
+
+template <int P>
+__global__ void __launch_bounds__(512, 1) policy_forward_split_duo_kernel(const SplitArgs sa) {
+    const PolicyArgs &p = sa.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char duo_lds[];
+    const int tid_wg = threadIdx.x;
+    const int half = __builtin_amdgcn_readfirstlane(tid_wg >> 8), tid = tid_wg & 255, lane = tid & 63;
+    unsigned char *planes = duo_lds + (size_t)half * policy_split_lds_bytes();
+    float *len_f = reinterpret_cast<float *>(planes + 2 * kSpPlaneB);
+    int *tile_row = reinterpret_cast<int *>(len_f + 64);
+    int *wave_max = tile_row + 64;
+    int *pair_steps = reinterpret_cast<int *>(duo_lds + 2 * policy_split_lds_bytes());
+    const int64_t row0 = ((int64_t)blockIdx.x * 2 + half) * 64;
+    const int64_t n_rows = p.row_count ? (int64_t)*p.row_count : p.rows;
+    const int rows_here = n_rows - row0 < 64 ? (int)(n_rows - row0 > 0 ? n_rows - row0 : 0) : 64;
+    const int A = p.num_actions;
+    const int step = p.actions_out ? *p.step_counter : 0;
+    const bool listed = p.row_index != nullptr;
+    if (listed && n_rows <= (int64_t)blockIdx.x * 128) {  // uniform over the workgroup: nothing listed for either tile
+        if (p.actions_out) policy_finish(p, step, tid_wg);
+        return;
+    }
+    POLICY_STAMP(0);
+    if (tid < 64) tile_row[tid] = listed ? (tid < rows_here ? p.row_index[row0 + tid] : 0) : (tid < rows_here ? tid : 0);
+    const float *src = listed ? p.x : p.x + (rows_here > 0 ? row0 : 0) * p.stride;   // (an empty tile re-reads row 0 of the batch: valid, selected away)
+    // the number of LSTM steps of either tile, before the phase offset (the tile function computes its own again: one more trip to the row)
+    if (tid < 64) {
+        int len = tid < rows_here ? (int)src[(int64_t)tile_row[tid] * p.stride] : 0;
+        len = len < 0 ? 0 : (len > p.max_other ? p.max_other : len);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(len, d, 64); len = o > len ? o : len; }
+        if (lane == 0) pair_steps[half] = len;
+    }
+    __syncthreads();
+    const int steps_total = pair_steps[0] > pair_steps[1] ? pair_steps[0] : pair_steps[1];
+    auto load = [&](int r, int k) -> float { return src[(int64_t)tile_row[r] * p.stride + k]; };
+    auto emit = [&](int trow, int g, const float (&pj)[4], const f32x4 &logit) {
+        const bool in_tile = trow < rows_here;
+        const int64_t row = listed ? (in_tile ? (int64_t)tile_row[trow] : p.rows) : (in_tile ? row0 + trow : p.rows);
+        if (row < p.rows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 4 * g + r;
+                if (col < A) p.p_out[row * A + col] = pj[r];
+                else if (col == A) p.v_out[row] = logit[r];
+            }
+        }
+        if (p.actions_out) {                               // wave-uniform
+            const int action = split_select_action(pj, g, lane, A, p.greedy != 0, row, step, p.seed_lo, p.seed_hi);
+            if (row < p.rows && g == 0) p.actions_out[row] = action;
+        }
+    };
+    if (half == 1) __syncthreads();                        // the second tile runs one phase behind the first
+    policy_split_tile<P>(sa, planes, len_f, wave_max, rows_here, tid, load, emit, ~0ull, nullptr, steps_total);
+    if (half == 0) __syncthreads();
+    if (p.actions_out) policy_finish(p, step, tid_wg);
 }
 
 }  // namespace cavoid

@@ -310,15 +310,15 @@ def test_a_masked_reset_between_two_fused_launches_needs_no_flag_fixup():
     from the world state, not from what the previous launch left in those buffers.  A masked cavoid_reset between two launches leaves them
     stale for the reset worlds (done = 1 of an agent whose world now starts a new episode, game_over = 0): launch 2 must give those agents real
     actions all the same -- identical to a twin whose buffers were patched by hand to what round 5's kernel wanted to see."""
-    W, N, seed = 1024, 4, 9
+    W, N, seed, K1 = 2048, 4, 9, 40                          # (K1 even: the current observation is back in env.obs)
     env_a, _, _, a = _make(W, N, seed, False)
     env_b, _, _, b = _make(W, N, seed, False)
     for r in (a, b):
-        r.run_fused(12)                                      # (even: the current observation is back in env.obs)
+        r.run_fused(K1)
     _same(a.obs, b.obs, "after launch 1")
     # worlds that are NOT over but hold a finished learning agent: stale done = 1 after the reset
     stale = (env_a.done.bool() & (a.obs[..., 0] > 0.5)).any(dim=1) & (env_a.game_over == 0)
-    assert int(stale.sum()) >= 10
+    assert int(stale.sum()) >= 5
     mask = stale.to(torch.uint8)
     for env in (env_a, env_b):
         env.reset(mask)                                      # writes the observation of all worlds into env.obs == the rollout's current buffer
@@ -333,7 +333,7 @@ def test_a_masked_reset_between_two_fused_launches_needs_no_flag_fixup():
     for name in ("x", "val", "ret", "act_ring", "emit_t"):
         _same(getattr(a, name), getattr(b, name), name)
     # and the reset worlds' learning agents did act: their first step's ring entry is not the 'no action needed' filler everywhere
-    t0 = 12 % a.ring_len
+    t0 = K1 % a.ring_len
     acted = a.act_ring[t0].view(W, N)[stale]
     assert int((acted != 0).sum()) > 0
     for r in (a, b):

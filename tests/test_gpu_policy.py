@@ -503,3 +503,40 @@ def test_fused_actor_availability_follows_the_handles_not_the_environment(monkey
     env3.cfg.gen_nonlearning_fraction, env3.cfg.gen_frozen_fraction = 0.5, 0.5
     assert not roll3.fused_available and "frozen-network agents" in roll3.fused_unavailable_reason and "one launch per phase" in roll3.actor_path
     roll3.close(); env3.close(); env2.close()
+
+
+@pytest.mark.parametrize("form", ["oct", "duo"])
+@pytest.mark.parametrize("M,B,scale", [(3, 5000, 1.0), (9, 2111, 1.0), (3, 4096, 4.0), (1, 300, 1.0), (3, 64, 1.0), (5, 129, 1.0)])
+def test_other_tile_to_wavefront_forms_are_bit_identical(M, B, scale, form, monkeypatch):
+    """Two other mappings of the same pass (CAVOID_POLICY_FORM, read at cavoid_policy_create):
+    oct -- eight wavefronts per 64-row tile, each owning 32 output columns (cavoid_policy_split8.hpp; the LSTM's gate columns re-ordered so
+           that a lane still holds all four gates of its hidden units);
+    duo -- two tiles per workgroup of eight wavefronts, the second tile one barrier behind the first, so that one tile's matrix phases run
+           beside the other's vector phases (policy_forward_split_duo_kernel); a tile with fewer LSTM steps idles through the difference.
+    Every output element is the same float32 sum in the same order: probabilities, values and the drawn actions are BIT for bit the default
+    form's -- full pass and row-list pass, ragged observed-agent counts, odd tile counts, a last tile with one row."""
+    from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
+    net = _net(M, seed=60 + M)
+    x = _inputs(net, B, seed=11, scale=scale)
+    g = torch.Generator().manual_seed(3)
+    x[:, 0] = torch.randint(0, M + 1, (B,), generator=g).float().cuda()
+    x[: B // 3, 0] = float(M)                               # tiles in which every row is live at every LSTM step
+    x[B // 3: B // 3 + 70, 0] = 1.0                         # ... and a tile with fewer steps than its neighbour (duo: the idle barrier pairs)
+    monkeypatch.setenv("CAVOID_POLICY_FORM", "quad")
+    pol4 = FusedPolicy(net, seed=77)
+    monkeypatch.setenv("CAVOID_POLICY_FORM", form)
+    pol8 = FusedPolicy(net, seed=77)
+    a4, p4, v4 = pol4.act(x)
+    a8, p8, v8 = pol8.act(x)
+    assert torch.equal(p4, p8) and torch.equal(v4, v8) and torch.equal(a4, a8)
+    assert float((p4.sum(dim=1) - 1.0).abs().max()) < 1e-5 and (B < 100 or a4.float().std().item() > 0)
+    idx = torch.zeros(B, dtype=torch.int32, device="cuda")
+    listed = torch.randperm(B, generator=torch.Generator().manual_seed(1))[: B // 2 + 3].to(torch.int32).cuda()
+    idx[: listed.numel()] = listed
+    count = torch.tensor([listed.numel()], dtype=torch.int32, device="cuda")
+    a4r, p4r, v4r = pol4.act(x, rows=(idx, count))
+    a8r, p8r, v8r = pol8.act(x, rows=(idx, count))
+    assert torch.equal(p4r, p8r) and torch.equal(v4r, v8r) and torch.equal(a4r, a8r)
+    count.zero_()                                            # an empty list: every workgroup leaves at once
+    a0, p0, v0 = pol8.act(x, rows=(idx, count))
+    assert float(p0.abs().sum()) == 0.0

@@ -43,7 +43,7 @@ def main():
     chunks = (1 + 5 * (M - 1)) + 5 + 16 + 16
     flop = B * (chunks * 16 * 256 * 2 + 256 * 16 * 2)
     useful = B * 2 * ((7 + 64 * (M - 1) + 7 * (M - 1)) * 256 + 68 * 256 + 2 * 256 * 256 + 256 * 12)
-    print({"rows": B, "max_other": M, "fused_us": round(t_fused, 1), "torch_us": round(t_torch, 1), "pack_us": round(t_load, 1),
+    print({"form": os.environ.get("CAVOID_POLICY_FORM", "quad"), "rows": B, "max_other": M, "fused_us": round(t_fused, 1), "torch_us": round(t_torch, 1), "pack_us": round(t_load, 1),
            "issued_TFLOPs": round(flop / t_fused * 1e-6, 1), "useful_TFLOPs": round(useful / t_fused * 1e-6, 1),
            "frac_of_157TF_issued": round(flop / t_fused * 1e-6 / 157.3, 3)})
 
