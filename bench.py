@@ -354,7 +354,8 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
                                                    "f32 in/out; bf16 split, %d partial products per float32 product, f32 accumulate") % products,
                         "precision_vs_float64": ("|dp| <= 1.9e-7, |dv| <= 1.4e-6 incl. x4 inputs (float32-MFMA kernel: 1.8e-7 / 8.7e-7); "
                                                  "profiles/r04_split_f16_vs_bf16.txt") if form == 16 else "|dp| <= 3.7e-6, |dv| <= 2.5e-5 (bf16 pieces)",
-                        "kernel": "cavoid::policy_forward_split_kernel"})
+                        "kernel": "cavoid::policy_forward_split_duo_kernel (two tiles per workgroup, phases one barrier apart)" if tiles >= 512 and os.environ.get("CAVOID_POLICY_FORM") in (None, "duo")
+                                  else "cavoid::policy_forward_split_kernel"})
         else:
             out.update({"issued_TFLOPs": flop / fused_us * 1e-6, "peak_TFLOPs": F32_VECTOR_PEAK_TFLOPS, "frac": flop / fused_us * 1e-6 / F32_VECTOR_PEAK_TFLOPS,
                         "bound": "mfma", "dtype": "f32", "kernel": "cavoid::policy_forward_kernel"})
@@ -385,6 +386,9 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
 def step_kernel_name(N: int, W: int, spl: int) -> str:
     """Which instantiation cavoid_step_autoreset_n takes (csrc/cavoid_capi.hip, cavoid_launch.hpp)."""
     if spl == 1:
+        tiles1 = -(-W // (64 // N))
+        if tiles1 <= 512 and N in (2, 3, 4, 5, 6, 10) and os.environ.get("CAVOID_QUAD", "-1") != "0":
+            return "cavoid::env_quad_kernel<%d> (one step by four cooperating wavefronts per tile)" % N
         return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET, false>" % N
     if W * N > 131072:
         return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET_N, false>" % N
@@ -518,7 +522,7 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
             if ctr not in cs:
                 continue
             hit = re.search(r"env_kernel<%d, (\d+)" % N, name)
-            if hit and hit.group(1) == "1":
+            if (hit and hit.group(1) == "1") or ("env_quad_kernel<%d>" % N) in name:
                 form = "one_step"
             elif (hit and hit.group(1) in ("4", "5")) or ("env_pipe_kernel<%d," % N) in name or ("env_relay_kernel<%d>" % N) in name:
                 form = "k_step"
@@ -546,7 +550,7 @@ def measure_mfma(N: int, W: int, timeout_s: float):
     if res is None:
         return None
     out = {}
-    for key, sub in (("policy_kernel", "policy_forward_split_kernel"), ("actor_kernel", "actor_kernel<")):
+    for key, sub in (("policy_kernel", "policy_forward_split_"), ("actor_kernel", "actor_kernel<")):
         for name, cs in res.items():
             if sub in name and "SQ_INSTS_MFMA" in cs:
                 # the actor kernel: the LAST launches only -- the child starts from a reset, and until the first episodes end every row of

@@ -113,7 +113,7 @@ typedef struct cavoid_cfg {
     double reward_collision;   /* -0.25 */
     double reward_getting_close;/* -0.1 */
     double reward_time_step;   /* 0.0 */
-    double close_penalty_slope;/* -0.5: r = reward_getting_close + slope*gap */
+    double close_penalty_slope;/* +0.5 (the published reward, arXiv:1805.01956; -0.5 = upstream code as the survey recalls it): r = reward_getting_close + slope*gap */
     double reward_clip_lo, reward_clip_hi; /* [-0.25, 1.0] */
     double sensing_horizon;    /* +inf */
     double max_turn_rate;      /* 3.0 rad/s (CAVOID_DYN_UNICYCLE_MAX_TURN only) */

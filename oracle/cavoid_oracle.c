@@ -40,7 +40,7 @@ void oracle_default_cfg(oracle_cfg *c, int32_t max_agents, int32_t max_other) {
     c->dt = 0.2; c->near_goal_threshold = 0.2; c->max_time_ratio = 2.0; c->collision_dist = 0.0;
     c->getting_close_range = 0.2; c->reward_at_goal = 1.0; c->reward_collision = -0.25;
     c->reward_getting_close = -0.1; c->reward_time_step = 0.0; c->sensing_horizon = INFINITY;
-    c->close_penalty_slope = -0.5; c->max_turn_rate = 3.0; c->reward_clip_lo = -0.25; c->reward_clip_hi = 1.0;
+    c->close_penalty_slope = 0.5; c->max_turn_rate = 3.0; c->reward_clip_lo = -0.25; c->reward_clip_hi = 1.0;
     /* RVO_TIME_HORIZON :237-239, RVO_COLLAB_COEFF :234-236; radius inflation and turn limit: upstream RVOPolicy as recalled */
     c->rvo_time_horizon = 5.0; c->rvo_collab_coeff = 0.5; c->rvo_radius_scale = 1.05; c->rvo_max_delta_heading = PI / 6;
     c->max_agents = max_agents; c->max_other = max_other; c->sort_method = SORT_CLOSEST_LAST;

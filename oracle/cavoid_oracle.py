@@ -93,7 +93,7 @@ class OracleConfig:
     max_agents: int = 4                  # MAX_NUM_AGENTS_IN_ENVIRONMENT (N)
     max_other_agents_observed: int = 3   # MAX_NUM_OTHER_AGENTS_OBSERVED (M)
     # --- U-switches ------------------------------------------------------
-    close_penalty_slope: float = -0.5    # U5: r = reward_getting_close + slope*gap  (-0.5 code / +0.5 paper)
+    close_penalty_slope: float = 0.5     # U5: r = reward_getting_close + slope*gap  (+0.5: the paper, favoured by the reference's recorded scores; -0.5: upstream code as recalled)
     actions_fp32: bool = True            # joint action array is float32 in the env's _take_action
     timeout_enabled: bool = True         # U1
     dynamics: int = DYN_UNICYCLE         # U3

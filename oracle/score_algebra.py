@@ -23,7 +23,7 @@ class RewardAlgebra:
     reward_collision: float = -0.25
     reward_getting_close: float = -0.1
     getting_close_range: float = 0.2
-    close_penalty_slope: float = -0.5
+    close_penalty_slope: float = 0.5
 
     def close_term_range(self):
         """[lo, hi] of one getting-close term over gaps d in (0, range] (d = 0 is a collision: the end at d -> 0 is open)"""

@@ -76,7 +76,7 @@ extern "C" int cavoid_default_cfg(cavoid_cfg *c, int32_t max_agents, int32_t max
     c->reward_collision = -0.25;
     c->reward_getting_close = -0.1;
     c->reward_time_step = 0.0;
-    c->close_penalty_slope = -0.5;
+    c->close_penalty_slope = 0.5;                          // U5: the published sign (arXiv:1805.01956), which the reference's recorded scores favour too
     c->reward_clip_lo = -0.25;
     c->reward_clip_hi = 1.0;
     c->sensing_horizon = INFINITY;

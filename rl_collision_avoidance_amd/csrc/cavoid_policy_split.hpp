@@ -671,7 +671,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
             // all eight loads (and the sixteen of avg / std) are issued before the first use: unused elements re-read element 0
             // of the slot and rows past the end re-read row 0 -- valid addresses, selected away below -- so nothing is conditional
             // COMPACT: r == this thread's lane; a live row writes tile row `pos`, a lane at or behind n_live zeroes tile row `lane`, the
-            // lanes in between (not live, below n_live) own no tile row
+            // lanes in between (not live, below n_live) own no tile row; a LIVE lane at or behind n_live also zeroes tile row `lane` (below)
             const bool row_ok = COMPACT ? mine : r < rows_here;
             if (COMPACT && !mine && r < n_live) continue;
             const int rr = row_ok ? r : 0;
@@ -696,6 +696,11 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
             unsigned char *d = planes + ((COMPACT && mine) ? pos : r) * kSpStrideB + sp_phys(kSpSlotCol + 8 * s);
             *reinterpret_cast<uint4 *>(d) = uint4{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<uint4 *>(d + kSpPlaneB) = uint4{lo[0], lo[1], lo[2], lo[3]};
+            if (COMPACT && mine && r >= n_live) {           // a live lane behind the packed rows: tile row `lane` is nobody's -- it takes zeros like the rest of the tail
+                unsigned char *z = planes + r * kSpStrideB + sp_phys(kSpSlotCol + 8 * s);
+                *reinterpret_cast<uint4 *>(z) = uint4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<uint4 *>(z + kSpPlaneB) = uint4{0u, 0u, 0u, 0u};
+            }
         }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {

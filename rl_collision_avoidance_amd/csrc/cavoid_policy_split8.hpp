@@ -295,6 +295,11 @@ __device__ __forceinline__ void policy_split_tile8(const SplitArgs &sa, unsigned
             unsigned char *d = planes + ((COMPACT && mine) ? pos : r) * kSpStrideB + sp_phys(kSpSlotCol + 8 * s);
             *reinterpret_cast<uint4 *>(d) = uint4{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<uint4 *>(d + kSpPlaneB) = uint4{lo[0], lo[1], lo[2], lo[3]};
+            if (COMPACT && mine && r >= n_live) {           // a live lane behind the packed rows: tile row `lane` is nobody's -- it takes zeros like the rest of the tail
+                unsigned char *z = planes + r * kSpStrideB + sp_phys(kSpSlotCol + 8 * s);
+                *reinterpret_cast<uint4 *>(z) = uint4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<uint4 *>(z + kSpPlaneB) = uint4{0u, 0u, 0u, 0u};
+            }
         }
     }
     __syncthreads();

@@ -310,7 +310,7 @@ def test_u_switches_follow_the_oracle():
     """close-penalty sign (U5), float64 action array, timeout off (U1), time budget from the goal centre (U11):
     flipped on both sides."""
     W, N, steps, seed = 300, 4, 120, 8
-    over = dict(close_penalty_slope=0.5, actions_fp32=0, timeout_enabled=0, time_budget_from_goal_edge=0)
+    over = dict(close_penalty_slope=-0.5, actions_fp32=0, timeout_enabled=0, time_budget_from_goal_edge=0)
     ocfg, ogen = _oracle(N, **over)
     env = _env(W, N, seed=seed, **over)
     st = co.State.empty(W, N)

@@ -217,11 +217,12 @@ def test_head_on_collision_step_index_and_reward():
         obs, rew, over, info = w.step({0: 2, 1: 2})
         if k < 22:
             assert not over and np.all(rew == 0.0)
-        if k == 22:      # gap = 9 - 8.8 = 0.2 -> getting-close term -0.1 - gap/2
+        if k == 22:      # gap = 9 - 8.8 = 0.2 -> getting-close term -0.1 + slope * gap (U5: +0.5, the published sign, is the default)
             gap = obs[0, 6 + 6]
             assert abs(gap - 0.2) < 1e-9 and not over
             if gap <= 0.2:
-                np.testing.assert_allclose(rew, -0.1 - gap / 2, atol=1e-12)
+                np.testing.assert_allclose(rew, -0.1 + cfg.close_penalty_slope * gap, atol=1e-12)
+                assert cfg.close_penalty_slope == 0.5
         if over:
             break
     assert k == 23 and np.all(rew == -0.25)
