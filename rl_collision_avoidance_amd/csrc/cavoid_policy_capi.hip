@@ -47,7 +47,7 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
     // 64-row tile, two independent workgroups per CU; oct: eight wavefronts per tile (cavoid_policy_split8.hpp); duo: two tiles per workgroup, phases
     // locked one barrier apart (policy_forward_split_duo_kernel)
     // Default (-1): duo once the launch has at least two tiles per compute unit (below that a paired workgroup would leave CUs idle), else quad.
-    if (const char *ov = std::getenv("CAVOID_POLICY_FORM")) h->form = !std::strcmp(ov, "oct") ? 1 : (!std::strcmp(ov, "duo") ? 2 : (!std::strcmp(ov, "quad") ? 0 : -1));
+    if (const char *ov = std::getenv("CAVOID_POLICY_FORM")) h->form = !std::strcmp(ov, "oct") ? 1 : (!std::strcmp(ov, "duo") ? 2 : (!std::strcmp(ov, "pipe") ? 3 : (!std::strcmp(ov, "quad") ? 0 : -1)));
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->num_cus <= 0) h->num_cus = 256;
     h->avg = reinterpret_cast<float *>(b + o_avg); h->std = reinterpret_cast<float *>(b + o_std);
     h->step_counter = reinterpret_cast<int32_t *>(b + o_step); h->blocks_done = reinterpret_cast<uint32_t *>(b + o_done);
@@ -67,6 +67,8 @@ extern "C" int cavoid_policy_create(int32_t max_other, int32_t num_actions, int 
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_split_lds_bytes()) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<kSpF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)policy_split_lds_bytes()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split_kernel<kSpF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_split_lds_bytes()) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)policy_split_lds_bytes()) != hipSuccess ||
@@ -168,6 +170,8 @@ static int policy_forward(cavoid_policy *h, const float *x, int64_t rows, int64_
         hipStream_t s = static_cast<hipStream_t>(stream);
         const int form = h->form >= 0 ? h->form : (blocks >= 2 * (int64_t)h->num_cus ? 2 : 0);
         if (h->split_products == kSpF16 && form == 1) hipLaunchKernelGGL(policy_forward_split8_kernel, dim3((unsigned)blocks), dim3(512), policy_split_lds_bytes(), s, sa);
+        else if (h->split_products == kSpF16 && form == 3)
+            hipLaunchKernelGGL((policy_forward_split_kernel<kSpF16, true>), dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);
         else if (h->split_products == kSpF16 && form == 2)
             hipLaunchKernelGGL(policy_forward_split_duo_kernel<kSpF16>, dim3((unsigned)((blocks + 1) / 2)), dim3(512), policy_split_duo_lds_bytes(), s, sa);
         else if (h->split_products == kSpF16) hipLaunchKernelGGL(policy_forward_split_kernel<kSpF16>, dim3((unsigned)blocks), dim3(256), policy_split_lds_bytes(), s, sa);

@@ -596,6 +596,10 @@ __device__ __forceinline__ void split_lstm_cell2(const f32x2 xi, const f32x2 xj,
     h_new = go * tc;
 }
 
+}  // namespace cavoid
+#include "cavoid_policy_pipe.hpp"
+namespace cavoid {
+
 // The forward pass of ONE 64-row tile by the 4 wavefronts of a workgroup (layout: header of this file).
 //   load(r, k)  -> policy input k (0 = num_other_agents) of tile row r, r < rows_here; the rows may live in global memory (the
 //                  stand-alone kernel) or in LDS (the fused actor kernel: the env step left them there);
@@ -610,7 +614,9 @@ __device__ __forceinline__ void split_lstm_cell2(const f32x2 xi, const f32x2 xj,
 // gives it; emit() is called for live rows only, with their ORIGINAL tile row (the action draw is keyed on it).
 // NRT > 0 = COMPACT with the first NRT row tiles computed: `live_mask` (bit r: tile row r still needs an action; the same value in every
 // wavefront; at least one bit, at most 16 NRT) comes from the caller, which picks the instantiation.
-template <int P, int NRT = 0, class Load, class Emit>
+// PIPE: the LSTM steps and layer1 run as a software pipeline over row halves, their cell updates / epilogue inside the other half's matrix
+// instructions (cavoid_policy_pipe.hpp); same results.
+template <int P, int NRT = 0, bool PIPE = false, class Load, class Emit>
 __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned char *planes, float *len_f, int *wave_max, int rows_here,
                                                   int tid, Load load, Emit emit, unsigned long long live_mask = ~0ull, int *rmap = nullptr,
                                                   int steps_total = -1) {
@@ -635,7 +641,11 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     SplitW f0;
     f32x4 b4[4];                                           // the bias of the GEMM that comes next (P = 3: its first product's C operand)
     // first LSTM step: h == 0, only the input chunk contributes (float16 form: its mixed plane, one product)
-    if constexpr (F16) split_load_w1(f0.w[0], src, w_lstm, 2, wave, lane, kSpSlotChunk);
+    static_assert(!PIPE || F16, "the pipelined form carries the float16 pieces");
+    PpW wb[2];                                             // (PIPE) the [h | slot] layer's weight fragments: chunk 0, chunk 1,
+    uint4 wslot[4];                                        //        the slot chunk's mixed plane
+    if constexpr (PIPE) split_load_w1(wslot, src, w_lstm, 2, wave, lane, kSpSlotChunk);
+    else if constexpr (F16) split_load_w1(f0.w[0], src, w_lstm, 2, wave, lane, kSpSlotChunk);
     else split_load_w<P>(f0, src, w_lstm, wave, lane, kSpSlotChunk);
     split_load_bias(b4, src, kBiasLstm, wave, lane);
 
@@ -724,65 +734,122 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     f32x4 cell[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) cell[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // One LSTM step; ALL_LIVE (a type: two separately compiled bodies): every row of the tile has more than t observed agents -- the usual
-    // case in full worlds -- so the cell update needs no selects.  (As ONE loop with a uniform `all_live` flag the compiler folded the two
-    // cases into selects on every cell register plus ~100 register moves per step at the loop's end: 15 % of the tile's vector instructions.)
-    auto lstm_step = [&](const int t, auto all_live_c) {
-        constexpr bool ALL_LIVE = decltype(all_live_c)::value;
-        f32x4 acc[4][4];
-        if (t == 1) POLICY_STAMP(8);
-        split_gemm<P>(planes, src, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
-                      t + 1 < steps ? w_lstm : (int)kSpOffL1, 0, kBiasLstm, b4,
-                      t + 1 < steps ? kBiasLstm : kBiasL1, rt);             // (requests the next step's / layer1's first fragments and bias)
-        if (t == 1) POLICY_STAMP(9);
-        __syncthreads();                                   // every wavefront has read h
-        if (t == 1) POLICY_STAMP(10);
-        // lane: row 16nt + l%16, hidden units 16w + 4g + r; column tile = gate (i, j, f, o).  dynamic_rnn: rows past their own
-        // length keep (c, h)
+    if constexpr (PIPE) {
+        // ---- LSTM steps and layer1 in row halves: H0 = row tiles 0 .. NT0-1 (accumulators A), H1 = the rest (accumulators B) ----------
+        constexpr int NRTc = COMPACT ? NRT : 4, NT0 = (NRTc + 1) / 2, NT1 = NRTc - NT0;
+        static_assert(NT1 >= 1 && NT0 <= 2, "two to four row tiles");
+        f32x4 accA[4][2], accB[4][2];
+        auto load_wb = [&](int layer) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (!rt.has(nt)) continue;
-            const bool live = ALL_LIVE || len_r[nt] > (float)t;
-            f32x4 h_new;
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                f32x2 c2, h2;
-                split_lstm_cell2(f32x2{acc[0][nt][r], acc[0][nt][r + 1]}, f32x2{acc[1][nt][r], acc[1][nt][r + 1]},
-                                 f32x2{acc[2][nt][r], acc[2][nt][r + 1]}, f32x2{acc[3][nt][r], acc[3][nt][r + 1]},
-                                 f32x2{cell[nt][r], cell[nt][r + 1]}, c2, h2);
-                h_new[r] = h2[0]; h_new[r + 1] = h2[1];
-                if constexpr (ALL_LIVE) { cell[nt][r] = c2[0]; cell[nt][r + 1] = c2[1]; }
-                else { cell[nt][r] = live ? c2[0] : cell[nt][r]; cell[nt][r + 1] = live ? c2[1] : cell[nt][r + 1]; }
+            for (int c = 0; c < 2; ++c) { split_load_w1(wb[c].p0, src, layer, 0, wave, lane, c); split_load_w1(wb[c].p1, src, layer, 1, wave, lane, c); }
+        };
+        const int l1 = (int)kSpOffL1;
+        if (steps > 0) {
+            load_wb(steps > 1 ? w_lstm : l1);              // (the first bracket that has plain chunks: LSTM step 1, or layer1)
+            // t = 0: h == 0, the slot's product only; no barrier between the halves (nothing reads h yet)
+            pp_bracket<NT0, false, false>(planes, src, kSpSlotCol + 8, wave, lane, 0, wb, wslot, accA, b4, 0, kBiasLstm, PpNoFill{});
+            pp_bracket<NT1, false, true>(planes, src, kSpSlotCol + 8, wave, lane, NT0, wb, wslot, accB, b4, steps > 1 ? w_lstm : l1,
+                                         steps > 1 ? kBiasLstm : kBiasL1, PpCellFill<NT0, 0>{planes, accA, cell, len_f, 0, wave, lane});
+            __syncthreads();
+#pragma unroll 1
+            for (int t = 1; t < steps; ++t) {
+                if (t == 1) POLICY_STAMP(8);
+                pp_bracket<NT0, true, false>(planes, src, kSpSlotCol + 8 * (1 + t), wave, lane, 0, wb, wslot, accA, b4, 0, kBiasLstm,
+                                             PpCellFill<NT1, NT0>{planes, accB, cell, len_f, t - 1, wave, lane});
+                if (t == 1) POLICY_STAMP(9);
+                __syncthreads();
+                if (t == 1) POLICY_STAMP(10);
+                const bool last = t + 1 >= steps;
+                pp_bracket<NT1, true, true>(planes, src, kSpSlotCol + 8 * (1 + t), wave, lane, NT0, wb, wslot, accB, b4, last ? l1 : w_lstm,
+                                            last ? kBiasL1 : kBiasLstm, PpCellFill<NT0, 0>{planes, accA, cell, len_f, t, wave, lane});
+                if (t == 1) POLICY_STAMP(11);
+                __syncthreads();
+                if (t == 1) POLICY_STAMP(12);
             }
-            if (live) split_store4<F16>(planes, 16 * nt + (lane & 15), 16 * wave + 4 * g, h_new);   // (else h stays as it is)
-        }
-        if (t == 1) POLICY_STAMP(11);
-        __syncthreads();                                   // the new h is in place
-        if (t == 1) POLICY_STAMP(12);
-    };
-    {
-        const int t_all = tile_min_len < steps ? tile_min_len : steps;
-        int t = 0;
-#pragma unroll 1
-        for (; t < t_all; ++t) lstm_step(t, SplitYes{});
-#pragma unroll 1
-        for (; t < steps; ++t) lstm_step(t, SplitNo{});
-        // (the paired form, policy_forward_split_duo_kernel: the workgroup's other tile has more LSTM steps -- keep its barrier count)
-#pragma unroll 1
-        for (; t < steps_total; ++t) { __syncthreads(); __syncthreads(); }
-    }
-    POLICY_STAMP(1);
-    // ---- layer1 on [h | host] -------------------------------------------------------------------------------------
-    {
-        f32x4 acc[4][4];
-        if (steps == 0) {                                  // (else the last LSTM step asked for them)
-            split_load_w<P>(f0, src, (int)kSpOffL1, wave, lane, 0);
+            POLICY_STAMP(1);
+            // layer1, H0 -- beside the last cell update of H1
+            pp_bracket<NT0, true, false>(planes, src, kSpSlotCol, wave, lane, 0, wb, wslot, accA, b4, 0, kBiasL1,
+                                         PpCellFill<NT1, NT0>{planes, accB, cell, len_f, steps - 1, wave, lane});
+        } else {
+            POLICY_STAMP(1);
+            load_wb(l1);
+            split_load_w1(wslot, src, l1, 2, wave, lane, kSpSlotChunk);
             split_load_bias(b4, src, kBiasL1, wave, lane);
+            pp_bracket<NT0, true, false>(planes, src, kSpSlotCol, wave, lane, 0, wb, wslot, accA, b4, 0, kBiasL1, PpNoFill{});
         }
-        split_gemm<P>(planes, src, (int)kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, (int)kSpOffL2, 0, kBiasL1, b4, kBiasL2, rt);
         __syncthreads();
-        split_store_relu<F16>(planes, wave, lane, acc, rt);
+        // layer1, H1 -- beside the relu + split of H0
+        pp_bracket<NT1, true, false>(planes, src, kSpSlotCol, wave, lane, NT0, wb, wslot, accB, b4, 0, kBiasL2, PpReluFill<NT0, 0>{planes, accA, wave, lane});
+        split_load_w1(f0.w[0], src, (int)kSpOffL2, 0, wave, lane, 0);      // layer2's first fragments (its bias is on its way), as split_gemm expects them
+        split_load_w1(f0.w[1], src, (int)kSpOffL2, 1, wave, lane, 0);
+        __syncthreads();                                   // every wavefront has read H1's [h | host]
+        {
+            const PpReluFill<NT1, NT0> tail{planes, accB, wave, lane};
+#pragma unroll
+            for (int u = 0; u < PpReluFill<NT1, NT0>::units; ++u) tail.unit(u);
+        }
         __syncthreads();
+    } else {
+    // One LSTM step; ALL_LIVE (a type: two separately compiled bodies): every row of the tile has more than t observed agents -- the usual
+        // case in full worlds -- so the cell update needs no selects.  (As ONE loop with a uniform `all_live` flag the compiler folded the two
+        // cases into selects on every cell register plus ~100 register moves per step at the loop's end: 15 % of the tile's vector instructions.)
+        auto lstm_step = [&](const int t, auto all_live_c) {
+            constexpr bool ALL_LIVE = decltype(all_live_c)::value;
+            f32x4 acc[4][4];
+            if (t == 1) POLICY_STAMP(8);
+            split_gemm<P>(planes, src, w_lstm, t == 0 ? 2 : 0, kSpChLstm, 2, kSpSlotCol + 8 * (1 + t), wave, lane, f0, acc,
+                          t + 1 < steps ? w_lstm : (int)kSpOffL1, 0, kBiasLstm, b4,
+                          t + 1 < steps ? kBiasLstm : kBiasL1, rt);             // (requests the next step's / layer1's first fragments and bias)
+            if (t == 1) POLICY_STAMP(9);
+            __syncthreads();                                   // every wavefront has read h
+            if (t == 1) POLICY_STAMP(10);
+            // lane: row 16nt + l%16, hidden units 16w + 4g + r; column tile = gate (i, j, f, o).  dynamic_rnn: rows past their own
+            // length keep (c, h)
+    #pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (!rt.has(nt)) continue;
+                const bool live = ALL_LIVE || len_r[nt] > (float)t;
+                f32x4 h_new;
+    #pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2 c2, h2;
+                    split_lstm_cell2(f32x2{acc[0][nt][r], acc[0][nt][r + 1]}, f32x2{acc[1][nt][r], acc[1][nt][r + 1]},
+                                     f32x2{acc[2][nt][r], acc[2][nt][r + 1]}, f32x2{acc[3][nt][r], acc[3][nt][r + 1]},
+                                     f32x2{cell[nt][r], cell[nt][r + 1]}, c2, h2);
+                    h_new[r] = h2[0]; h_new[r + 1] = h2[1];
+                    if constexpr (ALL_LIVE) { cell[nt][r] = c2[0]; cell[nt][r + 1] = c2[1]; }
+                    else { cell[nt][r] = live ? c2[0] : cell[nt][r]; cell[nt][r + 1] = live ? c2[1] : cell[nt][r + 1]; }
+                }
+                if (live) split_store4<F16>(planes, 16 * nt + (lane & 15), 16 * wave + 4 * g, h_new);   // (else h stays as it is)
+            }
+            if (t == 1) POLICY_STAMP(11);
+            __syncthreads();                                   // the new h is in place
+            if (t == 1) POLICY_STAMP(12);
+        };
+        {
+            const int t_all = tile_min_len < steps ? tile_min_len : steps;
+            int t = 0;
+    #pragma unroll 1
+            for (; t < t_all; ++t) lstm_step(t, SplitYes{});
+    #pragma unroll 1
+            for (; t < steps; ++t) lstm_step(t, SplitNo{});
+            // (the paired form, policy_forward_split_duo_kernel: the workgroup's other tile has more LSTM steps -- keep its barrier count)
+    #pragma unroll 1
+            for (; t < steps_total; ++t) { __syncthreads(); __syncthreads(); }
+        }
+        POLICY_STAMP(1);
+        // ---- layer1 on [h | host] -------------------------------------------------------------------------------------
+        {
+            f32x4 acc[4][4];
+            if (steps == 0) {                                  // (else the last LSTM step asked for them)
+                split_load_w<P>(f0, src, (int)kSpOffL1, wave, lane, 0);
+                split_load_bias(b4, src, kBiasL1, wave, lane);
+            }
+            split_gemm<P>(planes, src, (int)kSpOffL1, 0, kSpChL1, 2, kSpSlotCol, wave, lane, f0, acc, (int)kSpOffL2, 0, kBiasL1, b4, kBiasL2, rt);
+            __syncthreads();
+            split_store_relu<F16>(planes, wave, lane, acc, rt);
+            __syncthreads();
+        }
     }
     POLICY_STAMP(2);
     // ---- layer2, fullyconnected1 ----------------------------------------------------------------------------------
@@ -851,7 +918,7 @@ __device__ __forceinline__ void policy_split_tile(const SplitArgs &sa, unsigned 
     POLICY_STAMP(4);
 }
 
-template <int P>
+template <int P, bool PIPE = false>
 __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const SplitArgs sa) {
     const PolicyArgs &p = sa.p;
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];      // plane 1 (hi), plane 2 (lo)
@@ -903,7 +970,7 @@ __global__ void __launch_bounds__(256, 2) policy_forward_split_kernel(const Spli
             if (row < p.rows && g == 0) p.actions_out[row] = action;
         }
     };
-    policy_split_tile<P>(sa, planes, len_f, wave_max, rows_here, tid, load, emit);
+    policy_split_tile<P, 0, PIPE>(sa, planes, len_f, wave_max, rows_here, tid, load, emit);
 #ifdef CAVOID_TRACE
     if (tid == 0 && g_pol_trace) g_pol_trace[(size_t)blockIdx.x * 16 + 6] = clock64() - trace_c0;   // shader-clock cycles
 #endif

@@ -505,7 +505,7 @@ def test_fused_actor_availability_follows_the_handles_not_the_environment(monkey
     roll3.close(); env3.close(); env2.close()
 
 
-@pytest.mark.parametrize("form", ["oct", "duo"])
+@pytest.mark.parametrize("form", ["oct", "duo", "pipe"])
 @pytest.mark.parametrize("M,B,scale", [(3, 5000, 1.0), (9, 2111, 1.0), (3, 4096, 4.0), (1, 300, 1.0), (3, 64, 1.0), (5, 129, 1.0)])
 def test_other_tile_to_wavefront_forms_are_bit_identical(M, B, scale, form, monkeypatch):
     """Two other mappings of the same pass (CAVOID_POLICY_FORM, read at cavoid_policy_create):
@@ -513,6 +513,8 @@ def test_other_tile_to_wavefront_forms_are_bit_identical(M, B, scale, form, monk
            that a lane still holds all four gates of its hidden units);
     duo -- two tiles per workgroup of eight wavefronts, the second tile one barrier behind the first, so that one tile's matrix phases run
            beside the other's vector phases (policy_forward_split_duo_kernel); a tile with fewer LSTM steps idles through the difference.
+    pipe -- the LSTM steps and layer1 as a software pipeline over row halves: one half's cell update / epilogue inside the other half's matrix
+           instructions (cavoid_policy_pipe.hpp).
     Every output element is the same float32 sum in the same order: probabilities, values and the drawn actions are BIT for bit the default
     form's -- full pass and row-list pass, ragged observed-agent counts, odd tile counts, a last tile with one row."""
     from rl_collision_avoidance_amd.ga3c.policy_kernel import FusedPolicy
