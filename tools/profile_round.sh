@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: kernel-trace --stats of the bench commands (N = 4 and N = 10, default and the driver's
 # K = 20 form, the full loop), PMC traffic, and the sweep.  usage: bash tools/profile_round.sh <tag>   (on the GPU box)
-tag=${1:-r05_m}; out=$PWD/gpurun_out/prof_$tag; mkdir -p $out; repo=$PWD
+tag=${1:-r06_a}; out=$PWD/gpurun_out/prof_$tag; mkdir -p $out; repo=$PWD
 export TMPDIR=/tmp
 prof() {   # prof <name> <bench args...>
   name=$1; shift
@@ -27,7 +27,7 @@ M = $1 - 1
 if r is not None:
     per_step = r["traffic"] / r["steps_per_launch"]
     moved = bench.moved_bytes_per_agent_step(M, $1, $3 == 1) * $1 * $2
-    r.update({"round": 5, "agents": $1, "worlds": $2, "steps_per_launch": $3, "outputs": "per-step slots [K,W,N,.]" if $3 > 1 else "one step per launch",
+    r.update({"round": 6, "agents": $1, "worlds": $2, "steps_per_launch": $3, "outputs": "per-step slots [K,W,N,.]" if $3 > 1 else "one step per launch",
               "traffic_bytes_per_step": per_step, "moved_bytes_per_step_expected": moved, "traffic_over_moved": per_step / moved,
               "contract_bytes_per_step": bench.algorithmic_bytes_per_agent_step(M) * $1 * $2})
 print(json.dumps(r, indent=1))
