@@ -23,6 +23,7 @@ import json, sys
 sys.path.insert(0, "$repo")
 import bench
 r = bench.measure_traffic($1, $2, $3, max(4 * $3, 64), timeout_s=400.0, min_agents=2 if $1 == 10 else 0)
+r = (r or {}).get("one_step" if $3 == 1 else "k_step")      # (both launch forms come back from one pass: this file is the named one's)
 M = $1 - 1
 if r is not None:
     per_step = r["traffic"] / r["steps_per_launch"]
