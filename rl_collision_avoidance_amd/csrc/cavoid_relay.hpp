@@ -104,6 +104,13 @@ __device__ __forceinline__ void relay_spin(const int *p, int v) {
     while (relay_peek(p) < v) { }
     asm volatile("" ::: "memory");
 }
+// issue the LDS read of a counter NOW, look at the value LATER (relay_seen): the round trip runs under whatever the wavefront does in between
+// -- D's waits that are almost always satisfied already (a consumer's ring slot, P's verdict in the D-bound regime) cost an issue slot
+// instead of an exposed LDS latency on the loop-carried chain
+__device__ __forceinline__ int relay_peek_issue(const int *p) { return *(relay_lds_int *)p; }
+__device__ __forceinline__ int relay_seen(int v) { return __builtin_amdgcn_readfirstlane(v); }
+typedef __attribute__((address_space(3))) volatile uint32_t relay_lds_u32;
+typedef __attribute__((address_space(3))) volatile double relay_lds_f64;
 __device__ __forceinline__ void relay_post(int *p, int v) {
     asm volatile("" ::: "memory");        // the data writes are issued before the counter (LDS keeps a wavefront's order)
     *(relay_lds_int *)p = v;
@@ -273,9 +280,11 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         }
         // the table row of the NEXT step's action is read one iteration ahead (two dependent LDS trips off the chain)
         double tab_s = 0.0, tab_h = 0.0;
+        int act_q = 0;                                      // ... and the action INDEX of the step after that, two iterations ahead
         if (n_steps > 1) {
             const int actn = (int)actring[64 + lane0];
             tab_s = lds_tab[2 * actn]; tab_h = lds_tab[2 * actn + 1];
+            if (n_steps > 2) act_q = (int)actring[2 * 64 + lane0];
         }
         auto stage_out = [&](RelayTent &tn, const Agent &x, int lane) {
             const bool present = active && (x.flags & CAVOID_F_PRESENT);
@@ -297,25 +306,42 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             //      is when its own verdict says so (no new collision, no restart in the tile) ---------------------------------
             RelayTent &tn = tents[(t + 1) & (kRelayRing - 1)];
             const double tab_s1 = tab_s, tab_h1 = tab_h;    // action(t+1)'s row
-            int act2 = 0;
-            if (t + 2 < n_steps) {
-                if ((t & 7) == 0) relay_wait(&seq->act, t + 10 < n_steps ? t + 10 : n_steps);   // (the loader runs 48 steps ahead)
-                act2 = (int)actring[((t + 2) & (kRelayActRing - 1)) * 64 + lane];
+            const int act2 = act_q;                        // action(t+2)'s index, read one iteration ago (0 past the end: a valid row, unused)
+            int act3 = 0;                                   // action(t+3)'s, for the next iteration: the ring read lands under the advance
+            if (t + 3 < n_steps) {
+                // (the loader's first batch is 8 steps -- iterations 0..3 read steps 3..6 --, from iteration 4 on every eighth iteration makes
+                //  sure of the next eight reads; the loader runs up to 48 steps ahead of `fin`)
+                if ((t & 7) == 4) relay_wait(&seq->act, t + 12 < n_steps ? t + 12 : n_steps);
+                act3 = (int)actring[((t + 3) & (kRelayActRing - 1)) * 64 + lane];
             }
+            // Round 6: this iteration is the launch's period (P idles a third of it), and five LDS round trips sat bare on it -- the action ring,
+            // the table row behind it, the consumer's ring-slot counter, P's verdict counter, the verdict itself.  The ring read runs one more
+            // iteration ahead (above); the table row and the slot counter are ISSUED here, in front of the advance, and looked at behind it;
+            // the verdict's words are read right behind its counter (LDS returns a wavefront's reads in order: a counter that says "posted"
+            // vouches for the words read after it)
+            const bool need_slot = t + 1 >= kRelayRing;    // slot free: the consumer of step t+1-ring is done with it
+            const int cons_early = need_slot ? relay_peek_issue(&seq->cons[cslot]) : 0;
+            const double tab_s2 = *(relay_lds_f64 *)&lds_tab[2 * act2], tab_h2 = *(relay_lds_f64 *)&lds_tab[2 * act2 + 1];
             bool mn;
             Agent Tn = relay_advance(cd, trig, T, tab_s1, tab_h1, active, mn);
-            if (t + 1 >= kRelayRing) {                      // slot free: the consumer of step t+1-ring is done with it
-                relay_wait(&seq->cons[cslot], t + 2 - kRelayRing);
+            if (need_slot) {
+                if (relay_seen(cons_early) < t + 2 - kRelayRing) relay_wait(&seq->cons[cslot], t + 2 - kRelayRing);
                 cslot = cslot + 1 == NC ? 0 : cslot + 1;
             }
             stage_out(tn, Tn, lane);
             relay_post(&seq->spec, t + 2);
             RELAY_STAMP(1);                                // D: successor computed and posted
             // ---- P's verdict on step t -----------------------------------------------------------------------------------
-            relay_spin(&seq->res, t + 1);
-            RELAY_STAMP(2);                                // D: verdict arrived
             RelayRes *res = &ress[t & (kRelayRing - 1)];
-            const uint32_t vflags = res->flags[lane], ctl = res->ctl[lane];
+            uint32_t vflags, ctl;
+            for (;;) {                                      // counter, then the words, in ONE trip
+                const int posted = relay_peek_issue(&seq->res);
+                vflags = *(relay_lds_u32 *)&res->flags[lane];
+                ctl = *(relay_lds_u32 *)&res->ctl[lane];
+                if (relay_seen(posted) >= t + 1) break;
+            }
+            asm volatile("" ::: "memory");
+            RELAY_STAMP(2);                                // D: verdict arrived
             moved_any = moved_any || T_moving;
             const bool new_coll = (vflags & CAVOID_F_IN_COLL) != 0u && (T.flags & CAVOID_F_IN_COLL) == 0u;
             const bool restart = (ctl & 2u) != 0u;
@@ -360,7 +386,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             //  were known; nobody else changed)
             T = Tn;
             T_moving = mn;
-            tab_s = lds_tab[2 * act2]; tab_h = lds_tab[2 * act2 + 1];
+            tab_s = tab_s2; tab_h = tab_h2;
+            act_q = act3;
             relay_post(&seq->fin, t + 1);                  // slot t (state + verdict) is final: the consumers may take it
             RELAY_STAMP(3);                                // D: slot t final
         }
