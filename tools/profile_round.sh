@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: kernel-trace --stats of the bench commands (N = 4 and N = 10, default and the driver's
 # K = 20 form, the full loop), PMC traffic, and the sweep.  usage: bash tools/profile_round.sh <tag>   (on the GPU box)
-tag=${1:-r06_a}; out=$PWD/gpurun_out/prof_$tag; mkdir -p $out; repo=$PWD
+tag=${1:-r06_c}; out=$PWD/gpurun_out/prof_$tag; mkdir -p $out; repo=$PWD
 export TMPDIR=/tmp
 prof() {   # prof <name> <bench args...>
   name=$1; shift
