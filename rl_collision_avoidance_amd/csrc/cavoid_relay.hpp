@@ -23,6 +23,9 @@
 //                      times per step.
 //   L  (loader)        everything that touches memory inside the loop and is not an output: the action block (a 64-step
 //                      byte ring in LDS, filled ahead of D) and the next scenario-pool record of every restarted lane.
+//   D + P + L          (N >= 4) the observation of the LAST step, together: one neighbour slot in three each, the mapping of
+//                      cavoid_quad.hpp -- all three are idle once the last step is settled, and the launch's tail is one
+//                      observation latency behind that moment (relay_coop_last).
 //
 // Same arithmetic per value, in the same operation order, as env_kernel: outputs and state are bit-identical
 // (tests/test_gpu_packed.py, test_gpu_parity.py run through this kernel by default).  Synchronisation: sequence counters in
@@ -49,16 +52,32 @@ struct RelaySeq {                        // sequence counters (each written by e
     int nxt;                             // L: 1 + restart events served (1: the first pool records are in; then re-armed after every restart)
     int cons[kRelayMaxConsumers];        // C: steps < cons[c] of consumer c's share are flushed (ring slots free)
     int cfin[kRelayMaxConsumers];        // C: all of the consumer's stores have completed
-    int pad[1];
+    int coop[2];                         // D, P, L (the last step's observation, made together): arrivals at its two hand-overs (LDS atomics)
+    int kernarg[2];                      // ... and what they start from: the kernel-argument segment's address and the tile (written once, at entry)
+    int tile_id;
 };
-static_assert(sizeof(RelaySeq) % 8 == 0, "the event queue behind it holds 64-bit masks");
+static_assert(sizeof(RelaySeq) % 16 == 0, "the event queue behind it holds 64-bit masks; the tiles further on are read 16 bytes at a time");
 struct RelayTent { double px[64], py[64], vx[64], vy[64], heading[64]; float r[64], gx[64], gy[64], pref[64]; uint32_t flags[64]; };
 struct RelayRes { uint32_t flags[64], ctl[64]; float rew[64]; };                            // ctl: bit 0 done, bit 1 the lane's world restarts
 struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], gy[64], radius[64], pref[64]; uint32_t flags[64]; };
+// The LAST step's observation is made by three wavefronts together (D, P and L: all idle once the last step is settled), one
+// neighbour slot in three each -- the mapping of cavoid_quad.hpp -- instead of by the consumer whose turn it would be: the launch's
+// tail is one observation latency behind D's last iteration (profiles/r05_g_relay_launch_timeline.txt), and that latency is a
+// single wavefront's dependent chain.  From kRelayCoopFromN agents per world on (every wavefront has a neighbour to work on).
+constexpr int kRelayCoopWaves = 3;
+constexpr int kRelayCoopFromN = 4;
+template <int N>
+struct RelayCoop {                       // what the three hand each other: every neighbour's sort key and "seen" bit, by host lane
+    static constexpr int K = Others<N>::K;
+    uint64_t key[K][64];
+    uint32_t bits[K][64];
+};
+template <int N>
+__host__ __device__ constexpr size_t relay_coop_bytes() { return N >= kRelayCoopFromN ? sizeof(RelayCoop<N>) : 0; }
 template <int N>
 __host__ __device__ constexpr size_t relay_lds_fixed_bytes() {
     return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + kRelayRing * (sizeof(RelayTent) + sizeof(RelayRes)) +
-           sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long);
+           sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long) + relay_coop_bytes<N>();
 }
 
 // development build: lane 0 of a role stamps the shader clock of step n_steps/2 into g_trace[tile*32 + k] (tools/trace_relay.py)
@@ -213,6 +232,211 @@ __device__ __forceinline__ void relay_read_nxt(const RelayNxt &nb, int lane, Age
     nxt.speed = 0.0f;
 }
 
+
+// ---- the last step's observation by D, P and L together -----------------------------------------------------------------------------
+// a hand-over of the three: the arriving wavefront's LDS writes are issued before its count (LDS keeps a wavefront's order), the
+// others read behind the count; bounded like the consumers' waits (a wavefront that never arrives traps the launch)
+__device__ __forceinline__ void relay_coop_arrive(int *p, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    int polls = 0;
+    while (relay_peek(p) < kRelayCoopWaves) {
+        if (++polls > kRelayPollLimit) __builtin_trap();
+    }
+    asm volatile("" ::: "memory");
+}
+// pair_pass_impl's statements (FEAT form) for the neighbours o = pw, pw + 3, .. of the lane's agent: the square-root chain, the sort key
+// and the five features; key and "seen" bit into LDS for the other two wavefronts' ranking (cavoid_quad.hpp's quad_pair_round on the
+// relay's hand-over arrays; the collision test is P's and long done)
+template <int N, bool SW>
+__device__ __forceinline__ void relay_pair_part(const KCfg &c, const Agent &a, const Ego &e, const bool present, const ArrayStage<N> &st, const int pw,
+                                                const int lane, RelayCoop<N> &co, float (&gapf)[Others<N>::K], float (&feat)[Others<N>::K][kFeat]) {
+    const double ri = (double)a.radius;
+#pragma unroll
+    for (int o = 0; o < N - 1; ++o) {
+        if (o % kRelayCoopWaves != pw) continue;           // (wave-uniform)
+        const OtherState q = st.other(o);
+        const float rjf = q.r;
+        const double rx = q.px - a.px, ry = q.py - a.py;
+#if defined(CAVOID_DEV_ULP_FAULT) && CAVOID_DEV_ULP_FAULT == 1     /* the injected fault of pair_pass_impl, here too */
+        const double d = sqrt_dist2((double)((float)rx * (float)rx) + ry * ry);
+#else
+        const double d = sqrt_dist2(rx * rx + ry * ry);
+#endif
+        const bool other = present && (rjf >= 0.0f);
+        const bool seen = other && !(d > c.horizon);
+        const double gap_o = d - ri - (double)rjf;
+#if defined(CAVOID_DEV_ULP_FAULT) && CAVOID_DEV_ULP_FAULT == 3
+        uint32_t hi = kKeyBias - (uint32_t)(int)rintf((float)gap_o * 100.0f);
+#else
+        uint32_t hi = kKeyBias - (uint32_t)(int)rint(gap_o * 100.0);
+#endif
+        uint32_t lo = orderable((float)(ry * e.tx - rx * e.ty));
+        if (SW) {
+            if (c.switches & kSwIndexTie) lo = (uint32_t)other_index(st.i, o, N);
+            if (c.switches & kSwExactGap) { lo = 0u; hi = 0x7FFFFFFEu - (orderable((float)gap_o) >> 1); }
+        }
+        hi = seen ? hi : kKeySentinel + (uint32_t)o;
+        co.key[o][lane] = ((uint64_t)hi << 32) | lo;
+        co.bits[o][lane] = seen ? 2u : 0u;
+        gapf[o] = (float)gap_o;
+        neighbour_features(e, (float)e.prll_x, (float)e.prll_y, rx, ry, q, feat[o]);
+    }
+}
+// the tile's rows out of LDS by the three wavefronts (flush_tile with tid / nthreads for lane / 64)
+template <bool STREAM>
+__device__ __forceinline__ void relay_flush_part(const float *tile, float *dst, int n_floats, int tid, int nthreads) {
+    if ((n_floats & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(tile);
+        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+        const int n4 = n_floats >> 2;
+        for (int k0 = tid; k0 < n4; k0 += nthreads * 4) {       // up to 4 LDS reads in flight per lane, then the stores
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + nthreads * u;
+                v[u] = k < n4 ? src4[k] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + nthreads * u;
+                if (k < n4) store16<STREAM>(dst4 + k, v[u]);
+            }
+        }
+    } else {
+        for (int k = tid; k < n_floats; k += nthreads) dst[k] = tile[k];
+    }
+}
+
+
+// Everything the three need they derive again from the kernel arguments and their thread ids, starting from two words D left in LDS at
+// kernel entry (the argument segment's address, the tile): nothing of it stays live in scalar registers across the role loops above
+// (written inline it cost D's and P's loops 23 and 16 v_readlane of spilled scalars per iteration; even the argument pointer kept live
+// put one of D's sine / cosine constants into a spill lane).
+struct RelayArgs { KCfg c; KState s; const PoolRec *pool; KIO io; };      // the kernel's argument segment
+template <class T>
+__device__ __forceinline__ void relay_load_args(T &dst, const __attribute__((address_space(4))) T *src) {      // word by word from the constant address space
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    const __attribute__((address_space(4))) uint32_t *w = (const __attribute__((address_space(4))) uint32_t *)src;
+    uint32_t d[sizeof(T) / 4];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) d[k] = w[k];
+    __builtin_memcpy(&dst, d, sizeof(T));
+}
+template <int N>
+__device__ __forceinline__ void relay_coop_last(unsigned char *smem) {
+    unsigned char *sp = smem + lds_floats_block() * sizeof(float);
+    RelaySeq *seq = reinterpret_cast<RelaySeq *>(sp); sp += sizeof(RelaySeq) + kRelayEvq * sizeof(unsigned long long);
+    const unsigned long long kp = (unsigned long long)(uint32_t)relay_peek(&seq->kernarg[0]) | ((unsigned long long)(uint32_t)relay_peek(&seq->kernarg[1]) << 32);
+    typedef const __attribute__((address_space(4))) RelayArgs *ArgP;
+    const ArgP ka = (ArgP)kp;
+    KCfg c;
+    KIO io;
+    relay_load_args(c, &ka->c);                             // (scalar loads of the fields the observation uses)
+    relay_load_args(io, &ka->io);
+    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += kRelayRing * sizeof(RelayTent) + sizeof(RelayNxt);
+    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += kRelayRing * sizeof(RelayRes) + kRelayActRing * 64;
+    RelayCoop<N> *coopb = reinterpret_cast<RelayCoop<N> *>(sp); sp += relay_coop_bytes<N>();
+    float *tiles = reinterpret_cast<float *>(sp);
+    const int role = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    const int NC = (blockDim.x >> 6) - 3;
+    const int pw = role < 2 ? role : 2;                     // D 0, P 1, L 2
+    const int ostride = io.obs_stride;
+    const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
+    const int wpw = c.wpw, lanes_used = wpw * N;
+    const int64_t wave = relay_peek(&seq->tile_id);
+    const int64_t w0 = wave * wpw;
+    const int lw = lane0 / N, i0 = lane0 - lw * N;
+    const int64_t w = w0 + lw;
+    const bool active = lane0 < lanes_used && w < c.num_worlds;
+    const int base0 = lane0 < lanes_used ? lw * N : 0;
+    const int64_t a_idx0 = w * N + i0;
+    const bool packed = io.packed != 0;
+    int64_t worlds_here = c.num_worlds - w0;
+    if (worlds_here > wpw) worlds_here = wpw;
+    if (worlds_here < 0) worlds_here = 0;
+    const int n_steps = io.n_steps;
+    constexpr int K = Others<N>::K;
+    const int t = n_steps - 1;
+    const int cid_l = t % NC;                          // the tile of the consumer whose turn the step would have been
+    float *tile = tiles + (size_t)cid_l * tile_floats;
+    RelayCoop<N> &co = *coopb;
+    relay_wait_bounded(&seq->fin, t + 1);              // (D: its own post)
+    const RelayTent &f = tents[t & (kRelayRing - 1)];
+    const RelayRes &v = ress[t & (kRelayRing - 1)];
+    Agent ao;
+    ao.px = f.px[lane0]; ao.py = f.py[lane0]; ao.vx = f.vx[lane0]; ao.vy = f.vy[lane0];
+    ao.heading = f.heading[lane0]; ao.t_rem = 0.0;
+    ao.gx = f.gx[lane0]; ao.gy = f.gy[lane0]; ao.speed = 0.0f;
+    ao.radius = f.r[lane0]; ao.pref = f.pref[lane0]; ao.flags = v.flags[lane0];
+    const uint32_t ctl_c = v.ctl[lane0];
+    const float rew_c = v.rew[lane0], done_c = (ctl_c & 1u) ? 1.0f : 0.0f;
+    const bool present = active && (ao.flags & CAVOID_F_PRESENT);
+    const Ego e = ego_frame_obs(c, ao);
+    const ArrayStage<N> as{f.px, f.py, f.vx, f.vy, f.r, i0, base0};
+    float gapf[K], feat[K][kFeat];
+#pragma unroll
+    for (int o = 0; o < K; ++o) {
+        gapf[o] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kFeat; ++q) feat[o][q] = 0.0f;
+    }
+    if (c.switches != 0u) relay_pair_part<N, true>(c, ao, e, present, as, pw, lane0, co, gapf, feat);
+    else relay_pair_part<N, false>(c, ao, e, present, as, pw, lane0, co, gapf, feat);
+    relay_coop_arrive(&seq->coop[0], lane0);           // every neighbour's key is in LDS
+    Key key[K];
+    uint32_t valid = 0u;
+    if (N == 1) key[0].set(kKeySentinel, 0u);
+#pragma unroll
+    for (int o = 0; o < N - 1; ++o) {
+        key[o].v = co.key[o][lane0];
+        valid |= (co.bits[o][lane0] & 2u) ? (1u << o) : 0u;
+    }
+    if (t - NC >= 0) relay_wait_bounded(&seq->cons[cid_l], t - NC + 1);   // that consumer's last rows have left the tile
+    const int rows_active = (int)worlds_here * N;
+    // the ranking (every one of the three makes it, from the same keys) and this wavefront's neighbours into the rows
+    assemble_obs<N, false, true, ArrayStage<N>, NoHook, false, PartOthers>(c, ao, e, active, lane0, as, key, gapf, feat, valid, tile, nullptr,
+                                                                           rows_active, ostride, false, 0.0f, 0.0f, wave, NoHook(), false, nullptr,
+                                                                           PartOthers{pw, kRelayCoopWaves});
+    if (pw == 0 && active && lane0 < rows_active) {    // the head of the row and the empty slots (assemble_obs's statements)
+        const int M = c.max_other;
+        const int m = __popc(valid);
+        const int first = m > M ? m - M : 0;
+        const int kept = m - first;
+        float *row = tile + lane0 * ostride;
+        row[0] = (present && (ao.flags & CAVOID_F_LEARNING)) ? 1.0f : 0.0f;
+        row[1] = (float)kept;
+        row[2] = present ? (float)e.dist : 0.0f;
+        row[3] = present ? (float)e.heading_ego : 0.0f;
+        row[4] = present ? ao.pref : 0.0f;
+        row[5] = present ? ao.radius : 0.0f;
+        for (int sl = kept; sl < M; ++sl) {
+            float *z = row + 6 + 7 * sl;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) z[q] = 0.0f;
+        }
+        if (packed) { row[c.width] = rew_c; row[c.width + 1] = done_c; }
+    }
+    relay_coop_arrive(&seq->coop[1], lane0);           // the rows are in the tile
+    if (io.out_step_stride == 0)                       // one output buffer for every step: the last step's rows land last
+        for (int o = 0; o < NC; ++o) relay_wait_bounded(&seq->cfin[o], 1);
+    const int64_t slot_w = (int64_t)t * io.out_step_stride;
+    if (worlds_here > 0) {
+        float *dst = io.obs + (slot_w + w0) * N * ostride;
+        if (io.out_step_stride != 0) relay_flush_part<true>(tile, dst, rows_active * ostride, pw * 64 + lane0, 64 * kRelayCoopWaves);
+        else relay_flush_part<false>(tile, dst, rows_active * ostride, pw * 64 + lane0, 64 * kRelayCoopWaves);
+    }
+    if (pw == 0 && active) {                           // the step's plain outputs
+        if (!packed) {
+            io.rew[slot_w * N + a_idx0] = rew_c;
+            io.done[slot_w * N + a_idx0] = (ctl_c & 1u) ? 1 : 0;
+        }
+        if (i0 == 0) io.game_over[slot_w + w] = (ctl_c & 2u) ? 1 : 0;
+    }
+    if (pw == 0) RELAY_MARK(29);                           // D: its share of the last step's rows flushed
+}
+
 template <int N>
 __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -224,6 +448,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     RelayNxt *nbuf = reinterpret_cast<RelayNxt *>(sp); sp += sizeof(RelayNxt);
     RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += kRelayRing * sizeof(RelayRes);    // verdict of step t in slot t % ring
     unsigned char *actring = sp; sp += kRelayActRing * 64;
+    RelayCoop<N> *coopb = reinterpret_cast<RelayCoop<N> *>(sp); sp += relay_coop_bytes<N>();   // (N < kRelayCoopFromN: nothing, never touched)
     float *tiles = reinterpret_cast<float *>(sp);
 
     const int role = threadIdx.x >> 6;                     // 0 D, 1 P, 2 .. 1+NC consumers, 2+NC L (consecutive wavefronts land on different SIMDs)
@@ -244,8 +469,17 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     if (worlds_here > wpw) worlds_here = wpw;
     if (worlds_here < 0) worlds_here = 0;
     const int n_steps = io.n_steps;
+    constexpr bool kCoop = N >= kRelayCoopFromN;            // the last step's observation: D, P and L together (below the roles)
+    const bool coop_role = role < 2 || role == 2 + NC;      // (the consumers are still at their own steps when the last one is settled)
 
     if (role == 0 && lane0 < (int)(sizeof(RelaySeq) / sizeof(int))) reinterpret_cast<int *>(seq)[lane0] = 0;
+    if constexpr (kCoop) {
+        if (role == 0 && lane0 == 0) {                      // (behind the zeroes: the same wavefront's LDS writes, in order)
+            const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+            seq->kernarg[0] = (int)(uint32_t)kp; seq->kernarg[1] = (int)(uint32_t)(kp >> 32);
+            seq->tile_id = (int)blockIdx.x;
+        }
+    }
 
     if (role == 0) {
         // ================================================ D: state owner =====================================================
@@ -262,22 +496,25 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         uint32_t episode = 0u;
         double tab_v = 0.0;
         if (lane0 < 2 * c.num_actions) tab_v = c.action_table[lane0];
-        if (active) {
+        int act0 = 0;                                       // step 0's action: D's own load, the same trip to memory as the state (the
+        if (active) {                                       // loader's first batch is for steps 1..7 as far as D is concerned)
             episode = s.episode[w];
             load_agent(s, a_idx0, a);
+            act0 = io.actions[a_idx0];
         }
         lds_tab[lane0] = tab_v;
+        act0 = act0 < 0 ? 0 : (act0 >= c.num_actions ? c.num_actions - 1 : act0);     // (clamped like E4 does, like the loader)
         const bool present_first = active && (a.flags & CAVOID_F_PRESENT);
         bool restarted_any = false, moved_any = false;
-        __syncthreads();                                   // table, counters, the loader's first records and actions
-        RELAY_MARK(21);                                    // D: state, table and the first actions are in
         int events = 0;
         bool T_moving;
         Agent T;
-        {
-            const int act0 = (int)actring[lane0];
-            T = relay_advance(cd, trig, a, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
-        }
+        // the first advance runs IN FRONT of the workgroup barrier -- the table is this wavefront's own LDS write, the state and the
+        // action its own loads -- so the barrier (the loader's first batch in LDS) is waited for under it, not before it
+        wave_lds_sync();
+        T = relay_advance(cd, trig, a, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
+        __syncthreads();                                   // table, counters, the loader's first actions
+        RELAY_MARK(21);                                    // D: state, table and the first actions are in; step 0 advanced
         // the table row of the NEXT step's action is read one iteration ahead (two dependent LDS trips off the chain)
         double tab_s = 0.0, tab_h = 0.0;
         int act_q = 0;                                      // ... and the action INDEX of the step after that, two iterations ahead
@@ -587,7 +824,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         const int cid = role - 2;
         float *tile = tiles + (size_t)cid * tile_floats;
         __syncthreads();
-        for (int t = cid; t < n_steps; t += NC) {
+        const int n_mine = kCoop ? n_steps - 1 : n_steps;   // (kCoop: the last step's observation is D's, P's and L's)
+        for (int t = cid; t < n_mine; t += NC) {
             int lane = lane0, i = i0, base = base0;
             asm volatile("" : "+v"(lane), "+v"(i), "+v"(base));
             RELAY_STAMP(16);                               // C: waiting for final state t
@@ -638,6 +876,10 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         __builtin_amdgcn_s_waitcnt(0);                     // every store of this consumer has completed
         if (cid == 0) RELAY_MARK(30);                      // C0: its stores have completed
         relay_post(&seq->cfin[cid], 1);
+    }
+    // ================================================ D, P, L: the LAST step's observation, together =======================================
+    if constexpr (kCoop) {
+        if (coop_role) relay_coop_last<N>(smem);
     }
 }
 
