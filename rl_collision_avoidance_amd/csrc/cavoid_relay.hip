@@ -24,10 +24,18 @@ int cavoid_launch_relay(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t 
 #define CAVOID_RELAY_CASE(NN) \
     case NN: {                                                                                                          \
         int nc = e->relay_consumers;                                                                                    \
-        while (nc > 1 && relay_lds_fixed_bytes<NN>() + (size_t)nc * tile_floats * sizeof(float) > 65536) --nc;         \
+        while (nc > 1 && relay_lds_fixed_bytes<NN>() + (size_t)nc * tile_floats * sizeof(float) > kRelayLdsLimit) --nc; \
         const size_t lds = relay_lds_fixed_bytes<NN>() + (size_t)nc * tile_floats * sizeof(float);                      \
         /* one observation wavefront cannot keep up with the loop: the two-wavefront pipeline is the better form then */  \
-        if (lds > 65536 || (nc < 2 && e->relay_consumers >= 2)) return CAVOID_EUNSUPPORTED;                             \
+        if (lds > kRelayLdsLimit || (nc < 2 && e->relay_consumers >= 2)) return CAVOID_EUNSUPPORTED;                    \
+        if (lds > 65536) {                        /* beyond the default dynamic-LDS limit: opted into once per instantiation */ \
+            static size_t allowed = 0;                                                                                  \
+            if (allowed < lds) {                                                                                        \
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(env_relay_kernel<NN>),                       \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRelayLdsLimit));          \
+                allowed = kRelayLdsLimit;                                                                               \
+            }                                                                                                           \
+        }                                                                                                               \
         const dim3 block(64 * (3 + nc));                                                                                \
         if (ev_start || ev_stop)                                                                                        \
             hipExtLaunchKernelGGL((env_relay_kernel<NN>), grid, block, lds, s, ev_start, ev_stop, 0, k, e->st, e->pool, io);  \

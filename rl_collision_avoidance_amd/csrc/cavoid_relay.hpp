@@ -37,7 +37,14 @@
 namespace cavoid {
 
 constexpr int kRelayMaxAgents = 6;        // instantiated (and faster than the two-wavefront pipeline) up to this many agents per world
-constexpr int kRelayRing = 4;            // depth of the state / verdict rings (steps in flight between D, P and the consumers)
+// depth of the state / verdict rings (steps in flight between D, P and the consumers).  D takes slot (t + 1) % ring when the consumer of
+// step t + 1 - ring has flushed: with 4 slots an observation has 2 periods + D's advance to get from "final" to "flushed" -- 7.3 k clocks at
+// the 2.9 k period of N = 4, against a median observation of 6.3 k and a 90th percentile of 7.3 k: the slowest tiles' D waited for a slot,
+// and a shorter D iteration bought nothing.  8 slots (18 KB more LDS: two workgroups per CU still fit 160 KB up to N = 5) take the
+// consumers' LATENCY out of the period; what is left is their throughput (a third of an observation per step each).
+template <int N>
+__host__ __device__ constexpr int relay_ring() { return N <= 5 ? 8 : 4; }
+constexpr size_t kRelayLdsLimit = 80 * 1024;      // per workgroup: two of them resident per CU (160 KB)
 constexpr int kRelayActRing = 64;        // action ring: steps
 constexpr int kRelayActAhead = 48;       // the loader runs at most this many steps ahead of D
 constexpr int kRelayEvq = 8;             // restart-event queue D -> L
@@ -45,7 +52,7 @@ constexpr int kRelayEvq = 8;             // restart-event queue D -> L
 struct RelaySeq {                        // sequence counters (each written by exactly one wavefront)
     int spec;                            // D: the SPECULATIVE tentative state of steps < spec is in `tent` (nothing happened at the step before)
     int stage;                           // D: ... and corrected for the verdict of the step before (collisions, restarts)
-    int res;                             // P: verdicts of steps < res are in `res`
+    int res;                             // P: 2 * (verdicts posted: steps < that many are in `res`) + (the last one holds a surprise)
     int fin;                             // D: the state and verdict slots of steps < fin are final (restarted worlds patched in)
     int act;                             // L: actions of steps < act are in the ring
     int ev;                              // D: restart events posted (it has read the old records of the restarted lanes)
@@ -76,7 +83,7 @@ template <int N>
 __host__ __device__ constexpr size_t relay_coop_bytes() { return N >= kRelayCoopFromN ? sizeof(RelayCoop<N>) : 0; }
 template <int N>
 __host__ __device__ constexpr size_t relay_lds_fixed_bytes() {
-    return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + kRelayRing * (sizeof(RelayTent) + sizeof(RelayRes)) +
+    return (size_t)lds_floats_block() * sizeof(float) + sizeof(RelaySeq) + kRelayActRing * 64 + relay_ring<N>() * (sizeof(RelayTent) + sizeof(RelayRes)) +
            sizeof(RelayNxt) + kRelayEvq * sizeof(unsigned long long) + relay_coop_bytes<N>();
 }
 
@@ -153,6 +160,18 @@ __device__ __forceinline__ RelayTrig relay_trig_constants() {
                  "+s"(k.s6), "+s"(k.c1), "+s"(k.c2), "+s"(k.c3), "+s"(k.c4), "+s"(k.c5), "+s"(k.c6));
     return k;
 }
+// wrap_angle with its two folds made side by side instead of one behind the other (a value >= pi folded down lands in [-pi, pi): the
+// second fold never applies to it, and the first never to a value < -pi): the same result for every input, half the dependent length
+__device__ __forceinline__ double relay_wrap(double a, uint32_t switches) {
+    const double down = a - 2.0 * kPi, up = a + 2.0 * kPi;
+    double r = a < -kPi ? up : a;
+    r = a >= kPi ? down : r;
+    if (CAVOID_RARE(__ballot(r >= kPi || r < -kPi) != 0ull)) {
+        while (r >= kPi) r -= 2.0 * kPi;
+        while (r < -kPi) r += 2.0 * kPi;
+    }
+    return wrap_closed_fixup(r, switches);
+}
 __device__ __forceinline__ void relay_sincos(const RelayTrig &q, double x, double *sn, double *cs) {
     const double k = rint(x * q.two_over_pi);
     double r = __builtin_fma(-k, q.pio2_hi, x);
@@ -172,39 +191,55 @@ __device__ __forceinline__ void relay_sincos(const RelayTrig &q, double x, doubl
     pc = __builtin_fma(pc, z, q.c2);
     pc = __builtin_fma(pc, z, q.c1);
     const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    const int qd = (int)k & 3;
+    const int qd = (int)k;
     const double s_out = (qd & 1) ? c : s, c_out = (qd & 1) ? s : c;
-    *sn = (qd & 2) ? -s_out : s_out;
-    *cs = ((qd + 1) & 2) ? -c_out : c_out;
+    // (the quadrant's sign flips as an exclusive-or of the sign bit -- what a negation is -- instead of compare + select: two
+    //  vector-compare -> select hand-overs off the chain)
+    *sn = __longlong_as_double(__double_as_longlong(s_out) ^ ((long long)(qd & 2) << 62));
+    *cs = __longlong_as_double(__double_as_longlong(c_out) ^ ((long long)((qd + 1) & 2) << 62));
 }
 
 // One agent's step up to (not including) the pair pass: E4 decode, scripted policies 1 / 2, E5 unicycle dynamics, goal test,
 // time budget -- env_kernel's statements, value for value.
-__device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &trig, const Agent &in, double tab_speed, double tab_dh, bool active,
-                                               bool &moving) {
+// What an agent's step re-derives from values that change once per episode: kept in registers by D, re-made for the lanes of a restarted world
+struct RelayStatics {
+    double pref, gx, gy;                                   // the float32 statics widened once
+    float r_staged;                                        // what the consumers and P find as the radius: < 0 for an absent row
+};
+__device__ __forceinline__ RelayStatics relay_statics(const Agent &a, bool active) {
+    RelayStatics k;
+    k.pref = (double)a.pref; k.gx = (double)a.gx; k.gy = (double)a.gy;
+    k.r_staged = (active && (a.flags & CAVOID_F_PRESENT)) ? a.radius : -1.0f;
+    return k;
+}
+// tab_dh: the table's heading change ALREADY rounded through float32 when c.actions_fp32 (D converts the table once, at the prologue:
+// (double)(float)x of a table entry is the same value whether made there or here)
+__device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &trig, const Agent &in, const RelayStatics &ks, double tab_speed, double tab_dh,
+                                               bool active, bool &moving) {
     Agent a = in;
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
     const bool done_in = (flags_in & CAVOID_F_DONE_MASK) != 0u;
     const uint32_t pol = (flags_in >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK;
-    double a0 = (double)a.pref * tab_speed;               // the action's table row, read one step ahead by the caller
+    double a0 = ks.pref * tab_speed;                       // the action's table row, read one step ahead by the caller
     double a1 = tab_dh;
-    if (__ballot(present_in && !done_in && pol != 0u) != 0ull) {
+    if (CAVOID_RARE(__ballot(present_in && !done_in && pol != 0u) != 0ull)) {      // scripted agents in this tile
         if (pol == 1u) { a0 = 0.0; a1 = 0.0; }
         if (pol == 2u) {
             const Ego e0 = ego_frame_exact(c, a);
-            a0 = (double)a.pref;
+            a0 = ks.pref;
             a1 = -e0.heading_ego;
+            if (c.actions_fp32) a1 = (double)(float)a1;
         }
     }
-    if (c.actions_fp32) { a0 = (double)(float)a0; a1 = (double)(float)a1; }
+    if (c.actions_fp32) a0 = (double)(float)a0;
     moving = present_in && !done_in;
     double dh = a1;
-    if (c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN) {
+    if (CAVOID_RARE(c.dynamics == CAVOID_DYN_UNICYCLE_MAX_TURN)) {
         const double rate = fmin(fmax(dh / c.dt, -c.cold->max_turn_rate), c.cold->max_turn_rate);
         dh = rate * c.dt;
     }
-    const double nh = wrap_angle(dh + a.heading, c.switches);
+    const double nh = relay_wrap(dh + a.heading, c.switches);
     double sn, cs;
     relay_sincos(trig, nh, &sn, &cs);
     const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
@@ -216,7 +251,7 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &t
     latch |= (flags_in & CAVOID_F_AT_GOAL) ? CAVOID_F_WAS_AT_GOAL : 0u;
     latch |= (flags_in & CAVOID_F_IN_COLL) ? CAVOID_F_WAS_IN_COLL : 0u;
     a.flags |= (present_in && done_in) ? latch : 0u;
-    const double dx = a.px - (double)a.gx, dy = a.py - (double)a.gy;
+    const double dx = a.px - ks.gx, dy = a.py - ks.gy;
     a.flags |= (moving && dx * dx + dy * dy <= c.near_goal_sq) ? CAVOID_F_AT_GOAL : 0u;
     const double t_next = a.t_rem - c.dt;
     a.t_rem = moving ? t_next : a.t_rem;
@@ -335,8 +370,8 @@ __device__ __forceinline__ void relay_coop_last(unsigned char *smem) {
     KIO io;
     relay_load_args(c, &ka->c);                             // (scalar loads of the fields the observation uses)
     relay_load_args(io, &ka->io);
-    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += kRelayRing * sizeof(RelayTent) + sizeof(RelayNxt);
-    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += kRelayRing * sizeof(RelayRes) + kRelayActRing * 64;
+    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += relay_ring<N>() * sizeof(RelayTent) + sizeof(RelayNxt);
+    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += relay_ring<N>() * sizeof(RelayRes) + kRelayActRing * 64;
     RelayCoop<N> *coopb = reinterpret_cast<RelayCoop<N> *>(sp); sp += relay_coop_bytes<N>();
     float *tiles = reinterpret_cast<float *>(sp);
     const int role = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
@@ -363,8 +398,8 @@ __device__ __forceinline__ void relay_coop_last(unsigned char *smem) {
     float *tile = tiles + (size_t)cid_l * tile_floats;
     RelayCoop<N> &co = *coopb;
     relay_wait_bounded(&seq->fin, t + 1);              // (D: its own post)
-    const RelayTent &f = tents[t & (kRelayRing - 1)];
-    const RelayRes &v = ress[t & (kRelayRing - 1)];
+    const RelayTent &f = tents[t & (relay_ring<N>() - 1)];
+    const RelayRes &v = ress[t & (relay_ring<N>() - 1)];
     Agent ao;
     ao.px = f.px[lane0]; ao.py = f.py[lane0]; ao.vx = f.vx[lane0]; ao.vy = f.vy[lane0];
     ao.heading = f.heading[lane0]; ao.t_rem = 0.0;
@@ -444,9 +479,9 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     double *lds_tab = reinterpret_cast<double *>(sp); sp += lds_floats_block() * sizeof(float);
     RelaySeq *seq = reinterpret_cast<RelaySeq *>(sp); sp += sizeof(RelaySeq);
     unsigned long long *evq = reinterpret_cast<unsigned long long *>(sp); sp += kRelayEvq * sizeof(unsigned long long);
-    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += kRelayRing * sizeof(RelayTent);   // state of step t in slot t % ring
+    RelayTent *tents = reinterpret_cast<RelayTent *>(sp); sp += relay_ring<N>() * sizeof(RelayTent);   // state of step t in slot t % ring
     RelayNxt *nbuf = reinterpret_cast<RelayNxt *>(sp); sp += sizeof(RelayNxt);
-    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += kRelayRing * sizeof(RelayRes);    // verdict of step t in slot t % ring
+    RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += relay_ring<N>() * sizeof(RelayRes);    // verdict of step t in slot t % ring
     unsigned char *actring = sp; sp += kRelayActRing * 64;
     RelayCoop<N> *coopb = reinterpret_cast<RelayCoop<N> *>(sp); sp += relay_coop_bytes<N>();   // (N < kRelayCoopFromN: nothing, never touched)
     float *tiles = reinterpret_cast<float *>(sp);
@@ -502,6 +537,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             load_agent(s, a_idx0, a);
             act0 = io.actions[a_idx0];
         }
+        if (cd.actions_fp32 && (lane0 & 1)) tab_v = (double)(float)tab_v;   // the heading-change column, rounded through float32 ONCE (relay_advance)
         lds_tab[lane0] = tab_v;
         act0 = act0 < 0 ? 0 : (act0 >= c.num_actions ? c.num_actions - 1 : act0);     // (clamped like E4 does, like the loader)
         const bool present_first = active && (a.flags & CAVOID_F_PRESENT);
@@ -512,7 +548,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         // the first advance runs IN FRONT of the workgroup barrier -- the table is this wavefront's own LDS write, the state and the
         // action its own loads -- so the barrier (the loader's first batch in LDS) is waited for under it, not before it
         wave_lds_sync();
-        T = relay_advance(cd, trig, a, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
+        RelayStatics ks = relay_statics(a, active);
+        T = relay_advance(cd, trig, a, ks, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
         __syncthreads();                                   // table, counters, the loader's first actions
         RELAY_MARK(21);                                    // D: state, table and the first actions are in; step 0 advanced
         // the table row of the NEXT step's action is read one iteration ahead (two dependent LDS trips off the chain)
@@ -523,13 +560,12 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             tab_s = lds_tab[2 * actn]; tab_h = lds_tab[2 * actn + 1];
             if (n_steps > 2) act_q = (int)actring[2 * 64 + lane0];
         }
-        auto stage_out = [&](RelayTent &tn, const Agent &x, int lane) {
-            const bool present = active && (x.flags & CAVOID_F_PRESENT);
-            tn.px[lane] = x.px; tn.py[lane] = x.py; tn.r[lane] = present ? x.radius : -1.0f; tn.flags[lane] = x.flags;
+        auto stage_out = [&](RelayTent &tn, const Agent &x, float r_staged, int lane) {   // r_staged: relay_statics of x's episode
+            tn.px[lane] = x.px; tn.py[lane] = x.py; tn.r[lane] = r_staged; tn.flags[lane] = x.flags;
             tn.vx[lane] = x.vx; tn.vy[lane] = x.vy; tn.heading[lane] = x.heading;
             tn.gx[lane] = x.gx; tn.gy[lane] = x.gy; tn.pref[lane] = x.pref;
         };
-        stage_out(tents[0], T, lane0);
+        stage_out(tents[0], T, ks.r_staged, lane0);
         relay_post(&seq->spec, 1);
         relay_post(&seq->stage, 1);
         RELAY_MARK(22);                                    // D: step 0 posted
@@ -541,14 +577,14 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             RELAY_STAMP(0);                                // D: iteration begins (stage t posted)
             // ---- the successor of step t as if nothing happens at t, while P works on step t: posted at once, P takes it as it
             //      is when its own verdict says so (no new collision, no restart in the tile) ---------------------------------
-            RelayTent &tn = tents[(t + 1) & (kRelayRing - 1)];
+            RelayTent &tn = tents[(t + 1) & (relay_ring<N>() - 1)];
             const double tab_s1 = tab_s, tab_h1 = tab_h;    // action(t+1)'s row
             const int act2 = act_q;                        // action(t+2)'s index, read one iteration ago (0 past the end: a valid row, unused)
             int act3 = 0;                                   // action(t+3)'s, for the next iteration: the ring read lands under the advance
             if (t + 3 < n_steps) {
                 // (the loader's first batch is 8 steps -- iterations 0..3 read steps 3..6 --, from iteration 4 on every eighth iteration makes
                 //  sure of the next eight reads; the loader runs up to 48 steps ahead of `fin`)
-                if ((t & 7) == 4) relay_wait(&seq->act, t + 12 < n_steps ? t + 12 : n_steps);
+                if (CAVOID_RARE((t & 7) == 4)) relay_wait(&seq->act, t + 12 < n_steps ? t + 12 : n_steps);
                 act3 = (int)actring[((t + 3) & (kRelayActRing - 1)) * 64 + lane];
             }
             // Round 6: this iteration is the launch's period (P idles a third of it), and five LDS round trips sat bare on it -- the action ring,
@@ -556,35 +592,35 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             // iteration ahead (above); the table row and the slot counter are ISSUED here, in front of the advance, and looked at behind it;
             // the verdict's words are read right behind its counter (LDS returns a wavefront's reads in order: a counter that says "posted"
             // vouches for the words read after it)
-            const bool need_slot = t + 1 >= kRelayRing;    // slot free: the consumer of step t+1-ring is done with it
+            const bool need_slot = t + 1 >= relay_ring<N>();    // slot free: the consumer of step t+1-ring is done with it
             const int cons_early = need_slot ? relay_peek_issue(&seq->cons[cslot]) : 0;
             const double tab_s2 = *(relay_lds_f64 *)&lds_tab[2 * act2], tab_h2 = *(relay_lds_f64 *)&lds_tab[2 * act2 + 1];
             bool mn;
-            Agent Tn = relay_advance(cd, trig, T, tab_s1, tab_h1, active, mn);
+            Agent Tn = relay_advance(cd, trig, T, ks, tab_s1, tab_h1, active, mn);
             if (need_slot) {
-                if (relay_seen(cons_early) < t + 2 - kRelayRing) relay_wait(&seq->cons[cslot], t + 2 - kRelayRing);
+                if (CAVOID_RARE(relay_seen(cons_early) < t + 2 - relay_ring<N>())) relay_wait(&seq->cons[cslot], t + 2 - relay_ring<N>());
                 cslot = cslot + 1 == NC ? 0 : cslot + 1;
             }
-            stage_out(tn, Tn, lane);
+            const int res_early = relay_peek_issue(&seq->res);   // P's counter for step t: the trip runs under the staging writes
+            stage_out(tn, Tn, ks.r_staged, lane);
             relay_post(&seq->spec, t + 2);
             RELAY_STAMP(1);                                // D: successor computed and posted
-            // ---- P's verdict on step t -----------------------------------------------------------------------------------
-            RelayRes *res = &ress[t & (kRelayRing - 1)];
-            uint32_t vflags, ctl;
-            for (;;) {                                      // counter, then the words, in ONE trip
-                const int posted = relay_peek_issue(&seq->res);
-                vflags = *(relay_lds_u32 *)&res->flags[lane];
-                ctl = *(relay_lds_u32 *)&res->ctl[lane];
-                if (relay_seen(posted) >= t + 1) break;
-            }
+            // ---- P's verdict on step t: ONE word -- 2 * (steps posted) + "the last of them holds a surprise" (a new collision, a
+            //      restart: P's own test).  P is at most one step ahead of this point, and only behind a step WITHOUT a surprise (else it
+            //      waits for the corrected state): a count beyond t + 1 says "none at t".  The verdict's words are read only when there
+            //      is one: without a surprise they are T's own flags, and nobody restarts ---------------------------------------------
+            RelayRes *res = &ress[t & (relay_ring<N>() - 1)];
+            int posted = relay_seen(res_early);
+            if (CAVOID_RARE((posted >> 1) < t + 1))          // (P is ahead of D in the steady state: the early read has it)
+                do posted = relay_peek(&seq->res); while ((posted >> 1) < t + 1);
             asm volatile("" ::: "memory");
             RELAY_STAMP(2);                                // D: verdict arrived
             moved_any = moved_any || T_moving;
-            const bool new_coll = (vflags & CAVOID_F_IN_COLL) != 0u && (T.flags & CAVOID_F_IN_COLL) == 0u;
-            const bool restart = (ctl & 2u) != 0u;
-            const unsigned long long rmask = __ballot(restart);
-            const bool surprise = __ballot(new_coll || restart) != 0ull;       // the same test P makes on its own verdict
-            if (surprise) {
+            const bool surprise = (posted >> 1) == t + 1 && (posted & 1) != 0;
+            if (CAVOID_RARE(surprise)) {
+                const uint32_t vflags = *(relay_lds_u32 *)&res->flags[lane], ctl = *(relay_lds_u32 *)&res->ctl[lane];
+                const bool restart = (ctl & 2u) != 0u;
+                const unsigned long long rmask = __ballot(restart);
                 Agent S = T;                               // the committed state of step t
                 S.flags = vflags;
                 if (rmask != 0ull) {                       // some world of the tile starts a new episode
@@ -592,10 +628,11 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     Agent nx;
                     relay_read_nxt(*nbuf, lane, nx);
                     bool mr;
-                    const Agent Tr = relay_advance(cd, trig, nx, tab_s1, tab_h1, active, mr);
+                    const RelayStatics ksn = relay_statics(nx, active);
+                    const Agent Tr = relay_advance(cd, trig, nx, ksn, tab_s1, tab_h1, active, mr);
                     if (restart) {
-                        S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr;
-                        stage_out(tents[t & (kRelayRing - 1)], nx, lane);       // the consumers see step t's FINAL state: the new episode
+                        S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr; ks = ksn;
+                        stage_out(tents[t & (relay_ring<N>() - 1)], nx, ksn.r_staged, lane);   // the consumers see step t's FINAL state: the new episode
                         res->flags[lane] = nx.flags;
                     }
                 }
@@ -610,7 +647,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 Tn.vx = frozen ? 0.0 : Tn.vx; Tn.vy = frozen ? 0.0 : Tn.vy; Tn.speed = frozen ? 0.0f : Tn.speed;
                 Tn.flags = frozen ? fflags : Tn.flags;      // (gx, gy, radius, pref: per-episode constants, S's == Tn's)
                 mn = frozen ? false : mn;
-                stage_out(tn, Tn, lane);                   // the posted successor was wrong for some lane
+                stage_out(tn, Tn, ks.r_staged, lane);      // the posted successor was wrong for some lane
                 relay_post(&seq->stage, t + 2);
                 if (rmask != 0ull) {                       // tell the loader which lanes need their next pool record
                     relay_wait(&seq->nxt, events + 1 - (kRelayEvq - 1));
@@ -632,8 +669,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         Agent S = T;
         {
             const int t = n_steps - 1;
-            relay_spin(&seq->res, t + 1);
-            RelayRes *res = &ress[t & (kRelayRing - 1)];
+            relay_spin(&seq->res, 2 * (t + 1));
+            RelayRes *res = &ress[t & (relay_ring<N>() - 1)];
             const uint32_t vflags = res->flags[lane0], ctl = res->ctl[lane0];
             moved_any = moved_any || T_moving;
             S.flags = vflags;
@@ -644,7 +681,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                 relay_read_nxt(*nbuf, lane0, nx);
                 if (restart) {
                     S = nx; episode += 1u; restarted_any = true;
-                    stage_out(tents[t & (kRelayRing - 1)], nx, lane0);
+                    stage_out(tents[t & (relay_ring<N>() - 1)], nx, relay_statics(nx, active).r_staged, lane0);
                     res->flags[lane0] = nx.flags;
                 }
             }
@@ -689,7 +726,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             if (prev_surprise) relay_spin(&seq->stage, t + 1);
             else relay_spin(&seq->spec, t + 1);
             RELAY_STAMP(9);                                // P: stage t arrived
-            const RelayTent *tent = &tents[t & (kRelayRing - 1)];
+            const RelayTent *tent = &tents[t & (relay_ring<N>() - 1)];
             Agent a;
             a.px = tent->px[lane]; a.py = tent->py[lane];
             a.radius = tent->r[lane];
@@ -733,13 +770,13 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const bool game_over = (running & wmask) == 0ull;
             const bool restart = active && game_over;
             const float rew_f = (float)r;
-            RelayRes *res = &ress[t & (kRelayRing - 1)];
+            RelayRes *res = &ress[t & (relay_ring<N>() - 1)];
             res->flags[lane] = flags;
             res->ctl[lane] = (done ? 1u : 0u) | (restart ? 2u : 0u);
             res->rew[lane] = rew_f;
-            relay_post(&seq->res, t + 1);
             const bool new_coll = (flags & CAVOID_F_IN_COLL) != 0u && (flags_t & CAVOID_F_IN_COLL) == 0u;
             prev_surprise = __ballot(new_coll || restart) != 0ull;
+            relay_post(&seq->res, 2 * (t + 1) + (prev_surprise ? 1 : 0));    // (D reads the verdict's words only behind a surprise)
             RELAY_STAMP(10);                               // P: verdict posted (the plain outputs go out with the consumer's rows)
         }
     } else if (role == 2 + NC) {
@@ -831,8 +868,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             RELAY_STAMP(16);                               // C: waiting for final state t
             relay_wait_bounded(&seq->fin, t + 1);
             RELAY_STAMP(17);                               // C: arrived
-            const RelayTent &f = tents[t & (kRelayRing - 1)];
-            const RelayRes &v = ress[t & (kRelayRing - 1)];
+            const RelayTent &f = tents[t & (relay_ring<N>() - 1)];
+            const RelayRes &v = ress[t & (relay_ring<N>() - 1)];
             Agent ao;
             ao.px = f.px[lane]; ao.py = f.py[lane]; ao.vx = f.vx[lane]; ao.vy = f.vy[lane];
             ao.heading = f.heading[lane]; ao.t_rem = 0.0;
