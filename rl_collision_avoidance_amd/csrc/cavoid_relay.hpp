@@ -67,6 +67,19 @@ static_assert(sizeof(RelaySeq) % 16 == 0, "the event queue behind it holds 64-bi
 struct RelayTent { double px[64], py[64], vx[64], vy[64], heading[64]; float r[64], gx[64], gy[64], pref[64]; uint32_t flags[64]; };
 struct RelayRes { uint32_t flags[64], ctl[64]; float rew[64]; };                            // ctl: bit 0 done, bit 1 the lane's world restarts
 struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], gy[64], radius[64], pref[64]; uint32_t flags[64]; };
+// Which wavefront of the workgroup carries which role (0 D, 1 P, 2 .. 1+NC consumers, 2+NC L).  Wavefront w of a workgroup lands on SIMD
+// (first + w) % 4 and the next workgroup of the CU goes on where this one ended (tools/ubench/wave_placement.hip): with six wavefronts per
+// workgroup and two workgroups per CU the EVEN wavefronts of both tiles share two SIMDs and the odd ones the other two.  Once the rings
+// no longer hid it (relay_ring), the placement is worth +-10 % (profiles/r06_u_relay_role_order_ab.txt, r06_v): best is D, P and one
+// consumer on the even wavefronts -- each D beside the OTHER tile's P -- and the loader with two consumers on the odd ones (-2 % against
+// the plain order D P C0 C1 C2 L; P beside two consumers +12 %; D beside its own P +1 %; padding wavefronts that shift the pattern 0 %).
+#ifndef CAVOID_RELAY_ORDER
+#define CAVOID_RELAY_ORDER 0x432150      /* one nibble per wavefront, wavefront 0 lowest: D L P C0 C1 C2 */
+#endif
+__device__ __forceinline__ int relay_role_of(int wv, int NC) {
+    if (NC == 3) return (int)(((unsigned)CAVOID_RELAY_ORDER >> (4 * wv)) & 15u);
+    return wv;                                              // (other consumer counts: the plain order)
+}
 // The LAST step's observation is made by three wavefronts together (D, P and L: all idle once the last step is settled), one
 // neighbour slot in three each -- the mapping of cavoid_quad.hpp -- instead of by the consumer whose turn it would be: the launch's
 // tail is one observation latency behind D's last iteration (profiles/r05_g_relay_launch_timeline.txt), and that latency is a
@@ -374,8 +387,9 @@ __device__ __forceinline__ void relay_coop_last(unsigned char *smem) {
     RelayRes *ress = reinterpret_cast<RelayRes *>(sp); sp += relay_ring<N>() * sizeof(RelayRes) + kRelayActRing * 64;
     RelayCoop<N> *coopb = reinterpret_cast<RelayCoop<N> *>(sp); sp += relay_coop_bytes<N>();
     float *tiles = reinterpret_cast<float *>(sp);
-    const int role = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     const int NC = (blockDim.x >> 6) - 3;
+    const int role = relay_role_of(threadIdx.x >> 6, NC);
     const int pw = role < 2 ? role : 2;                     // D 0, P 1, L 2
     const int ostride = io.obs_stride;
     const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
@@ -486,8 +500,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     RelayCoop<N> *coopb = reinterpret_cast<RelayCoop<N> *>(sp); sp += relay_coop_bytes<N>();   // (N < kRelayCoopFromN: nothing, never touched)
     float *tiles = reinterpret_cast<float *>(sp);
 
-    const int role = threadIdx.x >> 6;                     // 0 D, 1 P, 2 .. 1+NC consumers, 2+NC L (consecutive wavefronts land on different SIMDs)
     const int NC = (blockDim.x >> 6) - 3;
+    const int role = relay_role_of(threadIdx.x >> 6, NC);   // 0 D, 1 P, 2 .. 1+NC consumers, 2+NC L
     const int lane0 = threadIdx.x & 63;
     const int ostride = io.obs_stride;
     const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
