@@ -631,10 +631,30 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (a compile-time choice per flush: behind a run-time flag per store the optimiser merges the two stores of the diamond into one
 //  plain store)
+// CAVOID_STREAM_POLICY (per translation unit: every function here is inlined into that unit's kernels): the cache policy of those stores.
+// 0: `nt` -- the compiler's non-temporal store; the line stays DIRTY in the XCD's L2 until it is evicted or the launch's end-of-kernel release
+// writes it back.  1 / 2 / 3: write-through (`sc1`, `sc0 sc1`, `sc0 sc1 nt`): the bytes leave for memory when the store is made and the line
+// is dropped, nothing waits for the release.  env_relay_kernel at 4 x 8192, 20-step launches with per-step slots, same box: nt 31.06 us,
+// plain 31.76, sc1 29.60, sc0 sc1 30.06, sc0 sc1 nt 29.84; 64-step launches: no difference (profiles/r06_x_relay_deal_store.txt).
+#ifndef CAVOID_STREAM_POLICY
+#define CAVOID_STREAM_POLICY 0
+#endif
 template <bool STREAM>
 __device__ __forceinline__ void store16(float4 *p, const float4 &v) {
-    if (CAVOID_NT_STORES && STREAM) __builtin_nontemporal_store(f32x4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v *>(p));
-    else *p = v;
+    if (CAVOID_NT_STORES && STREAM) {
+        const f32x4v x{v.x, v.y, v.z, v.w};
+#if CAVOID_STREAM_POLICY == 1
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+#elif CAVOID_STREAM_POLICY == 2
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+#elif CAVOID_STREAM_POLICY == 3
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(x) : "memory");
+#else
+        __builtin_nontemporal_store(x, reinterpret_cast<f32x4v *>(p));
+#endif
+    } else {
+        *p = v;
+    }
 }
 template <bool STREAM = false>
 __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_floats, int lane) {

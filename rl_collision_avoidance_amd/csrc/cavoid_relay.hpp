@@ -76,6 +76,28 @@ struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], g
 #ifndef CAVOID_RELAY_ORDER
 #define CAVOID_RELAY_ORDER 0x432150      /* one nibble per wavefront, wavefront 0 lowest: D L P C0 C1 C2 */
 #endif
+// Issue priority of the roles (s_setprio: a SIMD's arbiter takes the ready wavefront of the highest priority).  D and P carry the loop-carried
+// cycle and stay on top; the consumers ABOVE the loader (it only polls between its rare refills) is worth -1.4 % (K = 20) / -2.4 % (K = 64)
+// against consumers 0 / loader 1; P or D one level down +-0.5 %; no priorities at all +4 ... +6 % (profiles/r06_w_relay_prio_ablation.txt).
+#ifndef CAVOID_RELAY_PRIO_D
+#define CAVOID_RELAY_PRIO_D 3
+#endif
+#ifndef CAVOID_RELAY_PRIO_P
+#define CAVOID_RELAY_PRIO_P 3
+#endif
+#ifndef CAVOID_RELAY_PRIO_L
+#define CAVOID_RELAY_PRIO_L 0
+#endif
+#ifndef CAVOID_RELAY_PRIO_C
+#define CAVOID_RELAY_PRIO_C 1
+#endif
+// development: timing-only ablations of the roles (WRONG results; profiles/r06_w_relay_prio_ablation.txt): 1 the consumers make no observation
+// (they only free their ring slots), 2 P's distance loop left out, 4 D's advance without its sine / cosine, 8 D never waits for P's verdict and
+// nobody acts on a surprise (the loop-carried cycle cut: what unbounded speculation would run at), 16 D waits for the verdict of the step BEFORE
+// the one it waits for now (the timing of a speculation two steps deep)
+#ifndef CAVOID_RELAY_ABL
+#define CAVOID_RELAY_ABL 0
+#endif
 __device__ __forceinline__ int relay_role_of(int wv, int NC) {
     if (NC == 3) return (int)(((unsigned)CAVOID_RELAY_ORDER >> (4 * wv)) & 15u);
     return wv;                                              // (other consumer counts: the plain order)
@@ -254,7 +276,8 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &t
     }
     const double nh = relay_wrap(dh + a.heading, c.switches);
     double sn, cs;
-    relay_sincos(trig, nh, &sn, &cs);
+    if (CAVOID_RELAY_ABL & 4) { sn = nh; cs = 1.0; }
+    else relay_sincos(trig, nh, &sn, &cs);
     const double npx = a.px + a0 * cs * c.dt, npy = a.py + a0 * sn * c.dt;
     const double nvx = a0 * cs, nvy = a0 * sn, nsp = a0;
     a.px = moving ? npx : a.px; a.py = moving ? npy : a.py; a.heading = moving ? nh : a.heading;
@@ -532,7 +555,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
 
     if (role == 0) {
         // ================================================ D: state owner =====================================================
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(CAVOID_RELAY_PRIO_D);
         RELAY_MARK(20);                                    // D: kernel entry
         KCfg cd = c;                                        // this role's constants, pinned in scalar registers (see P)
         asm volatile("" : "+s"(cd.dt), "+s"(cd.near_goal_sq), "+s"(cd.actions_fp32), "+s"(cd.dynamics),
@@ -625,12 +648,13 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             //      is one: without a surprise they are T's own flags, and nobody restarts ---------------------------------------------
             RelayRes *res = &ress[t & (relay_ring<N>() - 1)];
             int posted = relay_seen(res_early);
-            if (CAVOID_RARE((posted >> 1) < t + 1))          // (P is ahead of D in the steady state: the early read has it)
-                do posted = relay_peek(&seq->res); while ((posted >> 1) < t + 1);
+            if (CAVOID_RELAY_ABL & 8) posted = 2 * (t + 2);
+            if (CAVOID_RARE((posted >> 1) < t + 1 - ((CAVOID_RELAY_ABL & 16) ? 1 : 0)))   // (P is ahead of D in the steady state: the early read has it)
+                do posted = relay_peek(&seq->res); while ((posted >> 1) < t + 1 - ((CAVOID_RELAY_ABL & 16) ? 1 : 0));
             asm volatile("" ::: "memory");
             RELAY_STAMP(2);                                // D: verdict arrived
             moved_any = moved_any || T_moving;
-            const bool surprise = (posted >> 1) == t + 1 && (posted & 1) != 0;
+            const bool surprise = !(CAVOID_RELAY_ABL & 24) && (posted >> 1) == t + 1 && (posted & 1) != 0;
             if (CAVOID_RARE(surprise)) {
                 const uint32_t vflags = *(relay_lds_u32 *)&res->flags[lane], ctl = *(relay_lds_u32 *)&res->ctl[lane];
                 const bool restart = (ctl & 2u) != 0u;
@@ -717,7 +741,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         RELAY_MARK(24);                                    // D: write-back issued
     } else if (role == 1) {
         // ================================================ P: pair pass, rewards, done ==========================================
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(CAVOID_RELAY_PRIO_P);
         // the constants of this role, pinned in scalar registers for the whole loop (left to itself the compiler re-loads
         // them from the kernel-argument segment inside the reward branches: seven scalar loads + waits on the loop-carried chain)
         KCfg cp = c;
@@ -754,7 +778,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const double ri = (double)a.radius;
             RELAY_STAMP(12);                               // P: own state read
 #pragma unroll
-            for (int o = 0; o < N - 1; ++o) {
+            for (int o = 0; o < ((CAVOID_RELAY_ABL & 2) ? 0 : N - 1); ++o) {
                 const int j = base + other_index(i, o, N);
                 const float rjf = tent->r[j];
                 const double rx = tent->px[j] - a.px, ry = tent->py[j] - a.py;
@@ -789,13 +813,13 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             res->ctl[lane] = (done ? 1u : 0u) | (restart ? 2u : 0u);
             res->rew[lane] = rew_f;
             const bool new_coll = (flags & CAVOID_F_IN_COLL) != 0u && (flags_t & CAVOID_F_IN_COLL) == 0u;
-            prev_surprise = __ballot(new_coll || restart) != 0ull;
+            prev_surprise = !(CAVOID_RELAY_ABL & 24) && __ballot(new_coll || restart) != 0ull;
             relay_post(&seq->res, 2 * (t + 1) + (prev_surprise ? 1 : 0));    // (D reads the verdict's words only behind a surprise)
             RELAY_STAMP(10);                               // P: verdict posted (the plain outputs go out with the consumer's rows)
         }
     } else if (role == 2 + NC) {
         // ================================================ L: actions and pool records ==========================================
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(CAVOID_RELAY_PRIO_L);
         RELAY_MARK(25);                                    // L: kernel entry
         uint32_t ep = 0u;
         if (active) ep = s.episode[w];
@@ -869,7 +893,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         }
     } else {
         // ================================================ C: observation of every NC-th step ===================================
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(CAVOID_RELAY_PRIO_C);
         KCfg cc = c;                                        // this role's switch word, pinned like the other roles' constants
         asm volatile("" : "+s"(cc.switches));
         const int cid = role - 2;
@@ -882,6 +906,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             RELAY_STAMP(16);                               // C: waiting for final state t
             relay_wait_bounded(&seq->fin, t + 1);
             RELAY_STAMP(17);                               // C: arrived
+            if (CAVOID_RELAY_ABL & 1) { relay_post(&seq->cons[cid], t + 1); continue; }
             const RelayTent &f = tents[t & (relay_ring<N>() - 1)];
             const RelayRes &v = ress[t & (relay_ring<N>() - 1)];
             Agent ao;
