@@ -643,12 +643,15 @@ template <bool STREAM>
 __device__ __forceinline__ void store16(float4 *p, const float4 &v) {
     if (CAVOID_NT_STORES && STREAM) {
         const f32x4v x{v.x, v.y, v.z, v.w};
+        // (inline assembly: the compiler has no cache-policy argument for a plain vector store.  It does not see the instruction, so its hazard
+        //  recogniser cannot keep the two wait states gfx940+ wants between a store of more than 64 bits and a vector write of its DATA
+        //  registers -- and it does re-use them at once, as the next store's address: the s_nop is that distance, made by hand)
 #if CAVOID_STREAM_POLICY == 1
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #elif CAVOID_STREAM_POLICY == 2
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #elif CAVOID_STREAM_POLICY == 3
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(x) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #else
         __builtin_nontemporal_store(x, reinterpret_cast<f32x4v *>(p));
 #endif
