@@ -19,9 +19,6 @@ int cavoid_launch_relay(cavoid_env *e, const KIO &io, hipStream_t s, hipEvent_t 
     // every tile's workgroup must be resident at once (256 CUs x 2 workgroups): beyond that the tiles run in rounds
     // (measured with 1024 tiles, N = 4: 3.87 vs 2.50 us per step for the two-wavefront pipeline; 1366 tiles, N = 10: 25 vs 8.3)
     if (tiles > 512) return CAVOID_EUNSUPPORTED;
-#if CAVOID_RELAY_DEPTH == 2
-    if (io.n_steps >= 32768) return CAVOID_EUNSUPPORTED;               // (the state counter carries epoch * 65536 + states posted)
-#endif
     // wide rows make the observation wavefronts the limit (and N >= 9 spills): measured at 512 tiles, us per step, this kernel /
     // env_pipe_kernel: N = 2 1.42 / 1.97, 3 1.53 / 2.33, 5 1.86 / 2.91, 6 3.11 / 3.29, 8 4.35 / 3.88, 10 8.85 / 4.80
     if (e->cfg.max_agents > kRelayMaxAgents) return CAVOID_EUNSUPPORTED;

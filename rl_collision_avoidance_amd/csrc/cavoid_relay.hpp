@@ -91,10 +91,6 @@ struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], g
 #ifndef CAVOID_RELAY_PRIO_C
 #define CAVOID_RELAY_PRIO_C 1
 #endif
-// how far D runs ahead of P's verdicts: 1 -- it posts the state of step t+1 and then waits for the verdict on step t; 2 -- it posts t+2 first
-#ifndef CAVOID_RELAY_DEPTH
-#define CAVOID_RELAY_DEPTH 1
-#endif
 // development: timing-only ablations of the roles (WRONG results; profiles/r06_w_relay_prio_ablation.txt): 1 the consumers make no observation
 // (they only free their ring slots), 2 P's distance loop left out, 4 D's advance without its sine / cosine, 8 D never waits for P's verdict and
 // nobody acts on a surprise (the loop-carried cycle cut: what unbounded speculation would run at), 16 D waits for the verdict of the step BEFORE
@@ -584,139 +580,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         const bool present_first = active && (a.flags & CAVOID_F_PRESENT);
         bool restarted_any = false, moved_any = false;
         int events = 0;
-#if CAVOID_RELAY_DEPTH == 2
-        // ---- speculation TWO steps deep: A = X[t], the tentative state of step t (posted, P's verdict pending); B = X[t+1] (posted too, made from A
-        //      as if nothing happens at t).  Iteration t makes C = X[t+2] from B, posts it, and only THEN looks at the verdict on step t: P has had
-        //      two of D's advances for it, and the loop-carried cycle (state posted -> P's verdict -> D settles and advances) spans three iterations
-        //      instead of two.  A surprise at t discards B and C: B is corrected (frozen copies, restarted worlds' records advanced), C is made again
-        //      from it, both are posted under the next EPOCH -- `spec` carries epoch * 65536 + states posted, P waits for (its own count of
-        //      surprises so far, t + 1): a stale C of the old epoch never satisfies it.
-        bool A_moving, B_moving = false;
-        Agent A, B;
-        wave_lds_sync();
-        RelayStatics ks = relay_statics(a, active);
-        A = relay_advance(cd, trig, a, ks, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, A_moving);   // step 0 is not speculative
-        __syncthreads();                                   // table, counters, the loader's first actions
-        RELAY_MARK(21);                                    // D: state, table and the first actions are in; step 0 advanced
-        // the table rows of the next two steps' actions (r1: t+1, r2: t+2) and the action INDEX of the step after those (t+3), read ahead
-        double r1s = 0.0, r1h = 0.0, r2s = 0.0, r2h = 0.0;
-        int idx3 = 0;
-        if (n_steps > 1) { const int a1 = (int)actring[64 + lane0]; r1s = lds_tab[2 * a1]; r1h = lds_tab[2 * a1 + 1]; }
-        if (n_steps > 2) { const int a2 = (int)actring[2 * 64 + lane0]; r2s = lds_tab[2 * a2]; r2h = lds_tab[2 * a2 + 1]; }
-        if (n_steps > 3) idx3 = (int)actring[3 * 64 + lane0];
-        auto stage_out = [&](RelayTent &tn, const Agent &x, float r_staged, int lane) {   // r_staged: relay_statics of x's episode
-            tn.px[lane] = x.px; tn.py[lane] = x.py; tn.r[lane] = r_staged; tn.flags[lane] = x.flags;
-            tn.vx[lane] = x.vx; tn.vy[lane] = x.vy; tn.heading[lane] = x.heading;
-            tn.gx[lane] = x.gx; tn.gy[lane] = x.gy; tn.pref[lane] = x.pref;
-        };
-        int epoch = 0;                                      // surprises handled so far
-        stage_out(tents[0], A, ks.r_staged, lane0);
-        relay_post(&seq->spec, 1);
-        RELAY_MARK(22);                                    // D: step 0 posted
-        B = A;
-        if (n_steps > 1) {
-            B = relay_advance(cd, trig, A, ks, r1s, r1h, active, B_moving);
-            stage_out(tents[1], B, ks.r_staged, lane0);
-            relay_post(&seq->spec, 2);
-        }
-        int cslot = 0;                                      // (t + 2 - ring) mod NC, kept by counting
-        // steps 0 .. n-2: each iteration posts the state of step t+2 and then settles step t; the last step is settled below
-        for (int t = 0; t + 1 < n_steps; ++t) {
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));
-            RELAY_STAMP(0);                                // D: iteration begins
-            const bool has2 = t + 2 < n_steps;
-            int idx4 = 0;                                   // action(t+4)'s index, for the next iteration
-            if (t + 4 < n_steps) {
-                // (the loader's first batch is 8 steps -- iterations 0..3 read steps 4..7 --, from iteration 4 on every eighth iteration makes
-                //  sure of the next eight reads; the loader runs up to 48 steps ahead of `fin`)
-                if (CAVOID_RARE((t & 7) == 4)) relay_wait(&seq->act, t + 12 < n_steps ? t + 12 : n_steps);
-                idx4 = (int)actring[((t + 4) & (kRelayActRing - 1)) * 64 + lane];
-            }
-            const bool need_slot = has2 && t + 2 >= relay_ring<N>();    // slot free: the consumer of step t+2-ring is done with it
-            const int cons_early = need_slot ? relay_peek_issue(&seq->cons[cslot]) : 0;
-            const double r3s = *(relay_lds_f64 *)&lds_tab[2 * idx3], r3h = *(relay_lds_f64 *)&lds_tab[2 * idx3 + 1];
-            bool mC = false;
-            Agent Cn = B;
-            RelayTent &tc = tents[(t + 2) & (relay_ring<N>() - 1)];
-            if (has2) {
-                Cn = relay_advance(cd, trig, B, ks, r2s, r2h, active, mC);
-                if (need_slot) {
-                    if (CAVOID_RARE(relay_seen(cons_early) < t + 3 - relay_ring<N>())) relay_wait(&seq->cons[cslot], t + 3 - relay_ring<N>());
-                    cslot = cslot + 1 == NC ? 0 : cslot + 1;
-                }
-            }
-            const int res_early = relay_peek_issue(&seq->res);   // P's counter: the trip runs under the staging writes
-            if (has2) {
-                stage_out(tc, Cn, ks.r_staged, lane);
-                relay_post(&seq->spec, epoch * 65536 + t + 3);
-            }
-            RELAY_STAMP(1);                                // D: state t+2 computed and posted
-            // ---- P's verdict on step t: ONE word -- 2 * (steps posted) + "the last of them holds a surprise".  P goes past a step only when it
-            //      held no surprise (else it waits for the next epoch): a count beyond t + 1 says "none at t" ------------------------------------
-            RelayRes *res = &ress[t & (relay_ring<N>() - 1)];
-            int posted = relay_seen(res_early);
-            if (CAVOID_RARE((posted >> 1) < t + 1))
-                do posted = relay_peek(&seq->res); while ((posted >> 1) < t + 1);
-            asm volatile("" ::: "memory");
-            RELAY_STAMP(2);                                // D: verdict arrived
-            moved_any = moved_any || A_moving;
-            const bool surprise = (posted >> 1) == t + 1 && (posted & 1) != 0;
-            if (CAVOID_RARE(surprise)) {
-                const uint32_t vflags = *(relay_lds_u32 *)&res->flags[lane], ctl = *(relay_lds_u32 *)&res->ctl[lane];
-                const bool restart = (ctl & 2u) != 0u;
-                const unsigned long long rmask = __ballot(restart);
-                Agent S = A;                               // the committed state of step t
-                S.flags = vflags;
-                if (rmask != 0ull) {                       // some world of the tile starts a new episode
-                    relay_wait(&seq->nxt, events + 1);     // the first records are in / every earlier restart's are re-armed
-                    Agent nx;
-                    relay_read_nxt(*nbuf, lane, nx);
-                    bool mr;
-                    const RelayStatics ksn = relay_statics(nx, active);
-                    const Agent Tr = relay_advance(cd, trig, nx, ksn, r1s, r1h, active, mr);
-                    if (restart) {
-                        S = nx; episode += 1u; restarted_any = true; B = Tr; B_moving = mr; ks = ksn;
-                        stage_out(tents[t & (relay_ring<N>() - 1)], nx, ksn.r_staged, lane);   // the consumers see step t's FINAL state: the new episode
-                        res->flags[lane] = nx.flags;
-                    }
-                }
-                const bool s_present = active && (S.flags & CAVOID_F_PRESENT);
-                const bool s_done = (S.flags & CAVOID_F_DONE_MASK) != 0u;
-                const bool frozen = s_present && s_done && !restart;   // env_kernel: present_in && done_in
-                uint32_t fflags = S.flags;
-                if (S.flags & CAVOID_F_AT_GOAL) fflags |= CAVOID_F_WAS_AT_GOAL;
-                if (S.flags & CAVOID_F_IN_COLL) fflags |= CAVOID_F_WAS_IN_COLL;
-                B.px = frozen ? S.px : B.px; B.py = frozen ? S.py : B.py; B.heading = frozen ? S.heading : B.heading;
-                B.t_rem = frozen ? S.t_rem : B.t_rem;
-                B.vx = frozen ? 0.0 : B.vx; B.vy = frozen ? 0.0 : B.vy; B.speed = frozen ? 0.0f : B.speed;
-                B.flags = frozen ? fflags : B.flags;        // (gx, gy, radius, pref: per-episode constants, S's == B's)
-                B_moving = frozen ? false : B_moving;
-                stage_out(tents[(t + 1) & (relay_ring<N>() - 1)], B, ks.r_staged, lane);   // the posted state of step t+1 was wrong for some lane
-                epoch += 1;
-                relay_post(&seq->spec, epoch * 65536 + t + 2);
-                if (rmask != 0ull) {                       // tell the loader which lanes need their next pool record
-                    relay_wait(&seq->nxt, events + 1 - (kRelayEvq - 1));
-                    if (lane == 0) evq[events & (kRelayEvq - 1)] = rmask;
-                    events += 1;
-                    relay_post(&seq->ev, events);
-                }
-                if (has2) {                                // ... and the one of step t+2 was made from it
-                    Cn = relay_advance(cd, trig, B, ks, r2s, r2h, active, mC);
-                    stage_out(tc, Cn, ks.r_staged, lane);
-                    relay_post(&seq->spec, epoch * 65536 + t + 3);
-                }
-            }
-            A = B; A_moving = B_moving;
-            B = Cn; B_moving = mC;
-            r1s = r2s; r1h = r2h; r2s = r3s; r2h = r3h;
-            idx3 = idx4;
-            relay_post(&seq->fin, t + 1);                  // slot t (state + verdict) is final: the consumers may take it
-            RELAY_STAMP(3);                                // D: slot t final
-        }
-        const Agent &T = A;
-        const bool T_moving = A_moving;
-#else
         bool T_moving;
         Agent T;
         // the first advance runs IN FRONT of the workgroup barrier -- the table is this wavefront's own LDS write, the state and the
@@ -840,7 +703,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             relay_post(&seq->fin, t + 1);                  // slot t (state + verdict) is final: the consumers may take it
             RELAY_STAMP(3);                                // D: slot t final
         }
-#endif
         // ---- the last step: nothing to post, only its committed state ---------------------------------------------------------
         Agent S = T;
         {
@@ -886,7 +748,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         asm volatile("" : "+s"(cp.r_step), "+s"(cp.r_goal), "+s"(cp.r_coll), "+s"(cp.r_close), "+s"(cp.close_slope), "+s"(cp.close_range),
                      "+s"(cp.clip_lo), "+s"(cp.clip_hi), "+s"(cp.collision_dist), "+s"(cp.horizon), "+s"(cp.evaluate_mode));
         bool prev_surprise = false;
-        int nsur = 0;                                       // surprises posted so far (CAVOID_RELAY_DEPTH 2: the epoch this wavefront reads)
         __syncthreads();
         for (int t = 0; t < n_steps; ++t) {
             int lane = lane0, i = i0, base = base0;
@@ -900,12 +761,8 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             RELAY_STAMP(8);                                // P: waiting for stage t
             // the speculative successor D posted while this wavefront worked on step t-1 is exact unless the verdict of t-1 found
             // a new collision or restarted a world: only then wait for D's corrected state
-#if CAVOID_RELAY_DEPTH == 2
-            relay_spin(&seq->spec, nsur * 65536 + t + 1);   // the state of step t made in the epoch behind this wavefront's last surprise
-#else
             if (prev_surprise) relay_spin(&seq->stage, t + 1);
             else relay_spin(&seq->spec, t + 1);
-#endif
             RELAY_STAMP(9);                                // P: stage t arrived
             const RelayTent *tent = &tents[t & (relay_ring<N>() - 1)];
             Agent a;
@@ -957,7 +814,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             res->rew[lane] = rew_f;
             const bool new_coll = (flags & CAVOID_F_IN_COLL) != 0u && (flags_t & CAVOID_F_IN_COLL) == 0u;
             prev_surprise = !(CAVOID_RELAY_ABL & 24) && __ballot(new_coll || restart) != 0ull;
-            nsur += prev_surprise ? 1 : 0;
             relay_post(&seq->res, 2 * (t + 1) + (prev_surprise ? 1 : 0));    // (D reads the verdict's words only behind a surprise)
             RELAY_STAMP(10);                               // P: verdict posted (the plain outputs go out with the consumer's rows)
         }

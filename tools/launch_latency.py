@@ -36,3 +36,27 @@ us = [env.kernel_time_ms(acts64, 40 * k, k, slots=slots64) * 1e3 for k in ks]
 print("K-step launch, kernel us:", {k: round(u, 2) for k, u in zip(ks, us)})
 print("  per-step slope 32 -> 64: %.3f us; intercept at K = 20: %.2f us" % ((us[-1] - us[-3]) / 32, us[6] - 20 * (us[-1] - us[-3]) / 32))
 print("env:", {k: os.environ.get(k) for k in ("ROC_ACTIVE_WAIT_TIMEOUT", "HSA_ENABLE_INTERRUPT", "HIP_FORCE_SPIN")})
+# an ISOLATED launch against the same launch in a train: HIP-event time of ONE 20-step launch (a) behind a host synchronisation, (b) behind another
+# kernel on the stream (a torch op of ~20 us on a large tensor: other code, other data), (c) behind another 20-step launch; and the wall clock of
+# sync -> launch -> sync after an idle gap of g microseconds of host spinning
+big = torch.zeros(64 << 20, device="cuda")
+def one(pre):
+    v = []
+    for _ in range(60):
+        torch.cuda.synchronize()
+        pre()
+        v.append(env.kernel_time_ms(acts, 20, 20, slots=slots) * 1e3)
+    v.sort()
+    return round(v[len(v) // 2], 2)
+print("one 20-step launch, kernel us: behind a host sync %s, behind a torch kernel %s, behind another 20-step launch %s" % (
+    one(lambda: None), one(lambda: big.add_(1.0)), one(lambda: env.step_autoreset_n(acts, 20, slots=slots))))
+def gap(g_us):
+    v = []
+    for _ in range(80):
+        torch.cuda.synchronize()
+        t_end = time.perf_counter() + g_us * 1e-6
+        while time.perf_counter() < t_end: pass
+        t0 = time.perf_counter(); env.step_autoreset_n(acts, 20, slots=slots); torch.cuda.synchronize(); v.append(time.perf_counter() - t0)
+    v.sort()
+    return round(v[len(v) // 2] * 1e6, 1)
+print("sync -> 20-step launch -> sync, wall us, after an idle gap of 0 / 20 / 100 / 1000 / 10000 us:", [gap(g) for g in (0, 20, 100, 1000, 10000)])
