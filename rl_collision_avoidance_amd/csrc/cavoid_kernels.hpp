@@ -631,30 +631,34 @@ __device__ __forceinline__ void pair_pass(const KCfg &c, const Agent &a, const E
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (a compile-time choice per flush: behind a run-time flag per store the optimiser merges the two stores of the diamond into one
 //  plain store)
-// CAVOID_STREAM_POLICY (per translation unit: every function here is inlined into that unit's kernels): the cache policy of those stores.
-// 0: `nt` -- the compiler's non-temporal store; the line stays DIRTY in the XCD's L2 until it is evicted or the launch's end-of-kernel release
-// writes it back.  1 / 2 / 3: write-through (`sc1`, `sc0 sc1`, `sc0 sc1 nt`): the bytes leave for memory when the store is made and the line
-// is dropped, nothing waits for the release.  env_relay_kernel at 4 x 8192, 20-step launches with per-step slots, same box: nt 31.06 us,
-// plain 31.76, sc1 29.60, sc0 sc1 30.06, sc0 sc1 nt 29.84; 64-step launches: no difference (profiles/r06_x_relay_deal_store.txt).
+// CAVOID_STREAM_POLICY: what a streaming store of a tile that covers WHOLE 128-byte lines (WT: a compile-time property of the row width and rows per tile +
+// the run-time alignment of its destination) is.  0: `nt` like every other streaming store -- the line stays DIRTY in the XCD's L2 until it is evicted
+// or the launch's end-of-kernel release writes it back.  1 / 2 / 3: write-through (`sc1`, `sc0 sc1`, `sc0 sc1 nt`): the bytes leave for memory when the
+// store is made and the line is dropped, nothing waits for the release.  Same box, bench.py's slot form: env_relay_kernel at 4 x 8192, 20-step launches: nt
+// 29.9 us, sc1 28.2 (-5.7 %; 64-step launches unchanged; profiles/r06_x, r06_z); env_kernel<4, MODE_STEP_AUTORESET_N> at 4 x 65536: 485 -> 467 us per 64-step
+// launch (-4 %), 4 x 1 M worlds +-0.  Tiles with RAGGED lines must not take it: 10 agents per world (60 rows x 69 floats = 129.4 lines per tile) 411 -> 614 us
+// per 64-step launch, 10 x 262 144 2748 -> 4293 (profiles/r06_aa: every partial line becomes its own write at the memory side) -- hence WT.
 #ifndef CAVOID_STREAM_POLICY
-#define CAVOID_STREAM_POLICY 0
+#define CAVOID_STREAM_POLICY 1
 #endif
-template <bool STREAM>
+template <bool STREAM, bool WT = false>
 __device__ __forceinline__ void store16(float4 *p, const float4 &v) {
     if (CAVOID_NT_STORES && STREAM) {
         const f32x4v x{v.x, v.y, v.z, v.w};
-        // (inline assembly: the compiler has no cache-policy argument for a plain vector store.  It does not see the instruction, so its hazard
-        //  recogniser cannot keep the two wait states gfx940+ wants between a store of more than 64 bits and a vector write of its DATA
-        //  registers -- and it does re-use them at once, as the next store's address: the s_nop is that distance, made by hand)
-#if CAVOID_STREAM_POLICY == 1
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-#elif CAVOID_STREAM_POLICY == 2
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+        if (WT && CAVOID_STREAM_POLICY != 0) {
+            // (inline assembly: the compiler has no cache-policy argument for a plain vector store.  It does not see the instruction, so its hazard
+            //  recogniser cannot keep the two wait states gfx940+ wants between a store of more than 64 bits and a vector write of its DATA
+            //  registers -- and it does re-use them at once, as the next store's address: the s_nop is that distance, made by hand)
+#if CAVOID_STREAM_POLICY == 2
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #elif CAVOID_STREAM_POLICY == 3
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #else
-        __builtin_nontemporal_store(x, reinterpret_cast<f32x4v *>(p));
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #endif
+        } else {
+            __builtin_nontemporal_store(x, reinterpret_cast<f32x4v *>(p));
+        }
     } else {
         *p = v;
     }
@@ -731,7 +735,8 @@ __device__ __forceinline__ bool tournament(const Key (&key)[KK], int (&pos)[KK])
 
 // the same for a compile-time float count (the common shape: a full wavefront of rows of the default width): every
 // round but the last is unpredicated
-template <int NF, bool STREAM = false>
+// WT: the tile covers whole 128-byte lines at its destination (store16)
+template <int NF, bool STREAM = false, bool WT = false>
 __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, int lane) {
     static_assert(NF % 4 == 0, "whole float4s");
     constexpr int n4 = NF / 4, rounds = (n4 + 63) / 64;
@@ -756,7 +761,7 @@ __device__ __forceinline__ void flush_tile_fixed(const float *tile, float *dst, 
             const int r = r0 + u;
             if (r < rounds) {
                 const int k = lane + 64 * r;
-                if ((r + 1) * 64 <= n4 || k < n4) store16<STREAM>(dst4 + k, v[u]);
+                if ((r + 1) * 64 <= n4 || k < n4) store16<STREAM, WT>(dst4 + k, v[u]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -960,9 +965,18 @@ __device__ __forceinline__ void assemble_obs(const KCfg &c, const Agent &a, cons
         float *dst = obs_dst + (int64_t)p0 * ostride;
         const bool whole = rows_here == kRows && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
         if (stream_out) {                                        // (wave-uniform: a property of the launch)
-            if (kPlainOk && whole && ostride == kW) flush_tile_fixed<kPlainOk ? kRows * kW : 4, true>(tile, dst, lane);
-            else if (kPackedOk && whole && ostride == kW + 2) flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4, true>(tile, dst, lane);
-            else flush_tile<true>(tile, dst, rows_here * ostride, lane);
+            // whole 128-byte lines (32 floats) per tile and a destination on a line boundary: the write-through form of the streaming store (store16)
+            constexpr bool kPlainLines = kPlainOk && (kRows * kW) % 32 == 0, kPackedLines = kPackedOk && (kRows * (kW + 2)) % 32 == 0;
+            const bool lines = (reinterpret_cast<uintptr_t>(dst) & 127) == 0;
+            if (kPlainOk && whole && ostride == kW) {
+                if (kPlainLines && lines) flush_tile_fixed<kPlainOk ? kRows * kW : 4, true, kPlainLines>(tile, dst, lane);
+                else flush_tile_fixed<kPlainOk ? kRows * kW : 4, true>(tile, dst, lane);
+            } else if (kPackedOk && whole && ostride == kW + 2) {
+                if (kPackedLines && lines) flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4, true, kPackedLines>(tile, dst, lane);
+                else flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4, true>(tile, dst, lane);
+            } else {
+                flush_tile<true>(tile, dst, rows_here * ostride, lane);
+            }
         } else {
             if (kPlainOk && whole && ostride == kW) flush_tile_fixed<kPlainOk ? kRows * kW : 4>(tile, dst, lane);
             else if (kPackedOk && whole && ostride == kW + 2) flush_tile_fixed<kPackedOk ? kRows * (kW + 2) : 4>(tile, dst, lane);

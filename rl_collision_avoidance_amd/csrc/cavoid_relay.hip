@@ -1,11 +1,6 @@
 // cavoid_relay.hip -- env_relay_kernel instantiations (cavoid_relay.hpp): the in-launch step loop of small batches with the
 // step cut into roles on several wavefronts of one workgroup per tile.  Own translation unit, compiled with
 // -mllvm -disable-machine-licm like the other step-loop units (build.py).
-// this unit's per-step-slot output stores are write-through (cavoid_kernels.hpp, CAVOID_STREAM_POLICY): a K-step launch of a small batch ends
-// with nothing of its K x 3.8 MB of rows left dirty in the L2s for the end-of-kernel release to write back (-4.7 % on a 20-step launch)
-#ifndef CAVOID_STREAM_POLICY
-#define CAVOID_STREAM_POLICY 1
-#endif
 #include "cavoid_launch.hpp"
 #include "cavoid_relay.hpp"
 

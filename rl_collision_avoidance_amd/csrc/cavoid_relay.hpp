@@ -356,7 +356,7 @@ __device__ __forceinline__ void relay_pair_part(const KCfg &c, const Agent &a, c
     }
 }
 // the tile's rows out of LDS by the three wavefronts (flush_tile with tid / nthreads for lane / 64)
-template <bool STREAM>
+template <bool STREAM, bool WT = false>
 __device__ __forceinline__ void relay_flush_part(const float *tile, float *dst, int n_floats, int tid, int nthreads) {
     if ((n_floats & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
         const float4 *src4 = reinterpret_cast<const float4 *>(tile);
@@ -372,7 +372,7 @@ __device__ __forceinline__ void relay_flush_part(const float *tile, float *dst, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = k0 + nthreads * u;
-                if (k < n4) store16<STREAM>(dst4 + k, v[u]);
+                if (k < n4) store16<STREAM, WT>(dst4 + k, v[u]);
             }
         }
     } else {
@@ -496,7 +496,10 @@ __device__ __forceinline__ void relay_coop_last(unsigned char *smem) {
     const int64_t slot_w = (int64_t)t * io.out_step_stride;
     if (worlds_here > 0) {
         float *dst = io.obs + (slot_w + w0) * N * ostride;
-        if (io.out_step_stride != 0) relay_flush_part<true>(tile, dst, rows_active * ostride, pw * 64 + lane0, 64 * kRelayCoopWaves);
+        // (whole 128-byte lines per tile, on a line boundary: the write-through form of the streaming store, like assemble_obs's flush)
+        const bool lines = ((rows_active * ostride) & 31) == 0 && (reinterpret_cast<uintptr_t>(dst) & 127) == 0;
+        if (io.out_step_stride != 0 && lines) relay_flush_part<true, true>(tile, dst, rows_active * ostride, pw * 64 + lane0, 64 * kRelayCoopWaves);
+        else if (io.out_step_stride != 0) relay_flush_part<true>(tile, dst, rows_active * ostride, pw * 64 + lane0, 64 * kRelayCoopWaves);
         else relay_flush_part<false>(tile, dst, rows_active * ostride, pw * 64 + lane0, 64 * kRelayCoopWaves);
     }
     if (pw == 0 && active) {                           // the step's plain outputs

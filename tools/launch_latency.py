@@ -60,3 +60,22 @@ def gap(g_us):
     v.sort()
     return round(v[len(v) // 2] * 1e6, 1)
 print("sync -> 20-step launch -> sync, wall us, after an idle gap of 0 / 20 / 100 / 1000 / 10000 us:", [gap(g) for g in (0, 20, 100, 1000, 10000)])
+# the same loop on an env made the way bench.py makes its headline env (fresh scenarios from the look-ahead rings), with bench.py's own bracket
+env2 = BatchedCollisionAvoidanceEnv(8192, EnvConfig(), seed=7, gen_pool_size=0, gen_lookahead=128)
+env2.reset()
+slots2 = env2.new_step_slots(20)
+dev = torch.device("cuda:0")
+for _ in range(20): env2.step_autoreset_n(acts, 20, slots=slots2)
+def bench_like(e, sl, sync):
+    v = []
+    for _ in range(120):
+        int(e.episode.to(torch.int64).sum().item())
+        sync(); t0 = time.perf_counter(); e.step_autoreset_n(acts, 20, slots=sl); sync(); v.append(time.perf_counter() - t0)
+    v.sort()
+    return round(v[len(v) // 2] * 1e6, 1), round(v[len(v) // 10] * 1e6, 1), round(v[-len(v) // 10] * 1e6, 1)
+print("bench.py's bracket (episode sum .item(); sync; launch; sync), wall us median / p10 / p90:")
+print("   pool env,       torch.cuda.synchronize(device):", bench_like(env, slots, lambda: torch.cuda.synchronize(dev)))
+print("   pool env,       torch.cuda.synchronize():      ", bench_like(env, slots, lambda: torch.cuda.synchronize()))
+print("   look-ahead env, torch.cuda.synchronize(device):", bench_like(env2, slots2, lambda: torch.cuda.synchronize(dev)))
+print("   look-ahead env, torch.cuda.synchronize():      ", bench_like(env2, slots2, lambda: torch.cuda.synchronize()))
+print("   look-ahead env, kernel us per 20-step launch (events, back to back):", round(env2.kernel_time_ms(acts, 20 * 40, 20, slots=slots2) * 1e3, 2))
