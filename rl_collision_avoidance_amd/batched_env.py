@@ -358,6 +358,37 @@ class BatchedCollisionAvoidanceEnv(object):
             _lib.check(rc, "cavoid_step_autoreset_n")
         return self.obs, self.rewards, self.done, self.game_over
 
+    def prepared_autoreset_n(self, actions: torch.Tensor, n_steps: Optional[int] = None, slots: Optional[StepSlots] = None):
+        """``step_autoreset_n`` with its arguments checked and converted ONCE: returns a callable that launches the same
+        ``n_steps`` steps from the same action slices into the same slots every time it is called (a rollout loop that
+        re-launches over fixed buffers; the launch-bound small-batch regime, where the per-call checks and pointer
+        conversions are a visible part of a 30 us launch).  The callable keeps ``actions`` and ``slots`` alive, launches on the
+        stream that is current when it is CALLED, and returns what ``step_autoreset_n`` returns."""
+        T = actions.shape[0]
+        n = T if n_steps is None else int(n_steps)
+        if n > T:
+            raise ValueError("n_steps > number of action slices")
+        a = self._want(actions, (T, self.num_worlds, self.max_agents), torch.int32, "actions")
+        stride = self.num_worlds * self.max_agents
+        if slots is not None:
+            if slots.is_packed or slots.steps < n:
+                raise ValueError("need plain StepSlots of at least n_steps slots")
+            out = (slots.obs, slots.rewards, slots.done, slots.game_over)
+            args = (self._h, C.c_void_p(a.data_ptr()), stride, n, self.num_worlds, C.c_void_p(slots.obs.data_ptr()),
+                    C.c_void_p(slots.rewards.data_ptr()), C.c_void_p(slots.done.data_ptr()), C.c_void_p(slots.game_over.data_ptr()))
+        else:
+            out = (self.obs, self.rewards, self.done, self.game_over)
+            args = (self._h, C.c_void_p(a.data_ptr()), stride, n, 0, self._p_obs, self._p_rew, self._p_done, self._p_go)
+        fn, stream, keep = self._lib.cavoid_step_autoreset_n, self._stream, (a, slots)
+
+        def launch():
+            rc = fn(*args, stream())
+            if rc != 0:
+                _lib.check(rc, "cavoid_step_autoreset_n")
+            return out
+        launch.keeps = keep
+        return launch
+
     def step_continuous_autoreset(self, actions: torch.Tensor, n_steps: Optional[int] = None, slots: Optional[StepSlots] = None):
         """The auto-reset step with CONTINUOUS actions -- float32 ``[W,N,2]`` (one step) or pre-staged ``[T,W,N,2]`` (``n_steps`` <= T steps
         in ONE launch, the world state in registers between them): (speed, heading change) for the unicycle dynamics, a velocity for the

@@ -242,6 +242,33 @@ def test_every_step_of_a_multi_step_launch_lands_in_its_slot_and_matches_the_ora
         e.close()
 
 
+def test_prepared_launch_equals_the_plain_call():
+    """prepared_autoreset_n: arguments checked and converted once, then the same launch per call -- bitwise what step_autoreset_n does,
+    into slots and into the env's own buffers; its argument checks are the plain call's."""
+    W, N, K = 777, 4, 12
+    acts = _acts(3 * K, W, N, 21)
+    a, b = _env(W, N, seed=5), _env(W, N, seed=5)
+    a.reset(); b.reset()
+    sa, sb = a.new_step_slots(K), b.new_step_slots(K)
+    go = a.prepared_autoreset_n(acts[:K], K, slots=sa)
+    for rep in range(3):                                    # the same slices again: the launch is the same, the worlds move on
+        oa = go()
+        ob = b.step_autoreset_n(acts[:K], K, slots=sb)
+        assert all(torch.equal(x, y) for x, y in zip(oa, ob)), rep
+        assert oa[0] is sa.obs and oa[3] is sa.game_over
+    go2 = a.prepared_autoreset_n(acts, 5)                   # no slots: the env's own buffers hold the last step's outputs
+    oa, ob = go2(), b.step_autoreset_n(acts, 5)
+    assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and oa[0] is a.obs
+    assert all(torch.equal(x, y) for x, y in zip(a.get_state(), b.get_state())) and torch.equal(a.episode, b.episode)
+    with pytest.raises(ValueError):
+        a.prepared_autoreset_n(acts[:4], 5)
+    with pytest.raises(ValueError):
+        a.prepared_autoreset_n(acts, K, slots=a.new_step_slots(K, packed=True))
+    with pytest.raises(ValueError):
+        a.prepared_autoreset_n(acts, K + 1, slots=sa)
+    a.close(); b.close()
+
+
 def test_step_slots_argument_checks():
     import ctypes as C
     from rl_collision_avoidance_amd import _lib
