@@ -524,7 +524,7 @@ def measure_traffic(N: int, W: int, slices: int, steps: int, timeout_s: float = 
             hit = re.search(r"env_kernel<%d, (\d+)" % N, name)
             if (hit and hit.group(1) == "1") or ("env_quad_kernel<%d>" % N) in name:
                 form = "one_step"
-            elif (hit and hit.group(1) in ("4", "5")) or ("env_pipe_kernel<%d," % N) in name or ("env_relay_kernel<%d>" % N) in name:
+            elif (hit and hit.group(1) in ("4", "5")) or ("env_pipe_kernel<%d," % N) in name or re.search(r"env_relay_kernel<%d[,>]" % N, name):
                 form = "k_step"
             else:
                 continue

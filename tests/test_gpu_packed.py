@@ -183,6 +183,45 @@ def _oracle_run(env, N, seed, acts, gen_min=None, nonl=0.0, **cfg_over):
     return outs, st, ep
 
 
+@pytest.mark.parametrize("N,W,nc,rvo_frac", [(4, 8192, 3, 0.5), (4, 1000, 3, 1.0), (4, 37, 2, 0.5), (3, 600, 3, 0.5), (2, 4096, 3, 0.7), (4, 2000, 4, 0.3)])
+def test_relay_kernel_with_orca_agents_equals_single_steps(N, W, nc, rvo_frac, monkeypatch):
+    """env_relay_kernel<N, true>: world sets with ORCA (policy 3) agents in the role-split K-step loop -- the state owner does not speculate
+    across a step at which its tile holds a running ORCA agent (the policy reads the COMMITTED state of the whole world), tiles without one
+    run as ever, a restart that brings one takes the surprise path.  Reference: the same steps one per launch (env_kernel<N, 1, true>), bitwise;
+    per-step slots against the overwrite form; scripted static / non-cooperative agents beside the ORCA ones."""
+    monkeypatch.setenv("CAVOID_PIPELINE", "2")
+    monkeypatch.setenv("CAVOID_RELAY_CONSUMERS", str(nc))
+    kw = dict(rvo_enabled=1, gen_rvo_fraction=rvo_frac, gen_nonlearning_fraction=0.6, gen_static_fraction=0.1, gen_min_agents=2, gen_pool_size=4099)
+    T = 70
+    acts = _acts(T, W, N, 11)
+    a = _env(W, N, seed=13, **kw)
+    monkeypatch.setenv("CAVOID_PIPELINE", "0")
+    b = _env(W, N, seed=13, **kw)
+    monkeypatch.delenv("CAVOID_PIPELINE", raising=False)
+    a.reset(); b.reset()
+    slots = a.new_step_slots(24)
+    lo = 0
+    for n in (1, 2, 5, 24, 17, 21):                          # launches shorter and longer than the rings
+        assert lo + n <= T
+        if n == 24:
+            oa = a.step_autoreset_n(acts[lo:lo + n], slots=slots)
+            last = [x[n - 1] for x in oa]
+        else:
+            last = a.step_autoreset_n(acts[lo:lo + n])
+        for t in range(lo, lo + n):
+            ob = b.step_autoreset(acts[t])
+            if n == 24:
+                assert all(torch.equal(x[t - lo], y) for x, y in zip(oa, ob)), (n, t)
+        assert all(torch.equal(x, y) for x, y in zip(last, ob)), n
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert torch.equal(x, y), n
+        assert torch.equal(a.episode, b.episode)
+        lo += n
+    fl = a.get_state()[2].cpu().numpy().view(np.uint32)
+    assert ((fl >> 8) & 7 == 3).any() and a.episode.max().item() >= 1        # ORCA agents were there, worlds restarted
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("N,W,pipe,gen_min,nonl", [
     (4, 512, None, 4, 0.0),       # env_relay_kernel (BASELINE configs[1] shape; 32 tiles)
     (4, 512, "1", 4, 0.0),        # env_pipe_kernel

@@ -9,7 +9,7 @@ repo=$(cd "$(dirname "$0")/.." && pwd)
 src=${SRC:-$repo/rl_collision_avoidance_amd/csrc}
 obj=$repo/rl_collision_avoidance_amd/build
 mkdir -p $repo/.ab /tmp/relayvar_$name
-licm=""; case $tu in cavoid_multistep|cavoid_rvo|cavoid_relay|cavoid_actor|cavoid_actor_rvo|cavoid_actor_frozen) licm="-mllvm -disable-machine-licm";; esac
+licm=""; case $tu in cavoid_multistep|cavoid_rvo|cavoid_relay|cavoid_relay_rvo|cavoid_actor|cavoid_actor_rvo|cavoid_actor_frozen) licm="-mllvm -disable-machine-licm";; esac
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$repo/include -I$src $licm "$@" -c $src/$tu.hip -o /tmp/relayvar_$name/$tu.o
 others=$(ls $obj/*.o | grep -v "\.\(fault\|ulp[0-9]\|trace\)\.o$" | grep -v "/$tu\.o$")
 hipcc --offload-arch=gfx950 -shared -fPIC $others /tmp/relayvar_$name/$tu.o -ldl -o $repo/.ab/lib$name.so

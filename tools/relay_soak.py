@@ -34,6 +34,9 @@ def main():
                   gen_nonlearning_fraction=float(rng.choice([0.0, 0.3, 0.8])) if N > 1 else 0.0)
         if rng.random() < 0.3:
             kw["time_budget_from_goal_edge"] = 1
+        if N > 1 and os.environ.get("RELAY_SOAK_RVO", "1") != "0" and rng.random() < float(os.environ.get("RELAY_SOAK_RVO_P", "0.3")):
+            # ORCA agents: env_relay_kernel<N, true> (the state owner does not speculate across a step with a running ORCA agent in its tile)
+            kw.update(rvo_enabled=1, gen_rvo_fraction=float(rng.choice([0.3, 0.6, 1.0])), gen_nonlearning_fraction=float(rng.choice([0.3, 0.6, 0.9])))
         seed = int(rng.integers(0, 1 << 30))
         os.environ["CAVOID_PIPELINE"] = "2"
         os.environ["CAVOID_RELAY_CONSUMERS"] = str(nc)
