@@ -383,8 +383,15 @@ def full_loop(env_cls, cfg, device, W, N, rank, world_size, sync_all, steps: int
     return res
 
 
-def step_kernel_name(N: int, W: int, spl: int) -> str:
-    """Which instantiation cavoid_step_autoreset_n takes (csrc/cavoid_capi.hip, cavoid_launch.hpp)."""
+def step_kernel_name(N: int, W: int, spl: int, rvo: bool = False) -> str:
+    """Which instantiation cavoid_step_autoreset_n takes (csrc/cavoid_capi.hip, cavoid_launch.hpp).  rvo: the world set holds ORCA agents."""
+    if rvo:
+        if spl == 1:
+            return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET, true> (the ORCA instantiation)" % N
+        tiles = -(-W // (64 // N))
+        if tiles <= 1024 and W * N <= 131072 and os.environ.get("CAVOID_PIPELINE", "2") != "0":
+            return "cavoid::env_pipe_kernel<%d, true> (two-wavefront pipeline per tile, the ORCA instantiation)" % N
+        return "cavoid::env_kernel<%d, MODE_STEP_AUTORESET_N|PF, true> (the ORCA instantiations)" % N
     if spl == 1:
         tiles1 = -(-W // (64 // N))
         if tiles1 <= 512 and N in (2, 3, 4, 5, 6, 10) and os.environ.get("CAVOID_QUAD", "-1") != "0":
@@ -739,10 +746,11 @@ def main() -> None:
         """per-launch HIP-event durations of the step kernel, in launches shaped like the timed region's, + the one-step form"""
         spl = min(acts.shape[0], k)
         launch_ms = env.kernel_time_ms(acts, max(k, spl), spl, slots=slots)
-        fig = form_figures(step_kernel_name(n_agents, Wl, spl), n_agents, Wl, spl, launch_ms, one_step=(spl == 1))
+        rvo = bool(int(getattr(env.cfg, "rvo_enabled", 0)))
+        fig = form_figures(step_kernel_name(n_agents, Wl, spl, rvo), n_agents, Wl, spl, launch_ms, one_step=(spl == 1))
         fig["outputs"] = "per-step slots [K,W,N,.]" if slots is not None else "one slot, overwritten by every step"
         single_ms = env.kernel_time_ms(acts, min(max(k, 64), 256), 1)          # the closed-loop form: one step per launch
-        fig["one_step_launch"] = form_figures(step_kernel_name(n_agents, Wl, 1), n_agents, Wl, 1, single_ms, one_step=True)
+        fig["one_step_launch"] = form_figures(step_kernel_name(n_agents, Wl, 1, rvo), n_agents, Wl, 1, single_ms, one_step=True)
         return fig
 
     # ---- the slow evidence legs share one budget (--evidence): most important first, what does not fit is skipped and named ----
@@ -1119,7 +1127,9 @@ def main() -> None:
         cases = [("gen_v1_ring_" + m, scen_over(m)) for m in ("lookahead", "pool", "instep") if m != args.scenarios]
         cases += [("gen_v2_box_" + m, scen_over(m, gen_mode=1)) for m in ("lookahead", "instep")]
         # the reference's TRAINING MIX (static / non-cooperative / ORCA agents around the learners, index.txt:1-3): ORCA agents in the worlds take
-        # the env step's ORCA instantiation -- no role-split relay kernel (csrc/cavoid_relay.hip) -- so this is what a training run's env.step costs
+        # the two-wavefront pipeline's ORCA instantiation -- the role-split relay kernel with ORCA agents was built and is SLOWER (an ORCA action reads the
+        # committed state of its world, so the state owner cannot speculate across it: 12.2 against 7.6 us per step, profiles/r06_ac_relay_rvo.txt) --
+        # this is what a training run's env.step costs
         cases += [("training_mix_orca_agents_pool", dict(rvo_enabled=1, gen_rvo_fraction=0.4, gen_nonlearning_fraction=0.5, gen_static_fraction=0.2,
                                                          gen_min_agents=2))]
         n_rep = 3

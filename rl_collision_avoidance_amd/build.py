@@ -11,15 +11,14 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcavoid_hip.so")
 SOURCES = [os.path.join(CSRC, "cavoid_capi.hip"), os.path.join(CSRC, "cavoid_multistep.hip"), os.path.join(CSRC, "cavoid_rvo.hip"),
-           os.path.join(CSRC, "cavoid_relay.hip"), os.path.join(CSRC, "cavoid_relay_rvo.hip"), os.path.join(CSRC, "cavoid_quad.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
+           os.path.join(CSRC, "cavoid_relay.hip"), os.path.join(CSRC, "cavoid_quad.hip"), os.path.join(CSRC, "cavoid_rollout_capi.hip"),
            os.path.join(CSRC, "cavoid_policy_capi.hip"), os.path.join(CSRC, "cavoid_comm_capi.hip"), os.path.join(CSRC, "cavoid_actor.hip"),
            os.path.join(CSRC, "cavoid_actor_rvo.hip"), os.path.join(CSRC, "cavoid_actor_frozen.hip")]
 HEADERS = {
     "cavoid_capi.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_multistep.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rvo.hip": ["cavoid_kernels.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
-    "cavoid_relay.hip": ["cavoid_kernels.hpp", "cavoid_relay.hpp", "cavoid_relay_host.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
-    "cavoid_relay_rvo.hip": ["cavoid_kernels.hpp", "cavoid_relay.hpp", "cavoid_relay_host.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
+    "cavoid_relay.hip": ["cavoid_kernels.hpp", "cavoid_relay.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_quad.hip": ["cavoid_kernels.hpp", "cavoid_quad.hpp", "cavoid_launch.hpp", "cavoid_host.hpp"],
     "cavoid_rollout_capi.hip": ["cavoid_rollout.hpp", "cavoid_rollout_host.hpp", "cavoid_host.hpp"],
     "cavoid_policy_capi.hip": ["cavoid_policy.hpp", "cavoid_policy_split.hpp", "cavoid_policy_split8.hpp", "cavoid_policy_host.hpp", "cavoid_host.hpp"],
@@ -35,7 +34,7 @@ HEADERS = {
 # constant materialisation of the body (float64 polynomial coefficients, config scalars) out of that loop into
 # registers live across it: 128 VGPRs + 276 B/lane of scratch instead of 128 VGPRs + 12 B (N = 4).
 EXTRA_FLAGS = {"cavoid_multistep.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_rvo.hip": ["-mllvm", "-disable-machine-licm"],
-               "cavoid_relay.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_relay_rvo.hip": ["-mllvm", "-disable-machine-licm"],
+               "cavoid_relay.hip": ["-mllvm", "-disable-machine-licm"],
                # the fused actor kernel runs policy + env step + bookkeeping inside ONE step loop: same reason (without it the
                # GEMM loops' fragment addresses are hoisted across the loop: 256 VGPRs + 232 B/lane of scratch instead of 243 + 0)
                "cavoid_actor.hip": ["-mllvm", "-disable-machine-licm"], "cavoid_actor_rvo.hip": ["-mllvm", "-disable-machine-licm"],

@@ -128,7 +128,6 @@ int cavoid_ahead_prepare(cavoid_env *e, int32_t n_steps, hipStream_t s, hipEvent
 void cavoid_ahead_consumed(cavoid_env *e, int32_t n_steps);     // call after the stepping launch that cavoid_ahead_prepare(n_steps) preceded
 // env_relay_kernel (cavoid_relay.hip): CAVOID_EUNSUPPORTED when the batch is too large for it or its LDS does not fit
 int cavoid_launch_relay(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
-int cavoid_launch_relay_rvo(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-step auto-reset launch (cavoid_multistep.hip): prefetch != 0 -> MODE_STEP_AUTORESET_PF, else MODE_STEP_AUTORESET_N
 // env_quad_kernel (cavoid_quad.hip): CAVOID_EUNSUPPORTED when the configuration or the launch is not one it carries
 int cavoid_launch_quad(cavoid_env *e, const cavoid::KIO &io, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);

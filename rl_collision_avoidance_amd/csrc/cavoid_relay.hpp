@@ -48,7 +48,6 @@ constexpr size_t kRelayLdsLimit = 80 * 1024;      // per workgroup: two of them 
 constexpr int kRelayActRing = 64;        // action ring: steps
 constexpr int kRelayActAhead = 48;       // the loader runs at most this many steps ahead of D
 constexpr int kRelayEvq = 8;             // restart-event queue D -> L
-constexpr size_t kRelayRvoVelBytes = 2 * 64 * sizeof(double);   // RVO instantiation: the agents' last velocities for the ORCA policy
 
 struct RelaySeq {                        // sequence counters (each written by exactly one wavefront)
     int spec;                            // D: the SPECULATIVE tentative state of steps < spec is in `tent` (nothing happened at the step before)
@@ -248,20 +247,10 @@ __device__ __forceinline__ RelayStatics relay_statics(const Agent &a, bool activ
     k.r_staged = (active && (a.flags & CAVOID_F_PRESENT)) ? a.radius : -1.0f;
     return k;
 }
-// RVO instantiation (env_relay_kernel<N, true>): what the ORCA policy of a policy-3 agent reads -- the PRE-move state of its world: positions and
-// radii as D staged them for the step before (the ring slot of step t, final: verdict applied, restarted worlds patched), last velocities made
-// here (speed along the heading, env_tile's statement) -- and its wave-private scratch for the half-planes.
-struct RelayRvo {
-    const double *px, *py; const float *r;                  // the slot of the step before (RelayTent arrays)
-    double *vx, *vy;                                        // [64] each
-    double *mem;                                            // KCfg::rvo_lds_floats floats
-    int i, base;
-};
 // tab_dh: the table's heading change ALREADY rounded through float32 when c.actions_fp32 (D converts the table once, at the prologue:
 // (double)(float)x of a table entry is the same value whether made there or here)
-template <int N = 0, bool RVO = false>
 __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &trig, const Agent &in, const RelayStatics &ks, double tab_speed, double tab_dh,
-                                               bool active, bool &moving, const RelayRvo *rv = nullptr, bool rvo_lane = true, int lane = 0) {
+                                               bool active, bool &moving) {
     Agent a = in;
     const uint32_t flags_in = a.flags;
     const bool present_in = active && (flags_in & CAVOID_F_PRESENT);
@@ -275,20 +264,6 @@ __device__ __forceinline__ Agent relay_advance(const KCfg &c, const RelayTrig &t
             const Ego e0 = ego_frame_exact(c, a);
             a0 = ks.pref;
             a1 = -e0.heading_ego;
-            if (c.actions_fp32) a1 = (double)(float)a1;
-        }
-    }
-    if constexpr (RVO) {
-        // ORCA agents among the lanes this call is FOR (rvo_lane): env_tile's statements, the neighbours' positions from the ring slot
-        if (CAVOID_RARE(__ballot(rvo_lane && present_in && !done_in && pol == 3u) != 0ull)) {
-            double sn0, cs0;
-            sincos_bounded(a.heading, &sn0, &cs0);
-            rv->vx[lane] = present_in ? (double)a.speed * cs0 : 0.0;
-            rv->vy[lane] = present_in ? (double)a.speed * sn0 : 0.0;
-            wave_lds_sync();
-            if (rvo_lane && present_in && !done_in && pol == 3u)
-                rvo_action<N>(c, a, rv->i, rv->base, lane, rv->px, rv->py, rv->vx, rv->vy, rv->r, rv->mem, a0, a1);
-            wave_lds_sync();
             if (c.actions_fp32) a1 = (double)(float)a1;
         }
     }
@@ -537,11 +512,7 @@ __device__ __forceinline__ void relay_coop_last(unsigned char *smem) {
     if (pw == 0) RELAY_MARK(29);                           // D: its share of the last step's rows flushed
 }
 
-// RVO: the instantiation that can drive policy-3 (ORCA) agents.  An ORCA action reads the COMMITTED state of the agent's whole world, so D does not
-// speculate across a step at which its tile holds a running ORCA agent: it waits for P's verdict on step t, settles it, and only then advances (the
-// loop-carried chain at full length: ~2.5x the speculative period, against 6x for the two-wavefront pipeline that carried these worlds before).
-// Tiles without such an agent run exactly as in the plain instantiation.
-template <int N, bool RVO = false>
+template <int N>
 __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_kernel(const KCfg c, const KState s, const PoolRec *pool, const KIO io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sp = smem;
@@ -560,9 +531,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     const int lane0 = threadIdx.x & 63;
     const int ostride = io.obs_stride;
     const int tile_floats = (c.tile_rows * ostride + 3) & ~3;
-    // RVO instantiation: behind the consumers' tiles, the agents' last velocities [2][64] and D's half-plane scratch (KCfg::rvo_lds_floats floats)
-    double *rvo_v = reinterpret_cast<double *>(tiles + (size_t)NC * tile_floats);
-    double *rvo_mem = rvo_v + kRelayRvoVelBytes / sizeof(double);
     const int wpw = c.wpw, lanes_used = wpw * N;
     const int64_t wave = blockIdx.x;                       // one tile per workgroup
     const int64_t w0 = wave * wpw;
@@ -607,7 +575,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         if (active) {                                       // loader's first batch is for steps 1..7 as far as D is concerned)
             episode = s.episode[w];
             load_agent(s, a_idx0, a);
-            if constexpr (RVO) a.speed = s.speed[a_idx0];   // (ORCA agents read the others' last velocities)
             act0 = io.actions[a_idx0];
         }
         if (cd.actions_fp32 && (lane0 & 1)) tab_v = (double)(float)tab_v;   // the heading-change column, rounded through float32 ONCE (relay_advance)
@@ -622,14 +589,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
         // action its own loads -- so the barrier (the loader's first batch in LDS) is waited for under it, not before it
         wave_lds_sync();
         RelayStatics ks = relay_statics(a, active);
-        RelayRvo rv{nullptr, nullptr, nullptr, rvo_v, rvo_v + 64, rvo_mem, i0, base0};
-        if constexpr (RVO) {                                // step 0's ORCA agents read the launch's initial state: staged in slot 0 (overwritten below)
-            RelayTent &t0 = tents[0];
-            t0.px[lane0] = a.px; t0.py[lane0] = a.py; t0.r[lane0] = ks.r_staged;
-            rv.px = t0.px; rv.py = t0.py; rv.r = t0.r;
-            wave_lds_sync();
-        }
-        T = relay_advance<N, RVO>(cd, trig, a, ks, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving, &rv, true, lane0);   // step 0 is not speculative
+        T = relay_advance(cd, trig, a, ks, lds_tab[2 * act0], lds_tab[2 * act0 + 1], active, T_moving);   // step 0 is not speculative
         __syncthreads();                                   // table, counters, the loader's first actions
         RELAY_MARK(21);                                    // D: state, table and the first actions are in; step 0 advanced
         // the table row of the NEXT step's action is read one iteration ahead (two dependent LDS trips off the chain)
@@ -675,56 +635,6 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
             const bool need_slot = t + 1 >= relay_ring<N>();    // slot free: the consumer of step t+1-ring is done with it
             const int cons_early = need_slot ? relay_peek_issue(&seq->cons[cslot]) : 0;
             const double tab_s2 = *(relay_lds_f64 *)&lds_tab[2 * act2], tab_h2 = *(relay_lds_f64 *)&lds_tab[2 * act2 + 1];
-            if constexpr (RVO) {
-                // ---- a running ORCA agent in the tile (as far as T says; a collision or restart at t can only take one away -- a restart
-                //      that brings one is the surprise path's business): no speculation across this step.  Verdict first, then the advance
-                //      from the COMMITTED state of step t, the ring slot of step t being what the ORCA policy reads its neighbours from.
-                const uint32_t polT = (T.flags >> CAVOID_F_POLICY_SHIFT) & CAVOID_F_POLICY_MASK;
-                if (CAVOID_RARE(__ballot(active && (T.flags & CAVOID_F_PRESENT) && (T.flags & CAVOID_F_DONE_MASK) == 0u && polT == 3u) != 0ull)) {
-                    if (need_slot) {
-                        if (CAVOID_RARE(relay_seen(cons_early) < t + 2 - relay_ring<N>())) relay_wait(&seq->cons[cslot], t + 2 - relay_ring<N>());
-                        cslot = cslot + 1 == NC ? 0 : cslot + 1;
-                    }
-                    relay_spin(&seq->res, 2 * (t + 1));
-                    RelayRes *res = &ress[t & (relay_ring<N>() - 1)];
-                    RelayTent &tc = tents[t & (relay_ring<N>() - 1)];
-                    const uint32_t vflags = *(relay_lds_u32 *)&res->flags[lane], ctl = *(relay_lds_u32 *)&res->ctl[lane];
-                    const bool restart = (ctl & 2u) != 0u;
-                    const unsigned long long rmask = __ballot(restart);
-                    moved_any = moved_any || T_moving;
-                    Agent S = T;                           // the committed state of step t
-                    S.flags = vflags;
-                    if (rmask != 0ull) {
-                        relay_wait(&seq->nxt, events + 1);
-                        Agent nx;
-                        relay_read_nxt(*nbuf, lane, nx);
-                        if (restart) {
-                            S = nx; episode += 1u; restarted_any = true; ks = relay_statics(nx, active);
-                            stage_out(tc, nx, ks.r_staged, lane);   // the consumers (and the ORCA policy below) see step t's FINAL state: the new episode
-                            res->flags[lane] = nx.flags;
-                        }
-                    }
-                    wave_lds_sync();
-                    rv.px = tc.px; rv.py = tc.py; rv.r = tc.r;
-                    bool mn;
-                    const Agent Tn = relay_advance<N, RVO>(cd, trig, S, ks, tab_s1, tab_h1, active, mn, &rv, true, lane);
-                    stage_out(tn, Tn, ks.r_staged, lane);
-                    relay_post(&seq->spec, t + 2);
-                    relay_post(&seq->stage, t + 2);
-                    if (rmask != 0ull) {                   // tell the loader which lanes need their next pool record
-                        relay_wait(&seq->nxt, events + 1 - (kRelayEvq - 1));
-                        if (lane == 0) evq[events & (kRelayEvq - 1)] = rmask;
-                        events += 1;
-                        relay_post(&seq->ev, events);
-                    }
-                    T = Tn;
-                    T_moving = mn;
-                    tab_s = tab_s2; tab_h = tab_h2;
-                    act_q = act3;
-                    relay_post(&seq->fin, t + 1);
-                    continue;
-                }
-            }
             bool mn;
             Agent Tn = relay_advance(cd, trig, T, ks, tab_s1, tab_h1, active, mn);
             if (need_slot) {
@@ -760,16 +670,10 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
                     relay_read_nxt(*nbuf, lane, nx);
                     bool mr;
                     const RelayStatics ksn = relay_statics(nx, active);
-                    if constexpr (RVO) {                   // the new episode may hold ORCA agents: its first action reads the new episode's state, from the slot
-                        RelayTent &tc = tents[t & (relay_ring<N>() - 1)];
-                        if (restart) stage_out(tc, nx, ksn.r_staged, lane);
-                        wave_lds_sync();
-                        rv.px = tc.px; rv.py = tc.py; rv.r = tc.r;
-                    }
-                    const Agent Tr = relay_advance<N, RVO>(cd, trig, nx, ksn, tab_s1, tab_h1, active, mr, &rv, restart, lane);
+                    const Agent Tr = relay_advance(cd, trig, nx, ksn, tab_s1, tab_h1, active, mr);
                     if (restart) {
                         S = nx; episode += 1u; restarted_any = true; Tn = Tr; mn = mr; ks = ksn;
-                        if constexpr (!RVO) stage_out(tents[t & (relay_ring<N>() - 1)], nx, ksn.r_staged, lane);   // the consumers see step t's FINAL state: the new episode
+                        stage_out(tents[t & (relay_ring<N>() - 1)], nx, ksn.r_staged, lane);   // the consumers see step t's FINAL state: the new episode
                         res->flags[lane] = nx.flags;
                     }
                 }

@@ -184,11 +184,11 @@ def _oracle_run(env, N, seed, acts, gen_min=None, nonl=0.0, **cfg_over):
 
 
 @pytest.mark.parametrize("N,W,nc,rvo_frac", [(4, 8192, 3, 0.5), (4, 1000, 3, 1.0), (4, 37, 2, 0.5), (3, 600, 3, 0.5), (2, 4096, 3, 0.7), (4, 2000, 4, 0.3)])
-def test_relay_kernel_with_orca_agents_equals_single_steps(N, W, nc, rvo_frac, monkeypatch):
-    """env_relay_kernel<N, true>: world sets with ORCA (policy 3) agents in the role-split K-step loop -- the state owner does not speculate
-    across a step at which its tile holds a running ORCA agent (the policy reads the COMMITTED state of the whole world), tiles without one
-    run as ever, a restart that brings one takes the surprise path.  Reference: the same steps one per launch (env_kernel<N, 1, true>), bitwise;
-    per-step slots against the overwrite form; scripted static / non-cooperative agents beside the ORCA ones."""
+def test_k_step_launches_with_orca_agents_equal_single_steps(N, W, nc, rvo_frac, monkeypatch):
+    """World sets with ORCA (policy 3) agents in the K-step launch forms small batches take (env_pipe_kernel<N, true>; written for an ORCA
+    instantiation of the role-split relay kernel, which passed it and was dropped for being slower: profiles/r06_ac_relay_rvo.txt):
+    launches shorter and longer than the hand-over rings, per-step slots and the overwrite form, scripted static / non-cooperative agents
+    beside the ORCA ones, restarts that bring ORCA agents.  Reference: the same steps one per launch (env_kernel<N, 1, true>), bitwise."""
     monkeypatch.setenv("CAVOID_PIPELINE", "2")
     monkeypatch.setenv("CAVOID_RELAY_CONSUMERS", str(nc))
     kw = dict(rvo_enabled=1, gen_rvo_fraction=rvo_frac, gen_nonlearning_fraction=0.6, gen_static_fraction=0.1, gen_min_agents=2, gen_pool_size=4099)
