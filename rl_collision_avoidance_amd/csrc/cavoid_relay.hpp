@@ -91,6 +91,9 @@ struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], g
 #ifndef CAVOID_RELAY_PRIO_C
 #define CAVOID_RELAY_PRIO_C 1
 #endif
+#ifndef CAVOID_RELAY_PRIO_TAIL
+#define CAVOID_RELAY_PRIO_TAIL 3          /* D, P and L while they make the last step's observation together (-1: as they were) */
+#endif
 // development: timing-only ablations of the roles (WRONG results; profiles/r06_w_relay_prio_ablation.txt): 1 the consumers make no observation
 // (they only free their ring slots), 2 P's distance loop left out, 4 D's advance without its sine / cosine, 8 D never waits for P's verdict and
 // nobody acts on a surprise (the loop-carried cycle cut: what unbounded speculation would run at), 16 D waits for the verdict of the step BEFORE
@@ -958,7 +961,12 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     }
     // ================================================ D, P, L: the LAST step's observation, together =======================================
     if constexpr (kCoop) {
-        if (coop_role) relay_coop_last<N>(smem);
+        if (coop_role) {
+            // the launch's tail is this observation: all three at the loop's top priority (the loader ran BELOW the consumers, two of which are
+            // still at their last steps on the same SIMDs)
+            if (CAVOID_RELAY_PRIO_TAIL >= 0) __builtin_amdgcn_s_setprio(CAVOID_RELAY_PRIO_TAIL);
+            relay_coop_last<N>(smem);
+        }
     }
 }
 
