@@ -78,7 +78,8 @@ struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], g
 #endif
 // Issue priority of the roles (s_setprio: a SIMD's arbiter takes the ready wavefront of the highest priority).  D and P carry the loop-carried
 // cycle and stay on top; the consumers ABOVE the loader (it only polls between its rare refills) is worth -1.4 % (K = 20) / -2.4 % (K = 64)
-// against consumers 0 / loader 1; P or D one level down +-0.5 %; no priorities at all +4 ... +6 % (profiles/r06_w_relay_prio_ablation.txt).
+// against consumers 0 / loader 1; P or D one level down +-0.5 %; no priorities at all +4 ... +6 % (profiles/r06_w_relay_prio_ablation.txt); D, P and the
+// loader all at 3 while they make the last step's observation together: +-0 (profiles/r06_ad_tail_prio.txt).
 #ifndef CAVOID_RELAY_PRIO_D
 #define CAVOID_RELAY_PRIO_D 3
 #endif
@@ -90,9 +91,6 @@ struct RelayNxt { double px[64], py[64], heading[64], t_rem[64]; float gx[64], g
 #endif
 #ifndef CAVOID_RELAY_PRIO_C
 #define CAVOID_RELAY_PRIO_C 1
-#endif
-#ifndef CAVOID_RELAY_PRIO_TAIL
-#define CAVOID_RELAY_PRIO_TAIL 3          /* D, P and L while they make the last step's observation together (-1: as they were) */
 #endif
 // development: timing-only ablations of the roles (WRONG results; profiles/r06_w_relay_prio_ablation.txt): 1 the consumers make no observation
 // (they only free their ring slots), 2 P's distance loop left out, 4 D's advance without its sine / cosine, 8 D never waits for P's verdict and
@@ -961,12 +959,7 @@ __global__ void __launch_bounds__(64 * (3 + kRelayMaxConsumers), 1) env_relay_ke
     }
     // ================================================ D, P, L: the LAST step's observation, together =======================================
     if constexpr (kCoop) {
-        if (coop_role) {
-            // the launch's tail is this observation: all three at the loop's top priority (the loader ran BELOW the consumers, two of which are
-            // still at their last steps on the same SIMDs)
-            if (CAVOID_RELAY_PRIO_TAIL >= 0) __builtin_amdgcn_s_setprio(CAVOID_RELAY_PRIO_TAIL);
-            relay_coop_last<N>(smem);
-        }
+        if (coop_role) relay_coop_last<N>(smem);
     }
 }
 
