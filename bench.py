@@ -958,6 +958,9 @@ def main() -> None:
               "ms_per_step_max": max(times) * 1e3 / args.steps, "ms_per_step_first_rep": times[0] * 1e3 / args.steps,
               "restarts_in_timed_region": restarts[mid], "restarts_per_rep_min_max": [min(restarts), max(restarts)],
               "preroll_steps": preroll,
+              "host_path": ("the region's launches are prepared once (BatchedCollisionAvoidanceEnv.prepared_autoreset_n: arguments checked and pointers converted outside "
+                            "the clock; the same cavoid_step_autoreset_n calls, the look-ahead refill included when one is due) and Python's collector is paused around "
+                            "the repetitions") if prepared is not None else "step-and-gather calls through ShardedEnv",
               "note": "each repetition = the K timed steps bracketed by barrier + synchronize; value / ms_per_step = the median repetition; "
                       "restarts = worlds of THIS rank whose episode ended and restarted inside that repetition (in-kernel auto-reset)"}
 
